@@ -1,0 +1,356 @@
+"""ctypes binding of ``libbigdl_hip.so`` — the gfx950 kernels.
+
+Every wrapper validates shapes/dtypes/devices on the host before the launch (a kernel that
+faults can take the whole node down), launches on PyTorch's current HIP stream (so calls are
+capturable into a hipGraph via ``torch.cuda.graph``) and raises if the native launcher rejects
+the call.  There is no silent fallback: on a GPU box a missing library is an error.
+"""
+from __future__ import annotations
+
+import ctypes
+from pathlib import Path
+
+import torch
+
+from .. import qtypes as Q
+
+_LIB = None
+_LIB_PATH = Path(__file__).resolve().parent.parent / "lib" / "libbigdl_hip.so"
+
+OUT_F16, OUT_BF16, OUT_F32 = 0, 1, 2
+ACT = {None: 0, "none": 0, "silu": 1, "swish": 1, "gelu": 2, "gelu_tanh": 3, "gelu_pytorch_tanh": 3,
+       "gelu_new": 3, "gelu_fast": 3, "relu": 4}
+_DT = {torch.float16: 0, torch.bfloat16: 1, torch.float32: 2}
+
+
+def available() -> bool:
+    return torch.cuda.is_available() and _LIB_PATH.exists()
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not _LIB_PATH.exists():
+            raise RuntimeError(
+                f"{_LIB_PATH} is missing: build it with `python -m bigdl_amd.csrc.build` "
+                "(hipcc cross-compiles gfx950 without a GPU)")
+        L = ctypes.CDLL(str(_LIB_PATH))
+        vp, i64, ci, cf = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
+        L.bigdl_gemv_lowbit.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, cf, cf, ci, ci, ci, ci, ci, ci, ci, ci, vp]
+        L.bigdl_attn_decode.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ci, cf, cf] + [ci] * 10 + [vp]
+        L.bigdl_attn_decode_ws_floats.argtypes = [ci] * 6
+        L.bigdl_attn_decode_ws_floats.restype = i64
+        L.bigdl_rope_append.argtypes = [vp, vp, vp, vp, vp, vp, cf] + [ci] * 10 + [vp]
+        L.bigdl_rms_norm.argtypes = [vp, vp, vp, vp, vp, i64, ci, i64, cf, cf, ci, vp]
+        L.bigdl_layer_norm.argtypes = [vp, vp, vp, vp, i64, ci, i64, cf, ci, vp]
+        L.bigdl_act_mul.argtypes = [vp, vp, vp, i64, ci, i64, i64, i64, ci, ci, vp]
+        L.bigdl_softmax_inplace.argtypes = [vp, i64, ci, cf, ci, vp]
+        L.bigdl_rope_inplace.argtypes = [vp, i64, i64, i64, vp, vp, vp, vp, i64, i64, ci, ci, ci, ci, ci, ci, ci, cf, ci, vp]
+        L.bigdl_to_e5m2.argtypes = [vp, vp, i64, ci, i64, i64, ci, vp]
+        L.bigdl_from_e5m2.argtypes = [vp, vp, i64, ci, i64, i64, ci, vp]
+        L.bigdl_repetition_penalty.argtypes = [vp, vp, ci, ci, ci, cf, ci, vp]
+        L.bigdl_argmax.argtypes = [vp, vp, i64, ci, i64, ci, vp]
+        L.bigdl_dequant_t16.argtypes = [vp, vp, ci, ci, i64, ci, ci, vp]
+        L.bigdl_dequant_rows.argtypes = [vp, vp, vp, i64, i64, ci, ci, i64, ci, vp]
+        _LIB = L
+    return _LIB
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError(f"{what}: native launcher rejected the call (code {rc})")
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and t.device.type != "cuda":
+            raise ValueError("expected tensors on the HIP device")
+
+
+def _out_type(dtype) -> int:
+    try:
+        return _DT[dtype]
+    except KeyError:
+        raise ValueError(f"unsupported dtype {dtype}")
+
+
+def gemv_lowbit(x, w, qtype, out_features, in_features, *, w2=None, bias=None, bias2=None, residual=None,
+                gamma=None, eps=1e-6, gamma_offset=0.0, act=None, out=None, out_dtype=None):
+    """``y = act(rmsnorm?(x) @ dequant(w)^T + bias) [* (x @ dequant(w2)^T + bias2)] [+ residual]``
+
+    x: [M, K] fp16 (M <= 64, or <= 32 with w2), row stride multiple of 8.  w/w2: T16 device buffers.
+    """
+    _need_cuda(x, w, w2, bias, bias2, residual, gamma, out)
+    if x.dim() != 2 or x.dtype != torch.float16 or x.stride(1) != 1:
+        raise ValueError("x must be a 2-D fp16 tensor with contiguous rows")
+    m, k = x.shape
+    if k != in_features:
+        raise ValueError(f"x has {k} features, weight expects {in_features}")
+    if qtype not in Q.T16_QTYPES:
+        raise ValueError(f"qtype {qtype} has no fused GEMV kernel")
+    from .host import device_nbytes
+    need = device_nbytes(qtype, out_features, in_features)
+    for ww in (w, w2):
+        if ww is not None and ww.numel() * ww.element_size() != need:
+            raise ValueError(f"weight buffer has {ww.numel() * ww.element_size()} bytes, expected {need} "
+                             f"for [{out_features}, {in_features}] qtype {qtype}")
+    out_dtype = out_dtype or (out.dtype if out is not None else torch.float16)
+    if out is None:
+        out = torch.empty((m, out_features), dtype=out_dtype, device=x.device)
+    if out.shape != (m, out_features) or out.stride(1) != 1 or out.dtype != out_dtype:
+        raise ValueError("bad out tensor")
+    for b in (bias, bias2):
+        if b is not None and (b.dtype != torch.float16 or b.numel() != out_features or not b.is_contiguous()):
+            raise ValueError("bias must be contiguous fp16 [out_features]")
+    if residual is not None and (residual.shape != out.shape or residual.dtype != out.dtype
+                                 or residual.stride() != out.stride()):
+        raise ValueError("residual must match out")
+    if gamma is not None and (gamma.dtype != torch.float16 or gamma.numel() != k or not gamma.is_contiguous()):
+        raise ValueError("gamma must be contiguous fp16 [in_features]")
+    rc = lib().bigdl_gemv_lowbit(_ptr(x), _ptr(w), _ptr(w2), _ptr(out), _ptr(bias), _ptr(bias2), _ptr(residual),
+                                 _ptr(gamma), eps, gamma_offset, m, out_features, k, x.stride(0), out.stride(0),
+                                 qtype, ACT[act], _out_type(out_dtype), _stream())
+    _check(rc, "gemv_lowbit")
+    return out
+
+
+def dequant_t16(w, qtype, out_features, in_features, dtype=torch.float16, out=None):
+    _need_cuda(w, out)
+    if out is None:
+        out = torch.empty((out_features, in_features), dtype=dtype, device=w.device)
+    if out.shape != (out_features, in_features) or out.stride(1) != 1 or out.dtype != dtype:
+        raise ValueError("bad out tensor")
+    from .host import device_nbytes
+    if w.numel() * w.element_size() != device_nbytes(qtype, out_features, in_features):
+        raise ValueError("weight buffer size does not match the tiled layout")
+    rc = lib().bigdl_dequant_t16(_ptr(w), _ptr(out), out_features, in_features, out.stride(0), qtype,
+                                 _out_type(dtype), _stream())
+    _check(rc, "dequant_t16")
+    return out
+
+
+def dequant_rows(w, qtype, n_rows, k, ids=None, dtype=torch.float16):
+    """host-layout block rows on the device -> dense rows (optionally gathered by ``ids``)."""
+    _need_cuda(w, ids)
+    from .host import ggml_qk_size, ggml_type_size
+    if w.numel() * w.element_size() != n_rows * (k // ggml_qk_size(qtype)) * ggml_type_size(qtype):
+        raise ValueError("weight buffer size does not match [n_rows, k]")
+    if ids is not None:
+        ids = ids.to(torch.int64).contiguous()
+        n_out, shape = ids.numel(), (*ids.shape, k)
+    else:
+        n_out, shape = n_rows, (n_rows, k)
+    out = torch.empty(shape, dtype=dtype, device=w.device)
+    if n_out == 0:
+        return out
+    rc = lib().bigdl_dequant_rows(_ptr(w), _ptr(ids), _ptr(out), n_out, n_rows, k, qtype, k, _out_type(dtype),
+                                  _stream())
+    _check(rc, "dequant_rows")
+    return out
+
+
+def rms_norm(x, weight, eps, *, residual=None, res_out=None, offset=0.0, out=None):
+    _need_cuda(x, weight, residual, res_out, out)
+    h = x.shape[-1]
+    if x.stride(-1) != 1:
+        x = x.contiguous()
+    x2 = x.reshape(-1, h) if x.is_contiguous() else x
+    if x2.dim() != 2:
+        x2 = x.contiguous().reshape(-1, h)
+    if weight.dtype != x.dtype:
+        weight = weight.to(x.dtype)
+    if out is None:
+        out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    if residual is not None and not residual.is_contiguous():
+        residual = residual.contiguous()
+    rc = lib().bigdl_rms_norm(_ptr(x2), _ptr(residual), _ptr(weight.contiguous()), _ptr(out), _ptr(res_out),
+                              x2.shape[0], h, x2.stride(0), eps, offset, _out_type(x.dtype), _stream())
+    _check(rc, "rms_norm")
+    return out
+
+
+def layer_norm(x, weight, bias, eps):
+    _need_cuda(x, weight, bias)
+    h = x.shape[-1]
+    x2 = x.contiguous().reshape(-1, h)
+    out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    w = weight.to(x.dtype).contiguous()
+    b = None if bias is None else bias.to(x.dtype).contiguous()
+    rc = lib().bigdl_layer_norm(_ptr(x2), _ptr(w), _ptr(b), _ptr(out), x2.shape[0], h, x2.stride(0), eps,
+                                _out_type(x.dtype), _stream())
+    _check(rc, "layer_norm")
+    return out
+
+
+def act_mul(gate, up, act="silu", out=None):
+    """out = act(gate) * up over the last dim; gate/up may be strided row views; out defaults to gate (in place)."""
+    _need_cuda(gate, up, out)
+    h = gate.shape[-1]
+    g2, u2 = gate.reshape(-1, h) if gate.dim() != 2 else gate, up.reshape(-1, h) if up.dim() != 2 else up
+    if g2.stride(1) != 1 or u2.stride(1) != 1:
+        raise ValueError("last dim must be contiguous")
+    o2 = g2 if out is None else (out.reshape(-1, h) if out.dim() != 2 else out)
+    rc = lib().bigdl_act_mul(_ptr(g2), _ptr(u2), _ptr(o2), g2.shape[0], h, g2.stride(0), u2.stride(0), o2.stride(0),
+                             ACT[act], _out_type(gate.dtype), _stream())
+    _check(rc, "act_mul")
+    return gate if out is None else out
+
+
+def softmax_inplace(x, scale=1.0):
+    _need_cuda(x)
+    if not x.is_contiguous():
+        raise ValueError("softmax_inplace needs a contiguous tensor")
+    L = x.shape[-1]
+    rc = lib().bigdl_softmax_inplace(_ptr(x), x.numel() // L, L, scale, _out_type(x.dtype), _stream())
+    _check(rc, "softmax_inplace")
+    return x
+
+
+def rope_inplace(x, *, position_ids=None, inv_freq=None, cos=None, sin=None, interleaved=False, rot_dim=None,
+                 scaling=1.0):
+    """In-place rotary embedding on a [B, H, S, D] view (any strides with contiguous last dim)."""
+    _need_cuda(x, position_ids, inv_freq, cos, sin)
+    if x.dim() != 4 or x.stride(3) != 1:
+        raise ValueError("x must be [B, H, S, D] with contiguous last dim")
+    b, h, s, d = x.shape
+    tab_sb = tab_ld = tab_full = 0
+    if inv_freq is not None:
+        inv_freq = inv_freq.to(torch.float32).contiguous()
+        rot = rot_dim or inv_freq.numel() * 2
+        pos = position_ids.to(torch.int64).expand(b, s).contiguous()
+    else:
+        if cos.dim() == 2:
+            cos, sin = cos[None], sin[None]
+        cos, sin = cos.to(x.dtype).contiguous(), sin.to(x.dtype).contiguous()
+        if cos.shape[-2] != s:
+            raise ValueError("cos/sin must have S rows")
+        tw = cos.shape[-1]
+        rot = rot_dim or (tw if tw <= d and tw * 2 > d else tw * 2 if tw * 2 <= d else tw)
+        tab_full = 1 if tw == rot else 0
+        tab_ld = tw
+        tab_sb = 0 if cos.shape[0] == 1 else s * tw
+        pos = None
+    rc = lib().bigdl_rope_inplace(_ptr(x), x.stride(0), x.stride(1), x.stride(2), _ptr(pos), _ptr(inv_freq),
+                                  _ptr(cos), _ptr(sin), tab_sb, tab_ld, tab_full, b, h, s, d, rot,
+                                  int(bool(interleaved)), scaling, _out_type(x.dtype), _stream())
+    _check(rc, "rope_inplace")
+    return x
+
+
+def to_e5m2(src, dst):
+    """src [..., D] float -> dst uint8 view of identical logical shape (last dim contiguous on both)."""
+    _need_cuda(src, dst)
+    d = src.shape[-1]
+    s2, d2 = src.reshape(-1, d), dst.reshape(-1, d)
+    rc = lib().bigdl_to_e5m2(_ptr(s2), _ptr(d2), s2.shape[0], d, s2.stride(0), d2.stride(0), _out_type(src.dtype),
+                             _stream())
+    _check(rc, "to_e5m2")
+    return dst
+
+
+def from_e5m2(src, dst):
+    _need_cuda(src, dst)
+    d = src.shape[-1]
+    s2, d2 = src.reshape(-1, d), dst.reshape(-1, d)
+    rc = lib().bigdl_from_e5m2(_ptr(s2), _ptr(d2), s2.shape[0], d, s2.stride(0), d2.stride(0), _out_type(dst.dtype),
+                               _stream())
+    _check(rc, "from_e5m2")
+    return dst
+
+
+def repetition_penalty_inplace(scores, input_ids, penalty):
+    _need_cuda(scores, input_ids)
+    if not scores.is_contiguous():
+        raise ValueError("scores must be contiguous")
+    ids = input_ids.to(torch.int64).contiguous()
+    b, v = scores.shape
+    rc = lib().bigdl_repetition_penalty(_ptr(scores), _ptr(ids), b, ids.shape[1], v, float(penalty),
+                                        _out_type(scores.dtype), _stream())
+    _check(rc, "repetition_penalty")
+    return scores
+
+
+def argmax(x, out=None):
+    _need_cuda(x, out)
+    v = x.shape[-1]
+    x2 = x.reshape(-1, v)
+    if x2.stride(1) != 1:
+        x2 = x2.contiguous()
+    if out is None:
+        out = torch.empty(x2.shape[0], dtype=torch.int64, device=x.device)
+    rc = lib().bigdl_argmax(_ptr(x2), _ptr(out), x2.shape[0], v, x2.stride(0), _out_type(x.dtype), _stream())
+    _check(rc, "argmax")
+    return out.reshape(x.shape[:-1])
+
+
+def attn_decode_ws_floats(b, hq, hkv, q_len, d, splits) -> int:
+    return lib().bigdl_attn_decode_ws_floats(b, hq, hkv, q_len, d, splits)
+
+
+def rope_append(qkv, k_cache, v_cache, past_len, inv_freq, *, n_heads, n_kv_heads, head_dim, q_len, batch,
+                rot_dim=None, interleaved=False, attn_scaling=1.0, position_ids=None):
+    """Rotate q (in place in ``qkv``) and k, and append k / v^T of the ``q_len`` new tokens to the caches."""
+    _need_cuda(qkv, k_cache, v_cache, past_len, inv_freq, position_ids)
+    if qkv.dtype != torch.float16 or qkv.dim() != 2 or qkv.stride(1) != 1:
+        raise ValueError("qkv must be 2-D fp16")
+    if qkv.shape[0] != batch * q_len or qkv.shape[1] < (n_heads + 2 * n_kv_heads) * head_dim:
+        raise ValueError("qkv shape does not match batch/q_len/heads")
+    lmax = k_cache.shape[2]
+    if tuple(k_cache.shape) != (batch, n_kv_heads, lmax, head_dim) or tuple(v_cache.shape) != (batch, n_kv_heads, head_dim, lmax):
+        raise ValueError("cache shapes must be K [B,Hkv,L,D], V^T [B,Hkv,D,L]")
+    if not (k_cache.is_contiguous() and v_cache.is_contiguous()) or k_cache.dtype != v_cache.dtype:
+        raise ValueError("caches must be contiguous and of one dtype")
+    fp8 = k_cache.dtype == torch.uint8
+    if not fp8 and k_cache.dtype != torch.float16:
+        raise ValueError("cache dtype must be float16 or uint8 (e5m2)")
+    if past_len.dtype != torch.int32 or past_len.numel() != batch:
+        raise ValueError("past_len must be int32 [batch]")
+    if inv_freq is not None:
+        inv_freq = inv_freq.to(torch.float32).contiguous()
+        rot_dim = rot_dim or inv_freq.numel() * 2
+    if position_ids is not None and (position_ids.dtype != torch.int32 or position_ids.numel() != batch * q_len):
+        raise ValueError("position_ids must be int32 [batch*q_len]")
+    rc = lib().bigdl_rope_append(_ptr(qkv), _ptr(k_cache), _ptr(v_cache), _ptr(past_len), _ptr(inv_freq),
+                                 _ptr(position_ids), attn_scaling, batch, n_heads, n_kv_heads, q_len, qkv.stride(0),
+                                 lmax, head_dim, rot_dim or 0, int(bool(interleaved)), int(fp8), _stream())
+    _check(rc, "rope_append")
+
+
+def attn_decode(qkv, k_cache, v_cache, past_len, out, ws, counters, *, n_heads, n_kv_heads, head_dim, q_len, batch,
+                scale, splits, softcap=0.0, window=0, mask=None):
+    _need_cuda(qkv, k_cache, v_cache, past_len, out, ws, counters, mask)
+    lmax = k_cache.shape[2]
+    if qkv.dtype != torch.float16 or out.dtype != torch.float16:
+        raise ValueError("qkv/out must be fp16")
+    if tuple(out.shape) != (batch * q_len, n_heads * head_dim) or not out.is_contiguous():
+        raise ValueError("out must be contiguous [batch*q_len, n_heads*head_dim]")
+    if tuple(k_cache.shape) != (batch, n_kv_heads, lmax, head_dim) or tuple(v_cache.shape) != (batch, n_kv_heads, head_dim, lmax):
+        raise ValueError("cache shapes must be K [B,Hkv,L,D], V^T [B,Hkv,D,L]")
+    if lmax % 128:
+        raise ValueError("cache capacity must be a multiple of 128")
+    fp8 = k_cache.dtype == torch.uint8
+    need = attn_decode_ws_floats(batch, n_heads, n_kv_heads, q_len, head_dim, splits)
+    if ws.dtype != torch.float32 or ws.numel() < need:
+        raise ValueError(f"workspace needs {need} floats")
+    if counters.dtype != torch.int32 or counters.numel() < batch * n_kv_heads:
+        raise ValueError("counters must be int32 [batch*n_kv_heads]")
+    if past_len.dtype != torch.int32 or past_len.numel() != batch:
+        raise ValueError("past_len must be int32 [batch]")
+    mask_ld = 0
+    if mask is not None:
+        if mask.dtype != torch.float16 or not mask.is_contiguous() or mask.shape[0] != batch or mask.shape[-2] != q_len:
+            raise ValueError("mask must be contiguous fp16 [B, q_len, L]")
+        mask_ld = mask.shape[-1]
+    rc = lib().bigdl_attn_decode(_ptr(qkv), _ptr(k_cache), _ptr(v_cache), _ptr(out), _ptr(ws), _ptr(counters),
+                                 _ptr(past_len), _ptr(mask), mask_ld, scale, softcap, batch, n_heads, n_kv_heads,
+                                 q_len, qkv.stride(0), lmax, head_dim, splits, window, int(fp8), _stream())
+    _check(rc, "attn_decode")
+    return out

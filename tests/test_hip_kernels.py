@@ -1,0 +1,265 @@
+"""Numerics of the gfx950 kernels against plain PyTorch fp32 references of the same op."""
+import math
+
+import pytest
+import torch
+
+from bigdl_amd import qtypes as Q
+from bigdl_amd.ops import host
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from bigdl_amd.ops import hip as h
+    h.lib()
+    return h
+
+
+def _quant_dev(w, qt):
+    n, k = w.shape
+    buf = host.quantize(w, qt)
+    raw = buf.view(torch.uint8) if buf.dtype != torch.uint8 else buf
+    ref = host.dequantize(raw, qt, w.shape)
+    dev = host.relayout_to_device(raw, qt, n, k).cuda()
+    return dev, ref
+
+
+T16 = ["sym_int4", "asym_int4", "woq_int4", "fp4", "nf4", "sym_int5", "asym_int5", "fp6", "sym_int8", "fp8_e4m3",
+       "fp8_e5m2"]
+
+
+@pytest.mark.parametrize("name", T16)
+@pytest.mark.parametrize("shape", [(64, 256), (48, 384), (200, 1024)])
+def test_dequant_t16(hip, name, shape):
+    torch.manual_seed(0)
+    qt = Q.ggml_tensor_qtype[name]
+    n, k = shape
+    w = torch.randn(n, k) * 0.05
+    dev, ref = _quant_dev(w, qt)
+    out = hip.dequant_t16(dev, qt, n, k, dtype=torch.float32).cpu()
+    torch.testing.assert_close(out, ref, rtol=1e-3, atol=1e-6)
+    out16 = hip.dequant_t16(dev, qt, n, k, dtype=torch.float16).cpu().float()
+    torch.testing.assert_close(out16, ref, rtol=2e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("name", T16)
+@pytest.mark.parametrize("m", [1, 3, 16, 33])
+def test_gemv_matches_dequant_reference(hip, name, m):
+    torch.manual_seed(1)
+    qt = Q.ggml_tensor_qtype[name]
+    n, k = 96, 640
+    w = torch.randn(n, k) * 0.05
+    x = torch.randn(m, k)
+    dev, ref_w = _quant_dev(w, qt)
+    xh = x.half()
+    ref = xh.float() @ ref_w.t()
+    out = hip.gemv_lowbit(xh.cuda(), dev, qt, n, k, out_dtype=torch.float32).cpu()
+    torch.testing.assert_close(out, ref, rtol=2e-3, atol=2e-3)
+
+
+def test_gemv_fused_norm_gate_up_bias_residual(hip):
+    torch.manual_seed(2)
+    qt = Q.SYM_INT4
+    n, k, m = 176, 512, 2
+    wg, wu = torch.randn(n, k) * 0.05, torch.randn(n, k) * 0.05
+    dg, rg = _quant_dev(wg, qt)
+    du, ru = _quant_dev(wu, qt)
+    x = torch.randn(m, k).half()
+    gamma = (1 + 0.1 * torch.randn(k)).half()
+    eps = 1e-5
+    xf = x.float()
+    xn = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps) * gamma.float()
+    ref = torch.nn.functional.silu(xn @ rg.t()) * (xn @ ru.t())
+    out = hip.gemv_lowbit(x.cuda(), dg, qt, n, k, w2=du, gamma=gamma.cuda(), eps=eps, act="silu",
+                          out_dtype=torch.float32).cpu()
+    torch.testing.assert_close(out, ref, rtol=5e-3, atol=5e-3)
+    # bias + residual, fp16 output
+    bias = torch.randn(n).half()
+    res = torch.randn(m, n).half()
+    ref2 = xf @ rg.t() + bias.float() + res.float()
+    out2 = hip.gemv_lowbit(x.cuda(), dg, qt, n, k, bias=bias.cuda(), residual=res.cuda(), out_dtype=torch.float16).cpu()
+    torch.testing.assert_close(out2.float(), ref2, rtol=5e-3, atol=2e-2)
+
+
+@pytest.mark.parametrize("name", ["q4_k", "q6_k", "q2_k", "q5_k", "nf3", "fp6_k", "sym_int4", "nf4"])
+def test_dequant_rows_host_layout(hip, name):
+    torch.manual_seed(3)
+    qt = Q.ggml_tensor_qtype[name]
+    w = torch.randn(50, 512) * 0.1
+    buf = host.quantize(w, qt)
+    raw = buf.view(torch.uint8) if buf.dtype != torch.uint8 else buf
+    ref = host.dequantize(raw, qt, w.shape)
+    out = hip.dequant_rows(raw.cuda(), qt, 50, 512, dtype=torch.float32).cpu()
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-6)
+    ids = torch.tensor([[3, 49, 0], [7, 7, 12]])
+    out = hip.dequant_rows(raw.cuda(), qt, 50, 512, ids=ids.cuda(), dtype=torch.float32).cpu()
+    torch.testing.assert_close(out, ref[ids], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
+def test_rms_norm_and_layer_norm(hip, dtype):
+    torch.manual_seed(4)
+    x = torch.randn(5, 7, 4096).to(dtype)
+    w = (1 + 0.1 * torch.randn(4096)).to(dtype)
+    b = (0.1 * torch.randn(4096)).to(dtype)
+    xf = x.float()
+    ref = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6) * w.float()
+    out = hip.rms_norm(x.cuda(), w.cuda(), 1e-6).cpu().float()
+    tol = dict(rtol=2e-2, atol=2e-2) if dtype != torch.float32 else dict(rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(out, ref, **tol)
+    res = torch.randn_like(x)
+    res_out = torch.empty_like(x).cuda()
+    out = hip.rms_norm(x.cuda(), w.cuda(), 1e-6, residual=res.cuda(), res_out=res_out, offset=1.0).cpu().float()
+    s = xf + res.float()
+    ref = s * torch.rsqrt(s.pow(2).mean(-1, keepdim=True) + 1e-6) * (1 + w.float())
+    torch.testing.assert_close(out, ref, **tol)
+    torch.testing.assert_close(res_out.cpu().float(), s, **tol)
+    ref = torch.nn.functional.layer_norm(xf, (4096,), w.float(), b.float(), 1e-5)
+    out = hip.layer_norm(x.cuda(), w.cuda(), b.cuda(), 1e-5).cpu().float()
+    torch.testing.assert_close(out, ref, **tol)
+
+
+def test_act_mul_softmax_argmax_penalty(hip):
+    torch.manual_seed(5)
+    gu = torch.randn(6, 2 * 1024).half().cuda()
+    gate, up = gu[:, :1024], gu[:, 1024:]
+    ref = torch.nn.functional.silu(gate.float()) * up.float()
+    out = torch.empty(6, 1024, dtype=torch.float16, device="cuda")
+    hip.act_mul(gate, up, "silu", out=out)
+    torch.testing.assert_close(out.float(), ref, rtol=2e-3, atol=2e-3)
+    s = torch.randn(3, 4, 5, 333).cuda()
+    ref = torch.softmax(s, -1)
+    hip.softmax_inplace(s)
+    torch.testing.assert_close(s, ref, rtol=1e-5, atol=1e-6)
+    logits = torch.randn(4, 32000).half().cuda()
+    assert torch.equal(hip.argmax(logits), logits.float().argmax(-1))
+    scores = torch.randn(2, 1000).cuda()
+    ids = torch.randint(0, 1000, (2, 17)).cuda()
+    ref = scores.clone()
+    g = torch.gather(ref, 1, ids)
+    ref.scatter_(1, ids, torch.where(g < 0, g * 1.3, g / 1.3))
+    hip.repetition_penalty_inplace(scores, ids, 1.3)
+    torch.testing.assert_close(scores, ref)
+
+
+@pytest.mark.parametrize("interleaved", [False, True])
+def test_rope_inplace_strided(hip, interleaved):
+    torch.manual_seed(6)
+    b, h, s, d, rot = 2, 4, 9, 128, 64
+    qkv = torch.randn(b, s, 3 * h * d).half().cuda()
+    q = qkv[..., : h * d].view(b, s, h, d).transpose(1, 2)  # strided view, like the fused-qkv split
+    q_ref = q.float().clone()
+    pos = torch.arange(5, 5 + s)[None].expand(b, s).cuda()
+    inv_freq = 1.0 / (10000 ** (torch.arange(0, rot, 2).float() / rot)).cuda()
+    ang = pos[:, None, :, None].float() * inv_freq
+    cos, sin = ang.cos(), ang.sin()
+    xr = q_ref[..., :rot]
+    if interleaved:
+        x0, x1 = xr[..., 0::2], xr[..., 1::2]
+        y = torch.stack([x0 * cos - x1 * sin, x1 * cos + x0 * sin], -1).flatten(-2)
+    else:
+        x0, x1 = xr[..., : rot // 2], xr[..., rot // 2:]
+        y = torch.cat([x0 * cos - x1 * sin, x1 * cos + x0 * sin], -1)
+    ref = torch.cat([y, q_ref[..., rot:]], -1)
+    hip.rope_inplace(q, position_ids=pos, inv_freq=inv_freq, interleaved=interleaved, rot_dim=rot)
+    torch.testing.assert_close(q.float(), ref, rtol=2e-3, atol=2e-3)
+
+
+def test_e5m2_roundtrip(hip):
+    x = (torch.randn(3, 5, 128) * 4).half().cuda()
+    q = torch.empty(3, 5, 128, dtype=torch.uint8, device="cuda")
+    hip.to_e5m2(x, q)
+    ref = x.to(torch.float8_e5m2)
+    assert torch.equal(q.view(torch.float8_e5m2).float(), ref.float())
+    back = torch.empty_like(x)
+    hip.from_e5m2(q, back)
+    assert torch.equal(back.float(), ref.float())
+
+
+def _ref_attention(q, k, v, scale, softcap=0.0, window=0, past=0):
+    # q [B,Hq,S,D], k/v [B,Hkv,L,D]; causal over the last S positions
+    b, hq, s, d = q.shape
+    hkv, L = k.shape[1], k.shape[2]
+    k = k.repeat_interleave(hq // hkv, 1)
+    v = v.repeat_interleave(hq // hkv, 1)
+    sc = (q @ k.transpose(-1, -2)) * scale
+    if softcap:
+        sc = softcap * torch.tanh(sc / softcap)
+    qpos = past + torch.arange(s)[:, None]
+    kpos = torch.arange(L)[None]
+    m = kpos > qpos
+    if window:
+        m |= kpos < qpos - window + 1
+    sc = sc.masked_fill(m, float("-inf"))
+    return torch.softmax(sc, -1) @ v
+
+
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("cfg", [(1, 32, 32, 128, 1, 1000), (2, 32, 8, 128, 1, 300), (1, 8, 2, 64, 5, 77),
+                                 (1, 4, 4, 256, 3, 513), (2, 6, 2, 96, 2, 130)])
+def test_rope_append_and_attn_decode(hip, fp8, cfg):
+    torch.manual_seed(7)
+    b, hq, hkv, d, q_len, past = cfg
+    lmax = 1152
+    ld = (hq + 2 * hkv) * d
+    cache_dtype = torch.uint8 if fp8 else torch.float16
+    kc = torch.zeros(b, hkv, lmax, d, dtype=cache_dtype, device="cuda")
+    vc = torch.zeros(b, hkv, d, lmax, dtype=cache_dtype, device="cuda")
+    inv_freq = 1.0 / (10000 ** (torch.arange(0, d, 2).float() / d))
+
+    def rope(x, pos):  # x [B,H,S,D]
+        ang = pos[None, None, :, None].float() * inv_freq
+        x0, x1 = x[..., : d // 2], x[..., d // 2:]
+        return torch.cat([x0 * ang.cos() - x1 * ang.sin(), x1 * ang.cos() + x0 * ang.sin()], -1)
+
+    def q8(t):
+        return t.half().to(torch.float8_e5m2).float() if fp8 else t.half().float()
+
+    # fill the past through the same kernel in chunks (exercises append at several positions)
+    k_all = torch.zeros(b, hkv, past + q_len, d)
+    v_all = torch.zeros(b, hkv, past + q_len, d)
+    pos0 = 0
+    past_len = torch.zeros(b, dtype=torch.int32, device="cuda")
+    chunks = [c for c in (past // 2, past - past // 2, q_len) if c > 0]
+    for ci, c in enumerate(chunks):
+        qkv = (torch.randn(b * c, ld) * 0.5).half()
+        x = qkv.float().view(b, c, hq + 2 * hkv, d).transpose(1, 2)
+        pos = torch.arange(pos0, pos0 + c)
+        k_all[:, :, pos0:pos0 + c] = q8(rope(x[:, hq:hq + hkv], pos))
+        v_all[:, :, pos0:pos0 + c] = q8(x[:, hq + hkv:])
+        qkv_d = qkv.cuda()
+        past_len.fill_(pos0)
+        hip.rope_append(qkv_d, kc, vc, past_len, inv_freq.cuda(), n_heads=hq, n_kv_heads=hkv, head_dim=d, q_len=c,
+                        batch=b)
+        q_rot = rope(x[:, :hq], pos)
+        got_q = qkv_d.cpu().float().view(b, c, hq + 2 * hkv, d).transpose(1, 2)[:, :hq]
+        torch.testing.assert_close(got_q, q_rot, rtol=3e-3, atol=3e-3)
+        last = (qkv_d, q_rot, c, pos0)
+        pos0 += c
+    # cache contents
+    if fp8:
+        kc_f = kc.view(torch.float8_e5m2).float().cpu()
+        vc_f = vc.view(torch.float8_e5m2).float().cpu()
+    else:
+        kc_f, vc_f = kc.float().cpu(), vc.float().cpu()
+    tol = dict(rtol=0.13, atol=2e-2) if fp8 else dict(rtol=3e-3, atol=3e-3)
+    torch.testing.assert_close(kc_f[:, :, :pos0], k_all, **tol)
+    torch.testing.assert_close(vc_f[:, :, :, :pos0].transpose(-1, -2), v_all, **tol)
+
+    qkv_d, q_rot, c, p0 = last
+    scale = 1.0 / math.sqrt(d)
+    for splits, softcap, window in ((1, 0.0, 0), (4, 0.0, 0), (3, 30.0, 0), (2, 0.0, 64)):
+        out = torch.empty(b * c, hq * d, dtype=torch.float16, device="cuda")
+        ws = torch.empty(hip.attn_decode_ws_floats(b, hq, hkv, c, d, splits), dtype=torch.float32, device="cuda")
+        counters = torch.zeros(b * hkv, dtype=torch.int32, device="cuda")
+        past_len.fill_(p0)
+        hip.attn_decode(qkv_d, kc, vc, past_len, out, ws, counters, n_heads=hq, n_kv_heads=hkv, head_dim=d, q_len=c,
+                        batch=b, scale=scale, splits=splits, softcap=softcap, window=window)
+        # reference on exactly what the cache holds
+        ref = _ref_attention(q_rot.half().float(), kc_f[:, :, :pos0], vc_f[:, :, :, :pos0].transpose(-1, -2), scale,
+                             softcap, window, past=p0)
+        got = out.cpu().float().view(b, c, hq, d).transpose(1, 2)
+        torch.testing.assert_close(got, ref, rtol=1e-2, atol=1e-2)
+        assert int(counters.abs().sum()) == 0
