@@ -1,0 +1,358 @@
+"""Quantized parameter + linear modules.
+
+Capability map to the reference (python/llm/src/ipex_llm/transformers/low_bit_linear.py):
+``FP4Params`` :312-459, ``ggml_convert_qtype`` :104-175, ``MatMulLowBit`` :500-541,
+``LowBitLinear`` :573-715, ``FP16Linear``/``BF16Linear`` :718-873, vLLM shims :876-908.
+
+MI355X design differences:
+* one device code path (HIP, gfx950): the fused MFMA GEMV serves 1..64 rows, larger row counts
+  dequantize tile-wise to fp16 and use the hipBLASLt GEMM; there is no per-device heuristic table.
+* the host keeps ggml block order (what checkpoints store); ``.to('cuda')`` re-tiles to the
+  "T16" kernel layout on the host and does a single H2D copy; ``.to('cpu')`` reverses it.
+* tensor-parallel all-reduce goes through ``torch.distributed`` (RCCL) on ``mp_group``.
+"""
+from __future__ import annotations
+
+import os
+from functools import reduce
+from operator import mul
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .. import qtypes as Q
+from ..ops import host
+from ..utils.common import invalidInputError
+
+TORCH_LINEAR_THRESHOLD = int(os.getenv("BIGDL_LLM_LINEAR_THRESHOLD", "512"))
+# rows above which the device path dequantizes + calls the dense GEMM instead of the fused GEMV
+GEMV_MAX_ROWS = 64
+
+
+def get_block_size(qtype) -> int:
+    return host.ggml_qk_size(Q.qtype_id(qtype))
+
+
+def get_qk_size(qtype: int) -> int:
+    return host.ggml_qk_size(qtype)
+
+
+def ggml_convert_qtype(tensor: torch.Tensor, qtype: int, device=None, convert_shape_only=False,
+                       imatrix: torch.Tensor = None, in_features: int = None, enable_scale_search: bool = False):
+    invalidInputError(tensor.dtype == torch.float, "Input tensor must be float32")
+    return host.quantize(tensor, qtype, imatrix=imatrix if qtype in Q.K_QTYPES or qtype in Q.RTN_QTYPES else None,
+                         scale_search=enable_scale_search, shape_only=convert_shape_only, device=device)
+
+
+def ggml_convert_fp32(tensor: torch.Tensor, weight_shape, k: int, qtype: int):
+    raw = tensor.view(torch.uint8) if tensor.dtype != torch.uint8 else tensor
+    return host.dequantize(raw, qtype, weight_shape)
+
+
+def ggml_int4_convert_fp32(tensor: torch.Tensor, weight_shape, k: int):
+    return ggml_convert_fp32(tensor, weight_shape, k, Q.SYM_INT4)
+
+
+def ggml_q_format_convet_cpu2xpu(tensor: torch.Tensor, shape, qtype: int):
+    """host block order -> device tile order (name kept from the reference API)."""
+    if qtype not in Q.T16_QTYPES:
+        return tensor
+    raw = tensor.view(torch.uint8) if tensor.dtype != torch.uint8 else tensor
+    return host.relayout_to_device(raw, qtype, shape[0], shape[1])
+
+
+def ggml_q_format_convet_xpu2cpu(tensor: torch.Tensor, shape, qtype: int):
+    if qtype not in Q.T16_QTYPES:
+        return tensor
+    return host.relayout_to_host(tensor, qtype, shape[0], shape[1])
+
+
+class FP4Params(torch.nn.Parameter):
+    """A frozen block-quantized weight.
+
+    ``data`` is fp32/fp16 before quantization, afterwards a flat byte buffer:
+    host layout on CPU/meta, T16 tile layout on the HIP device (``layout`` says which).
+    """
+
+    def __new__(cls, data=None, requires_grad=False, quantized=False, _shape=None, convert_shape_only=False,
+                qtype=None, imatrix=None, in_features=None, enable_scale_search=False, qlayout="host"):
+        if data is None:
+            data = torch.empty(0)
+        self = torch.Tensor._make_subclass(cls, data, requires_grad)
+        self.data = data
+        self.quantized = quantized
+        self._shape = _shape
+        self.qtype = qtype
+        self.convert_shape_only = convert_shape_only
+        self.imatrix = imatrix
+        self.in_features = in_features
+        self.enable_scale_search = enable_scale_search
+        self.qlayout = qlayout
+        return self
+
+    def _clone_with(self, data, layout=None):
+        return FP4Params(data, requires_grad=self.requires_grad, quantized=self.quantized, _shape=self._shape,
+                         qtype=self.qtype, enable_scale_search=self.enable_scale_search,
+                         qlayout=layout or self.qlayout)
+
+    def ggml_mse(self, w, ggml_qtype, device):
+        w_quant = ggml_convert_qtype(w, ggml_qtype, device=device, convert_shape_only=self.convert_shape_only,
+                                     enable_scale_search=self.enable_scale_search)
+        w_dequant = ggml_convert_fp32(w_quant, w.shape, reduce(mul, w.shape, 1), ggml_qtype)
+        return F.mse_loss(w_dequant, w), w_quant
+
+    def quantize(self, device=None):
+        if not self.quantized:
+            w = self.data.contiguous().float()
+            shape_only = self.convert_shape_only or device == "meta"
+            if self.qtype in (Q.MOFQ4, Q.MOFQ8):
+                # mixture of formats: keep whichever of the int / fp format reconstructs this tensor better
+                a, b = (Q.SYM_INT4, Q.FP4) if self.qtype == Q.MOFQ4 else (Q.SYM_INT8, Q.FP8E4)
+                if shape_only:
+                    self.data = ggml_convert_qtype(w, a, device=device, convert_shape_only=True)
+                    self.qtype = a
+                else:
+                    mse_a, q_a = self.ggml_mse(w, a, device)
+                    mse_b, q_b = self.ggml_mse(w, b, device)
+                    self.qtype, self.data = (a, q_a) if mse_a <= mse_b else (b, q_b)
+            else:
+                self.data = ggml_convert_qtype(w, self.qtype, device=device, convert_shape_only=shape_only,
+                                               imatrix=self.imatrix, in_features=self.in_features,
+                                               enable_scale_search=self.enable_scale_search)
+            self.quantized = True
+            self._shape = w.shape
+            self.qlayout = "host"
+        return self
+
+    def get_shape(self):
+        return self._shape
+
+    def to(self, *args, **kwargs):
+        device, dtype, non_blocking, _ = torch._C._nn._parse_to(*args, **kwargs)
+        src = self.data.device.type
+        if device is None:
+            return self._clone_with(self.data) if dtype is None else self  # dtype casts never touch the codes
+        dst = device.type
+        if dst == "cpu" and src == "cpu":
+            return self.quantize("cpu")
+        if dst == "meta" and src == "meta":
+            return self.quantize("meta")
+        if dst == "cuda" and src == "cpu":
+            self.quantize("cpu")
+            if self.qtype in Q.T16_QTYPES:
+                tiled = ggml_q_format_convet_cpu2xpu(self.data, self._shape, self.qtype)
+                return self._clone_with(tiled.to(device, non_blocking=non_blocking), layout="t16")
+            return self._clone_with(self.data.to(device, non_blocking=non_blocking), layout="host")
+        if dst == "cpu" and src == "cuda":
+            data = self.data.to("cpu")
+            if self.qlayout == "t16":
+                data = ggml_q_format_convet_xpu2cpu(data, self._shape, self.qtype)
+            elif self.qtype == Q.NF4 and data.dtype == torch.uint8:
+                data = data.view(torch.bfloat16)
+            return self._clone_with(data, layout="host")
+        return self._clone_with(self.data.to(device, non_blocking=non_blocking))
+
+    # nn.Module._apply calls these when moving modules between devices
+    def cuda(self, device=None, non_blocking=False):
+        return self.to(torch.device("cuda", torch.cuda.current_device() if device is None else device),
+                       non_blocking=non_blocking)
+
+    def cpu(self):
+        return self.to("cpu")
+
+    # dtype casts (model.half(), .bfloat16(), .float()) must never reinterpret quantized bytes
+    def half(self, *a, **k):
+        return self if self.quantized else super().half(*a, **k)
+
+    def bfloat16(self, *a, **k):
+        return self if self.quantized else super().bfloat16(*a, **k)
+
+    def float(self, *a, **k):
+        return self if self.quantized else super().float(*a, **k)
+
+
+# ---------------------------------------------------------------------------
+# functional kernels (device dispatch lives here, nowhere else)
+# ---------------------------------------------------------------------------
+def dequant_weight(weight: FP4Params, dtype=torch.float16) -> torch.Tensor:
+    """Dense [out, in] view of a quantized parameter on its own device (reference op ``xe_linear.dequant``)."""
+    n, k = weight._shape
+    if weight.data.device.type == "cuda":
+        from ..ops import hip
+        if weight.qlayout == "t16":
+            return hip.dequant_t16(weight.data, weight.qtype, n, k, dtype=dtype)
+        raw = weight.data.view(torch.uint8) if weight.data.dtype != torch.uint8 else weight.data
+        if weight.qtype in (Q.IQ2_XXS, Q.IQ2_XS, Q.IQ1_S, Q.IQ1_M):
+            return host.dequantize(raw.cpu(), weight.qtype, (n, k)).to(weight.data.device, dtype)
+        return hip.dequant_rows(raw, weight.qtype, n, k, dtype=dtype)
+    raw = weight.data.view(torch.uint8) if weight.data.dtype != torch.uint8 else weight.data
+    return host.dequantize(raw, weight.qtype, (n, k)).to(dtype)
+
+
+def lowbit_matmul(x_2d: torch.Tensor, weight: FP4Params, out_features: int) -> torch.Tensor:
+    """``x_2d @ dequant(weight)^T`` -> dtype of x_2d (reference op ``xe_linear.forward_new``)."""
+    n, k = weight._shape
+    if weight.data.device.type == "cuda":
+        from ..ops import hip
+        m = x_2d.shape[0]
+        if weight.qlayout == "t16" and m <= GEMV_MAX_ROWS:
+            xh = x_2d if x_2d.dtype == torch.float16 else x_2d.to(torch.float16)
+            if xh.stride(1) != 1 or xh.stride(0) % 8 or xh.data_ptr() % 16:
+                xh = xh.contiguous()
+            return hip.gemv_lowbit(xh, weight.data, weight.qtype, n, k, out_dtype=x_2d.dtype)
+        cdt = x_2d.dtype if x_2d.dtype in (torch.float16, torch.bfloat16) else torch.float16
+        w = dequant_weight(weight, cdt)
+        return F.linear(x_2d.to(cdt), w).to(x_2d.dtype)
+    # CPU: quantized matmul for few rows, dequantize + BLAS above the threshold
+    raw = weight.data.view(torch.uint8) if weight.data.dtype != torch.uint8 else weight.data
+    if x_2d.shape[0] >= TORCH_LINEAR_THRESHOLD:
+        return F.linear(x_2d.float(), host.dequantize(raw, weight.qtype, (n, k))).to(x_2d.dtype)
+    return host.matmul_q(x_2d, raw, weight.qtype, n, k).to(x_2d.dtype)
+
+
+class MatMulLowBit(torch.autograd.Function):
+    """Frozen-weight low-bit matmul with activation gradient: the QLoRA building block.
+    backward = grad_out @ dequant(W) (weights get no gradient)."""
+
+    @staticmethod
+    def forward(ctx, A, weight, output_size):
+        ctx.weight = weight if A.requires_grad else None
+        return lowbit_matmul(A, weight, output_size)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        grad_A = None
+        if ctx.needs_input_grad[0] and ctx.weight is not None:
+            w = dequant_weight(ctx.weight, grad_output.dtype if grad_output.dtype != torch.float32 else torch.float32)
+            grad_A = torch.matmul(grad_output, w.to(grad_output.dtype))
+        return grad_A, None, None
+
+
+MatMulLowBitCPU = MatMulLowBit
+
+
+def reshape_lm_head_input(x):
+    """Prefill only needs the logits of the last position (reference :262-269)."""
+    if x.dim() > 3:
+        x = x.reshape([-1, x.shape[-2], x.shape[-1]])
+    shape = list(x.size())
+    if shape[1] > 10:
+        shape[1] = 1
+        x = x[:, -1, :].view(shape)
+    return x
+
+
+def _all_reduce(t, group):
+    import torch.distributed as dist
+    if hasattr(group, "all_reduce"):      # vLLM style group coordinator
+        return group.all_reduce(t)
+    dist.all_reduce(t, group=group)
+    return t
+
+
+class LowBitLinear(nn.Linear):
+    def __init__(self, input_features, output_features, qtype, bias=True, conver_to_half=True, mp_group=None,
+                 optimize_lm_head=False, act_order=False, enable_scale_search=False):
+        super().__init__(input_features, output_features, bias)
+        self.weight = FP4Params(self.weight.data, requires_grad=False, quantized=False, _shape=None, qtype=qtype,
+                                enable_scale_search=enable_scale_search)
+        self.in_len = input_features
+        self.out_len = output_features
+        self.weight_shape = (self.out_len, self.in_len)
+        self.weight_length = self.out_len * self.in_len
+        self.qtype = qtype
+        self.conver_to_half = conver_to_half
+        self.mp_group = mp_group
+        self.compute_dtype = None  # only for training
+        self.optimize_lm_head = optimize_lm_head
+        self.act_order = act_order
+        if act_order:
+            self.register_buffer("g_idx_map", torch.arange(self.in_len, dtype=torch.int64))
+
+    def forward(self, x: torch.Tensor):
+        is_training = self.training and not torch.is_inference_mode_enabled()
+        if is_training:
+            if self.compute_dtype is not None and x.device.type == "cuda":
+                x = x.to(self.compute_dtype)
+            elif torch.is_autocast_enabled():
+                x = x.to(torch.get_autocast_dtype(x.device.type))
+        if self.bias is not None and self.bias.dtype != x.dtype:
+            self.bias.data = self.bias.data.to(x.dtype)
+        if self.optimize_lm_head:
+            x = reshape_lm_head_input(x)
+        new_shape = x.shape[:-1] + (self.out_len,)
+        if 0 in x.shape:
+            return torch.empty(new_shape, dtype=x.dtype, device=x.device)
+        if self.act_order:
+            x = x[..., self.g_idx_map]
+        x_2d = x.contiguous().view(-1, x.shape[-1])
+        if not self.weight.quantized:
+            self.weight = self.weight.to(self.weight.data.device)  # lazily quantize (CPU only)
+        if is_training and x_2d.requires_grad:
+            result = MatMulLowBit.apply(x_2d, self.weight, self.out_len)
+        else:
+            result = lowbit_matmul(x_2d, self.weight, self.out_len)
+        result = result.view(new_shape)
+        if self.mp_group is not None:
+            result = _all_reduce(result, self.mp_group)
+        if self.bias is not None:
+            result = result + self.bias
+        return result.to(x.dtype)
+
+    def extra_repr(self):
+        return f"in={self.in_len}, out={self.out_len}, qtype={Q.qtype_name(self.qtype)}, bias={self.bias is not None}"
+
+
+class _HalfLinear(nn.Linear):
+    _dtype = torch.float16
+
+    def __init__(self, input_features, output_features, bias=True, mp_group=None, weight_type=1,
+                 optimize_lm_head=False):
+        super().__init__(input_features, output_features, bias)
+        self.in_len = input_features
+        self.out_len = output_features
+        self.weight_shape = (self.out_len, self.in_len)
+        self.weight_length = self.out_len * self.in_len
+        self.qtype = Q.FP16 if self._dtype == torch.float16 else Q.BF16
+        self.mp_group = mp_group
+        self.weight_type = weight_type
+        self.optimize_lm_head = optimize_lm_head
+        self.compute_dtype = None
+
+    def forward(self, x: torch.Tensor):
+        if self.optimize_lm_head:
+            x = reshape_lm_head_input(x)
+        if self.weight.dtype != self._dtype:
+            self.weight.data = self.weight.data.to(self._dtype)
+        if self.bias is not None and self.bias.dtype != self._dtype:
+            self.bias.data = self.bias.data.to(self._dtype)
+        result = F.linear(x.to(self._dtype), self.weight)
+        if self.mp_group is not None:
+            result = _all_reduce(result, self.mp_group)
+        if self.bias is not None:
+            result = result + self.bias
+        return result.to(x.dtype)
+
+
+class FP16Linear(_HalfLinear):
+    _dtype = torch.float16
+
+
+class BF16Linear(_HalfLinear):
+    _dtype = torch.bfloat16
+
+
+class vLLMLowBitLinear(LowBitLinear):
+    def forward(self, x: torch.Tensor):
+        return super().forward(x.to(torch.bfloat16) if self.qtype == Q.NF4 and x.dtype == torch.float32 else x), None
+
+
+class vLLMFP16Linear(FP16Linear):
+    def forward(self, x: torch.Tensor):
+        return super().forward(x), None
+
+
+class vLLMBF16Linear(BF16Linear):
+    def forward(self, x: torch.Tensor):
+        return super().forward(x), None
