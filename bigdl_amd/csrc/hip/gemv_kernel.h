@@ -53,13 +53,10 @@ __device__ __forceinline__ T ldg_nt(const void* p) {
   return __builtin_nontemporal_load((const T*)p);
 }
 
+// unconditional loads: the caller passes an in-range tile index
 template <int QT>
-__device__ __forceinline__ void load_tile(Tile<QT>& t, const T16Planes& p, int64_t tile, int lane, bool valid) {
+__device__ __forceinline__ void load_tile(Tile<QT>& t, const T16Planes& p, int64_t tile, int lane) {
   constexpr int LO = (QT == Q_SYM_INT8 || QT == Q_FP8_E4M3 || QT == Q_FP8_E5M2) ? 8 : 4;
-  t.lo0 = t.lo1 = uint4v{0, 0, 0, 0};
-  t.hi0 = t.hi1 = 0;
-  t.d = t.m = half4{0, 0, 0, 0};
-  if (!valid) return;
   if constexpr (LO == 4) {
     t.lo0 = ldg_nt<uint4v>(p.lo + tile * 1024 + lane * 16);
   } else {
@@ -78,10 +75,34 @@ __device__ __forceinline__ void load_tile(Tile<QT>& t, const T16Planes& p, int64
   if constexpr (QT == Q_ASYM_INT4 || QT == Q_ASYM_INT5 || QT == Q_WOQ_INT4) t.m = ldg_nt<half4>(p.mn + tile * 64 + r * 4);
 }
 
+// 8 int4 codes -> 8 fp16 values (code - bias): 1 shift, 4 and/or, 4 packed fp16 ops.
+// Codes in nibbles 0 and 4 of a dword become 1024+q in place; codes in nibbles 1 and 5 become
+// 1024+16q in place and are brought back with one fused multiply-add (x/16 - 64 - bias).
+__device__ __forceinline__ half8 dec_int4_fast(uint32_t w, float bias) {
+  H8 r;
+  const half2v offA = {(_Float16)(1024.0f + bias), (_Float16)(1024.0f + bias)};
+  const half2v mulB = {(_Float16)0.0625f, (_Float16)0.0625f};
+  const half2v offB = {(_Float16)(-64.0f - bias), (_Float16)(-64.0f - bias)};
+  const uint32_t w8 = w >> 8;
+  // v_and_or_b32 takes at most one scalar/literal operand on gfx950: keep the magic exponent in a VGPR
+  uint32_t magic;
+  asm("v_mov_b32 %0, 0x64006400" : "=v"(magic));
+  uint32_t a0, a1, a2, a3;
+  asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(a0) : "v"(w), "s"(0x000F000Fu), "v"(magic));
+  asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(a1) : "v"(w), "s"(0x00F000F0u), "v"(magic));
+  asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(a2) : "v"(w8), "s"(0x000F000Fu), "v"(magic));
+  asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(a3) : "v"(w8), "s"(0x00F000F0u), "v"(magic));
+  r.h2[0] = u2h(a0) - offA;
+  r.h2[1] = u2h(a1) * mulB + offB;
+  r.h2[2] = u2h(a2) - offA;
+  r.h2[3] = u2h(a3) * mulB + offB;
+  return r.v;
+}
+
 template <int QT>
 __device__ __forceinline__ half8 decode_step(const Tile<QT>& t, int s, const _Float16* lut) {
-  if constexpr (QT == Q_SYM_INT4) return dec_int4(t.lo0[s], 8.0f);
-  else if constexpr (QT == Q_ASYM_INT4 || QT == Q_WOQ_INT4) return dec_int4(t.lo0[s], 0.0f);
+  if constexpr (QT == Q_SYM_INT4) return dec_int4_fast(t.lo0[s], 8.0f);
+  else if constexpr (QT == Q_ASYM_INT4 || QT == Q_WOQ_INT4) return dec_int4_fast(t.lo0[s], 0.0f);
   else if constexpr (QT == Q_FP4) return dec_fp4(t.lo0[s]);
   else if constexpr (QT == Q_NF4) return dec_nf4(t.lo0[s], lut);
   else if constexpr (QT == Q_SYM_INT5) return dec_int5(t.lo0[s], (t.hi0 >> (8 * s)) & 0xffu, 16.0f);
@@ -126,8 +147,11 @@ __device__ __forceinline__ float frag_sumsq(half8 a) {
   return s;
 }
 
+typedef float float2v __attribute__((ext_vector_type(2)));
+
 constexpr int GEMV_NW = 8;   // wavefronts per workgroup
 constexpr int XPAD = 8;      // halves of padding per LDS x row (16 B: rows land on different banks)
+constexpr int XTAIL = 128;   // zero halves after each LDS x row: the k-tile "one past the end" reads zeros
 
 // MT = number of 16-row x tiles (M <= 16*MT).  GATE_UP: second weight stream + act(g)*u.
 // XLDS: x (after the optional RMSNorm scaling by gamma) is staged once per workgroup in LDS and the
@@ -137,117 +161,124 @@ __global__ __launch_bounds__(GEMV_NW * 64) void gemv_t16_kernel(GemvArgs a) {
   constexpr int NACC = GATE_UP ? 2 : 1;
   constexpr int NSTREAM = GATE_UP ? 2 : 1;
   // weight tiles fetched per wavefront per round trip (per stream): 16 B x 64 lanes x 4 = 4 KiB in flight
-  constexpr int GEMV_U = GATE_UP ? 2 : 4;
+  constexpr int U = GATE_UP ? 2 : 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // carve: red | rs | lut | x
+  // carve: red | ssq | lut | x
   float* red = (float*)smem;                                  // [NW][NACC*MT][64][4]
-  float* rs_sh = red + GEMV_NW * NACC * MT * 256;             // [MT*16] 1/rms per row
-  _Float16* nf4_lut = (_Float16*)(rs_sh + MT * 16);           // [64*16] (nf4 only)
-  _Float16* xs = nf4_lut + (QT == Q_NF4 ? 64 * 16 : 0);       // [M][Kp + XPAD]
+  float* ssq_sh = red + GEMV_NW * NACC * MT * 256;            // [MT*16] sum of squares per row
+  _Float16* nf4_lut = (_Float16*)(ssq_sh + MT * 16);          // [64*16] (nf4 only)
+  _Float16* xs = nf4_lut + (QT == Q_NF4 ? 64 * 16 : 0);       // [M][Kp + XTAIL + XPAD]
 
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 15, g = lane >> 4;
   const int KT = (a.K + 127) >> 7;
   const int Kp = KT * 128;
-  const int XS = Kp + XPAD;
+  const int XS = Kp + XTAIL + XPAD;
   const int64_t nt = blockIdx.x;
   T16Planes pl[NSTREAM];
   pl[0] = t16_planes(a.w, QT, a.N, a.K);
   if constexpr (GATE_UP) pl[1] = t16_planes(a.w2, QT, a.N, a.K);
+  const int64_t tile0 = nt * KT;
 
   // ---- 1. put the first round of weight loads in flight before anything else ----
-  const int ntw = wave < KT ? (KT - wave + GEMV_NW - 1) / GEMV_NW : 0;   // tiles owned by this wavefront
-  Tile<QT> cur[NSTREAM][GEMV_U], nxt[NSTREAM][GEMV_U];
+  // this wavefront owns k-tiles wave, wave+NW, ...; indices past the end are clamped to the last tile
+  // (a valid address) and neutralised by reading the zero tail of x.
+  const int ntw = wave < KT ? (KT - wave + GEMV_NW - 1) / GEMV_NW : 0;
+  Tile<QT> ta[NSTREAM][U], tb[NSTREAM][U];
 #pragma unroll
-  for (int u = 0; u < GEMV_U; ++u)
+  for (int u = 0; u < U; ++u)
 #pragma unroll
-    for (int st = 0; st < NSTREAM; ++st)
-      load_tile<QT>(cur[st][u], pl[st], nt * KT + wave + GEMV_NW * u, lane, u < ntw);
+    for (int st = 0; st < NSTREAM; ++st) load_tile<QT>(ta[st][u], pl[st], tile0 + min(wave + GEMV_NW * u, KT - 1), lane);
 
-  // ---- 2. stage x (optionally RMS-normalised) in LDS: wavefront w handles rows w, w+NW, ... ----
+  // ---- 2. stage x (optionally scaled by the RMSNorm gamma) in LDS, all wavefronts together ----
   const bool norm = a.gamma != nullptr;
   const _Float16* lut = nullptr;
   if constexpr (QT == Q_NF4) {
-    for (int i = threadIdx.x; i < 64 * 16; i += blockDim.x) nf4_lut[i] = (_Float16)NF4_VALUES[i & 15];
+    for (int i = threadIdx.x; i < 64 * 16; i += GEMV_NW * 64) nf4_lut[i] = (_Float16)NF4_VALUES[i & 15];
     lut = nf4_lut + lane * 16;
   }
+  if (threadIdx.x < MT * 16) ssq_sh[threadIdx.x] = 0.0f;
   if constexpr (XLDS) {
-    for (int m = wave; m < a.M; m += GEMV_NW) {
+    __syncthreads();   // ssq_sh zeroed before the atomics below
+    const int vec_per_row = (Kp + XTAIL) >> 3;
+    for (int m = 0; m < a.M; ++m) {
       float ssq = 0.0f;
-      for (int c = lane * 8; c < Kp; c += 512) {
+      for (int v = threadIdx.x; v < vec_per_row; v += GEMV_NW * 64) {
+        const int c = v << 3;
         half8 xv = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (c < a.K) xv = *(const half8*)(a.x + (int64_t)m * a.ldx + c);
-        if (norm) {
-          ssq += frag_sumsq(xv);
-          half8 gm = c < a.K ? *(const half8*)(a.gamma + c) : xv;
-          if (a.gamma_offset != 0.0f) gm = gm + (_Float16)a.gamma_offset;
-          xv = xv * gm;
+        if (c < a.K) {
+          xv = *(const half8*)(a.x + (int64_t)m * a.ldx + c);
+          if (norm) {
+            ssq += frag_sumsq(xv);
+            half8 gm = *(const half8*)(a.gamma + c);
+            if (a.gamma_offset != 0.0f) gm = gm + (_Float16)a.gamma_offset;
+            xv = xv * gm;
+          }
         }
         *(half8*)(xs + m * XS + c) = xv;
       }
       if (norm) {
         ssq = wave_sum(ssq);
-        if (lane == 0) rs_sh[m] = rsqrtf(ssq / (float)a.K + a.eps);
+        if (lane == 0) atomicAdd(&ssq_sh[m], ssq);
       }
     }
   }
   __syncthreads();
 
-  float4v acc[NACC][MT];
+  float2v acc[NACC][MT][2];
 #pragma unroll
   for (int i = 0; i < NACC; ++i)
 #pragma unroll
-    for (int j = 0; j < MT; ++j) acc[i][j] = float4v{0, 0, 0, 0};
+    for (int j = 0; j < MT; ++j) acc[i][j][0] = acc[i][j][1] = float2v{0, 0};
   float ssq_g[MT];   // !XLDS path only
 #pragma unroll
   for (int j = 0; j < MT; ++j) ssq_g[j] = 0.0f;
   const float4v zero4 = {0, 0, 0, 0};
 
-  // ---- 3. main loop: prefetch round c+1, consume round c ----
-  for (int base = 0; base < ntw; base += GEMV_U) {
-    const bool more = base + GEMV_U < ntw;
-    if (more) {
+  // LDS row of x read by this lane for each m-tile (rows >= M alias the last valid row: their results
+  // are never stored, and MFMA rows do not mix)
+  int xrow[MT];
 #pragma unroll
-      for (int u = 0; u < GEMV_U; ++u)
+  for (int j = 0; j < MT; ++j) xrow[j] = min(16 * j + r, a.M - 1) * XS + 8 * g;
+
+  auto consume = [&](Tile<QT> (&tt)[NSTREAM][U], int base) {
 #pragma unroll
-        for (int st = 0; st < NSTREAM; ++st)
-          load_tile<QT>(nxt[st][u], pl[st], nt * KT + wave + GEMV_NW * (base + GEMV_U + u), lane, base + GEMV_U + u < ntw);
-    }
-#pragma unroll
-    for (int u = 0; u < GEMV_U; ++u) {
-      if (base + u >= ntw) break;
+    for (int u = 0; u < U; ++u) {
       const int kt = wave + GEMV_NW * (base + u);
+      const int ktx = min(kt, KT);   // KT = zero tail
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const int k0 = kt * 128 + 32 * s + 8 * g;
         half8 xa[MT];
 #pragma unroll
         for (int j = 0; j < MT; ++j) {
-          const int m = 16 * j + r;
-          half8 xv = {0, 0, 0, 0, 0, 0, 0, 0};
           if constexpr (XLDS) {
-            if (m < a.M) xv = *(const half8*)(xs + m * XS + k0);
+            xa[j] = *(const half8*)(xs + xrow[j] + ktx * 128 + 32 * s);
           } else {
-            if (m < a.M && k0 < a.K) xv = *(const half8*)(a.x + (int64_t)m * a.ldx + k0);
+            const int m = 16 * j + r;
+            const int k0 = kt * 128 + 32 * s + 8 * g;
+            half8 xv = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (m < a.M && k0 < a.K && kt < KT) xv = *(const half8*)(a.x + (int64_t)m * a.ldx + k0);
             if (norm) {
               ssq_g[j] += frag_sumsq(xv);
-              half8 gm = k0 < a.K ? *(const half8*)(a.gamma + k0) : xv;
+              half8 gm = (k0 < a.K && kt < KT) ? *(const half8*)(a.gamma + k0) : xv;
               if (a.gamma_offset != 0.0f) gm = gm + (_Float16)a.gamma_offset;
               xv = xv * gm;
             }
+            xa[j] = xv;
           }
-          xa[j] = xv;
         }
 #pragma unroll
         for (int st = 0; st < NSTREAM; ++st) {
-          const Tile<QT>& t = cur[st][u];
+          const Tile<QT>& t = tt[st][u];
           const half8 bf = decode_step<QT>(t, s, lut);
           const float d = (float)t.d[s] * post_scale<QT>();
+          const float2v d2 = {d, d};
 #pragma unroll
           for (int j = 0; j < MT; ++j) {
             const float4v c1 = mfma16(xa[j], bf, zero4);
-            acc[st][j] += c1 * d;
+            acc[st][j][0] = __builtin_elementwise_fma(float2v{c1[0], c1[1]}, d2, acc[st][j][0]);
+            acc[st][j][1] = __builtin_elementwise_fma(float2v{c1[2], c1[3]}, d2, acc[st][j][1]);
             if constexpr (has_min<QT>()) {
               // + min * sum_k x[m][k] over the block: per-row sums live on lanes (row m = lane&15),
               // the result needs them on (col n = lane&15, rows 4g+q): exchange through the wave
@@ -255,18 +286,31 @@ __global__ __launch_bounds__(GEMV_NW * 64) void gemv_t16_kernel(GemvArgs a) {
               sx += __shfl_xor(sx, 16);
               sx += __shfl_xor(sx, 32);
               const float mn = (float)t.m[s];
-#pragma unroll
-              for (int q = 0; q < 4; ++q) acc[st][j][q] += mn * __shfl(sx, 4 * g + q);
+              acc[st][j][0][0] += mn * __shfl(sx, 4 * g + 0);
+              acc[st][j][0][1] += mn * __shfl(sx, 4 * g + 1);
+              acc[st][j][1][0] += mn * __shfl(sx, 4 * g + 2);
+              acc[st][j][1][1] += mn * __shfl(sx, 4 * g + 3);
             }
           }
         }
       }
     }
-    if (more) {
+  };
+  auto fetch = [&](Tile<QT> (&tt)[NSTREAM][U], int base) {
 #pragma unroll
-      for (int u = 0; u < GEMV_U; ++u)
+    for (int u = 0; u < U; ++u)
 #pragma unroll
-        for (int st = 0; st < NSTREAM; ++st) cur[st][u] = nxt[st][u];
+      for (int st = 0; st < NSTREAM; ++st)
+        load_tile<QT>(tt[st][u], pl[st], tile0 + min(wave + GEMV_NW * (base + u), KT - 1), lane);
+  };
+
+  // ---- 3. main loop: ping-pong between two register sets; a round is fetched while the other is consumed ----
+  for (int base = 0; base < ntw; base += 2 * U) {
+    if (base + U < ntw) fetch(tb, base + U);
+    consume(ta, base);
+    if (base + U < ntw) {
+      if (base + 2 * U < ntw) fetch(ta, base + 2 * U);
+      consume(tb, base + U);
     }
   }
 
@@ -274,18 +318,18 @@ __global__ __launch_bounds__(GEMV_NW * 64) void gemv_t16_kernel(GemvArgs a) {
 #pragma unroll
   for (int i = 0; i < NACC; ++i)
 #pragma unroll
-    for (int j = 0; j < MT; ++j) *(float4v*)(red + ((wave * NACC * MT + i * MT + j) * 64 + lane) * 4) = acc[i][j];
+    for (int j = 0; j < MT; ++j) {
+      const float4v v = {acc[i][j][0][0], acc[i][j][0][1], acc[i][j][1][0], acc[i][j][1][1]};
+      *(float4v*)(red + ((wave * NACC * MT + i * MT + j) * 64 + lane) * 4) = v;
+    }
   if constexpr (!XLDS) {
     if (norm) {
-      // per-wave partial sums of squares -> rs_sh via atomics on LDS (rows are few)
-      if (threadIdx.x < MT * 16) rs_sh[threadIdx.x] = 0.0f;
-      __syncthreads();
 #pragma unroll
       for (int j = 0; j < MT; ++j) {
         float s = ssq_g[j];
         s += __shfl_xor(s, 16);
         s += __shfl_xor(s, 32);
-        if (g == 0) atomicAdd(&rs_sh[16 * j + r], s);
+        if (g == 0) atomicAdd(&ssq_sh[16 * j + r], s);
       }
     }
   }
@@ -307,7 +351,7 @@ __global__ __launch_bounds__(GEMV_NW * 64) void gemv_t16_kernel(GemvArgs a) {
       const int m = 16 * j + 4 * g + q;
       if (m >= a.M || n >= a.N) continue;
       float rs = 1.0f;
-      if (norm) rs = XLDS ? rs_sh[m] : rsqrtf(rs_sh[m] / (float)a.K + a.eps);
+      if (norm) rs = rsqrtf(ssq_sh[m] / (float)a.K + a.eps);
       float v = o[0][q] * rs;
       if (a.bias) v += (float)((const _Float16*)a.bias)[n];
       if constexpr (GATE_UP) {
@@ -339,7 +383,7 @@ static int launch_x(const GemvArgs& a, hipStream_t st) {
   const dim3 grid((a.N + 15) / 16), block(GEMV_NW * 64);
   const int Kp = (a.K + 127) / 128 * 128;
   const size_t fixed = (size_t)GEMV_NW * (GATE_UP ? 2 : 1) * MT * 256 * 4 + MT * 16 * 4 + (QT == Q_NF4 ? 64 * 16 * 2 : 0);
-  const size_t xbytes = (size_t)a.M * (Kp + XPAD) * 2;
+  const size_t xbytes = (size_t)a.M * (Kp + XTAIL + XPAD) * 2;
   if (xbytes <= GEMV_XLDS_LIMIT) {
     hipLaunchKernelGGL((gemv_t16_kernel<QT, MT, GATE_UP, true>), grid, block, fixed + xbytes, st, a);
   } else {
