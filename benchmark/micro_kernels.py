@@ -69,8 +69,8 @@ def main():
             qkv = torch.randn(1, (hq + 2 * hkv) * d, device="cuda").half()
             out = torch.empty(1, hq * d, device="cuda", dtype=torch.float16)
             past = torch.full((1,), ctx, dtype=torch.int32, device="cuda")
-            for splits in (4, 8, 16):
-                ws = torch.empty(hip.attn_decode_ws_floats(b, hq, hkv, 1, d, splits), device="cuda")
+            for splits in (1, 2, 4, 8):
+                ws = torch.empty(hip.attn_decode_ws_floats(b, hq, hkv, 1, d, splits) + 16, device="cuda")
                 cnt = torch.zeros(b * hkv, dtype=torch.int32, device="cuda")
 
                 def fn():

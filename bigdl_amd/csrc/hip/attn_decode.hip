@@ -23,22 +23,29 @@
 namespace bigdl {
 
 struct AttnArgs {
-  const _Float16* qkv;   // [B*q_len, ld]  q heads | k heads | v heads (q already rotated)
-  const void* kc;        // K cache
-  const void* vc;        // V^T cache
-  _Float16* out;         // [B*q_len, Hq*D]
+  _Float16* qkv;         // [B*q_total, ld]  q heads | k heads | v heads
+  void* kc;              // K cache
+  void* vc;              // V^T cache
+  _Float16* out;         // [B*q_total, Hq*D]
   float* ws;             // partials [B*Hkv][splits][16*RT rows][D + 4]  (O row, then m, l)
   int* counters;         // [B*Hkv] zero before first use; reset by the last arriver
   const int* past_len;   // [B] tokens in the cache before this step (device, graph-replayable)
-  const _Float16* mask;  // optional additive mask [B, q_len, mask_ld] or null
+  const _Float16* mask;  // optional additive mask [B, q_total, mask_ld] or null
+  const float* rope;     // fused RoPE: table [max_pos][rot/2][2] (cos, sin) or null (q/k already rotated+appended)
+  const int* position_ids;  // optional [B*q_total] rope positions (default: cache position)
   int mask_ld;
   float scale;           // softmax scale
   float softcap;         // gemma2 logit soft-capping (0 = off)
-  int B, Hq, Hkv, q_len, ld, Lmax, splits;
+  int B, Hq, Hkv, ld, Lmax, splits;
+  int q_total, q_off, q_cnt;   // this launch handles new tokens [q_off, q_off+q_cnt) of q_total
   int window;            // sliding window (0 = off): keys < pos - window + 1 are masked
+  int rot, interleaved, rope_max_pos;
+  int defer_combine;     // 1: stop after writing the per-split partials (the consumer GEMV combines them)
 };
 
 constexpr float NEG_BIG = -1.0e30f;
+constexpr int ATT_NW = 8;          // wavefronts per workgroup
+constexpr int ATT_KEYS = ATT_NW * 32;  // keys per workgroup iteration
 
 template <bool FP8>
 __device__ __forceinline__ half8 load_kv8(const void* base, int64_t elem_off) {
@@ -50,30 +57,93 @@ __device__ __forceinline__ half8 load_kv8(const void* base, int64_t elem_off) {
   }
 }
 
+__device__ __forceinline__ uint8_t f16_to_e5m2(_Float16 h) {
+  // round-to-nearest-even on the dropped 8 mantissa bits, saturate to the largest finite value
+  union { _Float16 h; uint16_t u; } c;
+  c.h = h;
+  uint32_t u = c.u;
+  const uint32_t sign = u & 0x8000u;
+  uint32_t mag = u & 0x7fffu;
+  if (mag > 0x7c00u) return (uint8_t)((sign >> 8) | 0x7f);   // NaN
+  mag += 0x7fu + ((mag >> 8) & 1u);
+  if (mag >= 0x7c00u) mag = 0x7b00u;
+  return (uint8_t)((sign | mag) >> 8);
+}
+
 // D = head dim (multiple of 32), RT = number of 16-row tiles
 template <int D, bool FP8, int RT>
-__global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
+__global__ __launch_bounds__(ATT_NW * 64) void attn_decode_kernel(AttnArgs a) {
   constexpr int DC = D / 32;   // QK k-steps
   constexpr int DT = D / 16;   // O^T d-tiles
-  constexpr int NW = 4;
+  constexpr int NW = ATT_NW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // merge buffers: per wave m,l per row, and O^T
-  float* s_m = (float*)smem;                       // [NW][RT*16]
-  float* s_l = s_m + NW * RT * 16;                 // [NW][RT*16]
-  float* s_o = s_l + NW * RT * 16;                 // [NW][RT*16][D]
-  int* s_flag = (int*)(s_o + NW * RT * 16 * D);
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int rr = lane & 15, g = lane >> 4;
   const int split = blockIdx.x, hkv = blockIdx.y, b = blockIdx.z;
   const int G = a.Hq / a.Hkv;
-  const int rows = G * a.q_len;
+  const int rows = G * a.q_cnt;
+  // merge buffers: per wave m,l per row, and O rows (only `rows` rows are ever touched)
+  float* s_m = (float*)smem;                       // [NW][RT*16]
+  float* s_l = s_m + NW * RT * 16;                 // [NW][RT*16]
+  float* s_o = s_l + NW * RT * 16;                 // [NW][rows][D]
+  int* s_flag = (int*)(s_o + NW * rows * D);
+
   const int past = a.past_len[b];
-  const int kv_len = past + a.q_len;
-  // split ranges in units of 128 keys (4 waves x 32)
-  const int nblk = (kv_len + 127) >> 7;
+  const int kv_len = past + a.q_total;
+  // split ranges in units of ATT_KEYS keys
+  const int nblk = (kv_len + ATT_KEYS - 1) / ATT_KEYS;
   const int per = (nblk + a.splits - 1) / a.splits;
   const int blk0 = split * per, blk1 = min(nblk, blk0 + per);
+
+  const int64_t kbase = ((int64_t)b * a.Hkv + hkv) * (int64_t)a.Lmax * D;
+  char* kc = (char*)a.kc + (FP8 ? kbase : kbase * 2);
+  char* vc = (char*)a.vc + (FP8 ? kbase : kbase * 2);
+  const int half_rot = a.rot >> 1;
+
+  // ---- fused RoPE(k) + KV append for the new tokens that fall into this workgroup's key range ----
+  if (a.rope != nullptr || a.rot == 0) {
+    if (a.q_off == 0) {
+      const int lo = blk0 * ATT_KEYS, hi = blk1 * ATT_KEYS;
+      for (int t = wave; t < a.q_total; t += NW) {
+        const int p = past + t;
+        if (p < lo || p >= hi || p >= a.Lmax) continue;
+        const int tokidx = b * a.q_total + t;
+        const int pos = a.position_ids ? a.position_ids[tokidx] : p;
+        const _Float16* krow = a.qkv + (int64_t)tokidx * a.ld + (int64_t)(a.Hq + hkv) * D;
+        const _Float16* vrow = krow + (int64_t)a.Hkv * D;
+        for (int i = lane; i < D / 2; i += 64) {
+          int i0, i1;
+          const bool rot = i < half_rot;
+          if (rot) {
+            if (a.interleaved) { i0 = 2 * i; i1 = 2 * i + 1; }
+            else { i0 = i; i1 = i + half_rot; }
+          } else {
+            i0 = a.rot + 2 * (i - half_rot);
+            i1 = i0 + 1;
+          }
+          float x0 = (float)krow[i0], x1 = (float)krow[i1];
+          if (rot) {
+            const float2 cs = *(const float2*)(a.rope + ((int64_t)min(pos, a.rope_max_pos - 1) * half_rot + i) * 2);
+            const float y0 = x0 * cs.x - x1 * cs.y, y1 = x1 * cs.x + x0 * cs.y;
+            x0 = y0;
+            x1 = y1;
+          }
+          if constexpr (FP8) {
+            ((uint8_t*)kc)[(int64_t)p * D + i0] = f16_to_e5m2((_Float16)x0);
+            ((uint8_t*)kc)[(int64_t)p * D + i1] = f16_to_e5m2((_Float16)x1);
+          } else {
+            ((_Float16*)kc)[(int64_t)p * D + i0] = (_Float16)x0;
+            ((_Float16*)kc)[(int64_t)p * D + i1] = (_Float16)x1;
+          }
+        }
+        for (int d = lane; d < D; d += 64) {
+          if constexpr (FP8) ((uint8_t*)vc)[(int64_t)d * a.Lmax + p] = f16_to_e5m2(vrow[d]);
+          else ((_Float16*)vc)[(int64_t)d * a.Lmax + p] = vrow[d];
+        }
+      }
+    }
+    __syncthreads();   // appended keys become visible to the whole workgroup (vmcnt(0) + barrier)
+  }
 
   const float qscale = a.softcap > 0.0f ? a.scale : a.scale * 1.4426950408889634f;
 
@@ -84,22 +154,61 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
 #pragma unroll
   for (int t = 0; t < RT; ++t) {
     const int row = 16 * t + rr;
-    const int tok = row / G, gq = row % G;
+    const int tok = a.q_off + row / G, gq = row % G;
     const bool valid = row < rows;
+    const int tokidx = b * a.q_total + tok;
     lim[t] = valid ? past + tok : -1;
     lo_lim[t] = (a.window > 0 && valid) ? max(0, past + tok - a.window + 1) : 0;
-    const _Float16* qp = a.qkv + (int64_t)(b * a.q_len + tok) * a.ld + (hkv * G + gq) * D;
+    const _Float16* qp = a.qkv + (int64_t)tokidx * a.ld + (hkv * G + gq) * D;
+    float qv[DC][8];
 #pragma unroll
     for (int c = 0; c < DC; ++c) {
       half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
       if (valid) v = *(const half8*)(qp + 32 * c + 8 * g);
-      qf[t][c] = v * (_Float16)qscale;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qv[c][j] = (float)v[j];
+    }
+    if (a.rope != nullptr && valid) {
+      const int pos = min(a.position_ids ? a.position_ids[tokidx] : past + tok, a.rope_max_pos - 1);
+      const float* tab = a.rope + (int64_t)pos * half_rot * 2;
+      if (a.interleaved) {
+#pragma unroll
+        for (int c = 0; c < DC; ++c) {
+          const int d0 = 32 * c + 8 * g;
+          if (d0 < a.rot) {
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+              const float2 cs = *(const float2*)(tab + (d0 + j));   // pair index (d0+j)/2 -> float offset d0+j
+              const float x0 = qv[c][j], x1 = qv[c][j + 1];
+              qv[c][j] = x0 * cs.x - x1 * cs.y;
+              qv[c][j + 1] = x1 * cs.x + x0 * cs.y;
+            }
+          }
+        }
+      } else {
+        // rotate-half pairs (d, d + D/2): the host only enables the fused path for full rotary
+        // (rot == D), so the partner lives in chunk c + DC/2 of the same lane
+#pragma unroll
+        for (int c = 0; c < DC / 2; ++c) {
+          const int d0 = 32 * c + 8 * g;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float2 cs = *(const float2*)(tab + (d0 + j) * 2);
+            const float x0 = qv[c][j], x1 = qv[c + DC / 2][j];
+            qv[c][j] = x0 * cs.x - x1 * cs.y;
+            qv[c + DC / 2][j] = x1 * cs.x + x0 * cs.y;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < DC; ++c) {
+      half8 v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (_Float16)(qv[c][j] * qscale);
+      qf[t][c] = v;
     }
   }
-
-  const int64_t kbase = ((int64_t)b * a.Hkv + hkv) * (int64_t)a.Lmax * D;
-  const char* kc = (const char*)a.kc + (FP8 ? kbase : kbase * 2);
-  const char* vc = (const char*)a.vc + (FP8 ? kbase : kbase * 2);
 
   float m_run[RT], l_run[RT];
   float4v o[RT][DT];
@@ -113,7 +222,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
   const float4v zero4 = {0, 0, 0, 0};
 
   for (int blk = blk0; blk < blk1; ++blk) {
-    const int kb = blk * 128 + wave * 32;
+    const int kb = blk * ATT_KEYS + wave * 32;
     if (kb >= kv_len) break;
     // ---- S^T = K . Q^T for two 16-key tiles ----
     // A-row i of tile u  <->  key kb + 8*(i>>2) + 4*u + (i&3)
@@ -149,7 +258,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
       if (a.mask) {
         const int row = 16 * t + rr;
         if (row < rows) {
-          const _Float16* mp = a.mask + ((int64_t)b * a.q_len + row / G) * a.mask_ld + kfirst;
+          const _Float16* mp = a.mask + ((int64_t)b * a.q_total + a.q_off + row / G) * a.mask_ld + kfirst;
 #pragma unroll
           for (int q = 0; q < 8; ++q)
             if (kfirst + q < a.mask_ld) sv[q] += (float)mp[q] * 1.4426950408889634f;
@@ -188,7 +297,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
     }
   }
 
-  // ---- merge the 4 wavefronts through LDS ----
+  // ---- merge the wavefronts through LDS ----
 #pragma unroll
   for (int t = 0; t < RT; ++t) {
     float l = l_run[t];
@@ -201,15 +310,16 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
     if (16 * t + rr < rows) {
 #pragma unroll
       for (int d = 0; d < DT; ++d)
-        *(float4v*)&s_o[((wave * RT * 16) + 16 * t + rr) * D + 16 * d + 4 * g] = o[t][d];
+        *(float4v*)&s_o[((wave * rows) + 16 * t + rr) * D + 16 * d + 4 * g] = o[t][d];
     }
   }
   __syncthreads();
 
   const int bh = b * a.Hkv + hkv;
+  const bool single = a.splits == 1;
   float* wsp = a.ws + ((int64_t)bh * a.splits + split) * (RT * 16) * (D + 4);
-  // thread -> (row, d-chunk): write merged partial for this split
-  for (int idx = threadIdx.x; idx < rows * (D / 4); idx += 256) {
+  // thread -> (row, d-chunk): merge the NW wavefronts; with one split this is the final result
+  for (int idx = threadIdx.x; idx < rows * (D / 4); idx += NW * 64) {
     const int row = idx / (D / 4), d4 = (idx % (D / 4)) * 4;
     float mw[NW], mm = NEG_BIG;
 #pragma unroll
@@ -220,35 +330,42 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
     for (int w = 0; w < NW; ++w) {
       const float f = exp2f(mw[w] - mm);
       lt += f * s_l[w * RT * 16 + row];
-      acc += *(const float4v*)&s_o[(w * RT * 16 + row) * D + d4] * f;
+      acc += *(const float4v*)&s_o[(w * rows + row) * D + d4] * f;
     }
-    float* dst = wsp + row * (D + 4);
-    *(float4v*)(dst + d4) = acc;
-    if (d4 == 0) { dst[D] = mm; dst[D + 1] = lt; }
+    if (single) {
+      const float inv = lt > 0.0f ? 1.0f / lt : 0.0f;
+      const int tok = a.q_off + row / G, gq = row % G;
+      _Float16* dst = a.out + (int64_t)(b * a.q_total + tok) * (a.Hq * D) + (hkv * G + gq) * D + d4;
+      half4 hv = {(_Float16)(acc[0] * inv), (_Float16)(acc[1] * inv), (_Float16)(acc[2] * inv), (_Float16)(acc[3] * inv)};
+      *(half4*)dst = hv;
+    } else {
+      float* dst = wsp + row * (D + 4);
+      *(float4v*)(dst + d4) = acc;
+      if (d4 == 0) { dst[D] = mm; dst[D + 1] = lt; }
+    }
   }
+  if (single || a.defer_combine) return;
 
   // ---- cross-split combine by the last-arriving workgroup of this (b, hkv) ----
-  if (a.splits > 1) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    const int ticket = __hip_atomic_fetch_add(&a.counters[bh], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = ticket == a.splits - 1;
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const int ticket = __hip_atomic_fetch_add(&a.counters[bh], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int last = ticket == a.splits - 1;
-      if (last) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(&a.counters[bh], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      *s_flag = last;
+      __hip_atomic_store(&a.counters[bh], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __syncthreads();
-    if (!*s_flag) return;
+    *s_flag = last;
   }
+  __syncthreads();
+  if (!*s_flag) return;
 
   const float* wbase = a.ws + (int64_t)bh * a.splits * (RT * 16) * (D + 4);
-  for (int idx = threadIdx.x; idx < rows * (D / 4); idx += 256) {
+  for (int idx = threadIdx.x; idx < rows * (D / 4); idx += NW * 64) {
     const int row = idx / (D / 4), d4 = (idx % (D / 4)) * 4;
     float mm = NEG_BIG;
     for (int s = 0; s < a.splits; ++s) mm = fmaxf(mm, wbase[((int64_t)s * RT * 16 + row) * (D + 4) + D]);
@@ -261,8 +378,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
       acc += *(const float4v*)(src + d4) * f;
     }
     const float inv = lt > 0.0f ? 1.0f / lt : 0.0f;
-    const int tok = row / G, gq = row % G;
-    _Float16* dst = a.out + (int64_t)(b * a.q_len + tok) * (a.Hq * D) + (hkv * G + gq) * D + d4;
+    const int tok = a.q_off + row / G, gq = row % G;
+    _Float16* dst = a.out + (int64_t)(b * a.q_total + tok) * (a.Hq * D) + (hkv * G + gq) * D + d4;
     half4 hv = {(_Float16)(acc[0] * inv), (_Float16)(acc[1] * inv), (_Float16)(acc[2] * inv), (_Float16)(acc[3] * inv)};
     *(half4*)dst = hv;
   }
@@ -270,23 +387,23 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
 
 template <int D, bool FP8>
 static int launch_rt(const AttnArgs& a, hipStream_t st) {
-  const int rows = (a.Hq / a.Hkv) * a.q_len;
+  const int rows = (a.Hq / a.Hkv) * a.q_cnt;
   const int rt = (rows + 15) / 16;
-  const dim3 grid(a.splits, a.Hkv, a.B), block(256);
-  auto smem = [&](int RT) { return (size_t)(4 * RT * 16 * 2 + 4 * RT * 16 * D) * 4 + 16; };
+  const dim3 grid(a.splits, a.Hkv, a.B), block(ATT_NW * 64);
+  auto smem = [&](int RT) { return (size_t)(ATT_NW * RT * 16 * 2 + ATT_NW * rows * D) * 4 + 16; };
   // more than 64 KiB of dynamic LDS has to be requested explicitly (once per kernel)
   static bool attr1 = false, attr2 = false;
   switch (rt) {
     case 1:
       if (!attr1 && smem(1) > 65536) {
-        if (hipFuncSetAttribute((const void*)attn_decode_kernel<D, FP8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem(1)) != hipSuccess) return -5;
+        if (hipFuncSetAttribute((const void*)attn_decode_kernel<D, FP8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -5;
         attr1 = true;
       }
       hipLaunchKernelGGL((attn_decode_kernel<D, FP8, 1>), grid, block, smem(1), st, a);
       break;
     case 2:
       if (!attr2 && smem(2) > 65536) {
-        if (hipFuncSetAttribute((const void*)attn_decode_kernel<D, FP8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem(2)) != hipSuccess) return -5;
+        if (hipFuncSetAttribute((const void*)attn_decode_kernel<D, FP8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -5;
         attr2 = true;
       }
       hipLaunchKernelGGL((attn_decode_kernel<D, FP8, 2>), grid, block, smem(2), st, a);
@@ -311,19 +428,6 @@ struct RopeAppendArgs {
   int interleaved;        // 0: neox "rotate half" pairs (i, i+rot/2); 1: gpt-j pairs (2i, 2i+1)
   int fp8;
 };
-
-__device__ __forceinline__ uint8_t f16_to_e5m2(_Float16 h) {
-  // round-to-nearest-even on the dropped 8 mantissa bits, saturate to the largest finite value
-  union { _Float16 h; uint16_t u; } c;
-  c.h = h;
-  uint32_t u = c.u;
-  const uint32_t sign = u & 0x8000u;
-  uint32_t mag = u & 0x7fffu;
-  if (mag > 0x7c00u) return (uint8_t)((sign >> 8) | 0x7f);   // NaN
-  mag += 0x7fu + ((mag >> 8) & 1u);
-  if (mag >= 0x7c00u) mag = 0x7b00u;
-  return (uint8_t)((sign | mag) >> 8);
-}
 
 // grid: (B*q_len, Hq + 2*Hkv); block: 64 threads (one per pair / per two channels)
 __global__ __launch_bounds__(64) void rope_append_kernel(RopeAppendArgs a) {
@@ -385,17 +489,30 @@ __global__ __launch_bounds__(64) void rope_append_kernel(RopeAppendArgs a) {
 
 using namespace bigdl;
 
-extern "C" int bigdl_attn_decode(const void* qkv, const void* kc, const void* vc, void* out, float* ws, int* counters,
-                                 const int* past_len, const void* mask, int mask_ld, float scale, float softcap,
-                                 int B, int Hq, int Hkv, int q_len, int ld, int Lmax, int D, int splits, int window,
-                                 int fp8, hipStream_t stream) {
-  if (B <= 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv || q_len <= 0 || splits <= 0 || (Lmax & 127) || (ld & 7)) return -1;
-  if (((uintptr_t)qkv | (uintptr_t)kc | (uintptr_t)vc | (uintptr_t)ws) & 15) return -1;
-  if ((Hq / Hkv) * q_len > 32) return -4;
+// q tokens [q_off, q_off+q_cnt) of the q_total tokens appended this step; (Hq/Hkv)*q_cnt <= 32.
+// rope != null: q is rotated in registers, k is rotated and k/v appended to the caches by this launch
+// (requires q_off == 0 for the append; rot/2 % 32 == 0 unless interleaved).
+extern "C" int bigdl_attn_decode(void* qkv, void* kc, void* vc, void* out, float* ws, int* counters,
+                                 const int* past_len, const void* mask, int mask_ld, const float* rope,
+                                 const int* position_ids, int rope_max_pos, int rot, int interleaved, float scale,
+                                 float softcap, int B, int Hq, int Hkv, int q_total, int q_off, int q_cnt, int ld,
+                                 int Lmax, int D, int splits, int window, int fp8, int append, int defer_combine,
+                                 hipStream_t stream) {
+  if (B <= 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv || q_cnt <= 0 || q_off < 0 || q_off + q_cnt > q_total || splits <= 0 ||
+      (Lmax & 255) || (ld & 7)) return -1;
+  if (((uintptr_t)qkv | (uintptr_t)kc | (uintptr_t)vc | (uintptr_t)ws | (uintptr_t)out) & 15) return -1;
+  if ((Hq / Hkv) * q_cnt > 32) return -4;
+  if (rope) {
+    if (rot <= 0 || rot > D || (rot & 7) || rope_max_pos <= 0) return -1;
+    if (!interleaved && rot != D) return -6;
+  }
   AttnArgs a;
-  a.qkv = (const _Float16*)qkv; a.kc = kc; a.vc = vc; a.out = (_Float16*)out; a.ws = ws; a.counters = counters;
+  a.qkv = (_Float16*)qkv; a.kc = kc; a.vc = vc; a.out = (_Float16*)out; a.ws = ws; a.counters = counters;
   a.past_len = past_len; a.mask = (const _Float16*)mask; a.mask_ld = mask_ld; a.scale = scale; a.softcap = softcap;
-  a.B = B; a.Hq = Hq; a.Hkv = Hkv; a.q_len = q_len; a.ld = ld; a.Lmax = Lmax; a.splits = splits; a.window = window;
+  a.rope = rope; a.position_ids = position_ids; a.rope_max_pos = rope_max_pos;
+  a.rot = rope ? rot : (append ? 0 : -1); a.interleaved = interleaved;
+  a.B = B; a.Hq = Hq; a.Hkv = Hkv; a.ld = ld; a.Lmax = Lmax; a.splits = splits; a.window = window;
+  a.q_total = q_total; a.q_off = q_off; a.q_cnt = q_cnt; a.defer_combine = defer_combine;
 #define DISPATCH_D(DD)                                                   \
   case DD: return fp8 ? launch_rt<DD, true>(a, stream) : launch_rt<DD, false>(a, stream);
   switch (D) {
@@ -410,7 +527,7 @@ extern "C" int bigdl_attn_decode(const void* qkv, const void* kc, const void* vc
 
 // workspace floats needed by bigdl_attn_decode
 extern "C" int64_t bigdl_attn_decode_ws_floats(int B, int Hq, int Hkv, int q_len, int D, int splits) {
-  const int rows = (Hq / Hkv) * q_len;
+  const int rows = (Hq / Hkv) * q_len > 32 ? 32 : (Hq / Hkv) * q_len;
   const int rt = (rows + 15) / 16;
   return (int64_t)B * Hkv * splits * rt * 16 * (D + 4);
 }

@@ -37,6 +37,11 @@ struct GemvArgs {
   int ldx, ldo;
   int act;
   int out_type;
+  // optional: x is the not-yet-combined output of the split-KV attention kernel.  Workspace layout
+  // [B*Hkv][splits][rows_alloc][D + 4] fp32 (O row, running max m, normaliser l); x[m][hq*D + d] is
+  // combined on the fly while x is staged into LDS (saves the attention kernel's cross-split hand-off).
+  const float* att_ws;
+  int att_splits, att_D, att_G, att_Hkv, att_qlen, att_rows_alloc;
 };
 
 template <int QT>
@@ -207,7 +212,28 @@ __global__ __launch_bounds__(GEMV_NW * 64) void gemv_t16_kernel(GemvArgs a) {
       for (int v = threadIdx.x; v < vec_per_row; v += GEMV_NW * 64) {
         const int c = v << 3;
         half8 xv = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (c < a.K) {
+        if (c < a.K && a.att_ws != nullptr) {
+          const int hq = c / a.att_D, d = c % a.att_D;
+          const int bb = m / a.att_qlen, tok = m % a.att_qlen;
+          const int64_t bh = (int64_t)bb * a.att_Hkv + hq / a.att_G;
+          const int row = tok * a.att_G + hq % a.att_G;
+          const int64_t stride = (int64_t)a.att_rows_alloc * (a.att_D + 4);
+          const float* p0 = a.att_ws + (bh * a.att_splits * a.att_rows_alloc + row) * (a.att_D + 4);
+          float mm = -1.0e30f;
+          for (int sp = 0; sp < a.att_splits; ++sp) mm = fmaxf(mm, p0[sp * stride + a.att_D]);
+          float lt = 0.0f, o8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+          for (int sp = 0; sp < a.att_splits; ++sp) {
+            const float* ps = p0 + sp * stride;
+            const float f = exp2f(ps[a.att_D] - mm);
+            lt += f * ps[a.att_D + 1];
+            const float4v v0 = *(const float4v*)(ps + d), v1 = *(const float4v*)(ps + d + 4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { o8[q] += f * v0[q]; o8[4 + q] += f * v1[q]; }
+          }
+          const float inv = lt > 0.0f ? 1.0f / lt : 0.0f;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) xv[q] = (_Float16)(o8[q] * inv);
+        } else if (c < a.K) {
           xv = *(const half8*)(a.x + (int64_t)m * a.ldx + c);
           if (norm) {
             ssq += frag_sumsq(xv);

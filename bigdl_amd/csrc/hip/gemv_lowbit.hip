@@ -23,16 +23,26 @@ using namespace bigdl;
 extern "C" int bigdl_gemv_lowbit(const void* x, const void* w, const void* w2, void* out, const void* bias,
                                  const void* bias2, const void* residual, const void* gamma, float eps,
                                  float gamma_offset, int M, int N, int K, int ldx, int ldo, int qtype, int act,
-                                 int out_type, hipStream_t stream) {
+                                 int out_type, const float* att_ws, int att_splits, int att_D, int att_G, int att_Hkv,
+                                 int att_qlen, int att_rows_alloc, hipStream_t stream) {
   if (M <= 0 || N <= 0 || K <= 0 || (K & 31) || (ldx & 7) || ((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return -1;
   if (gamma && ((uintptr_t)gamma & 15)) return -1;
   if (w2 && ((uintptr_t)w2 & 15)) return -1;
   if (out_type < 0 || out_type > 2) return -3;
   if (M > (w2 ? 32 : 64)) return -4;
+  if (att_ws) {
+    if (att_splits <= 0 || att_D <= 0 || (att_D & 7) || att_G <= 0 || att_Hkv <= 0 || att_qlen <= 0 || att_rows_alloc <= 0 ||
+        K != att_Hkv * att_G * att_D || M % att_qlen || att_G * att_qlen > att_rows_alloc || gamma || ((uintptr_t)att_ws & 15))
+      return -7;
+    // the combine is only implemented in the LDS staging prologue
+    if ((size_t)M * ((K + 127) / 128 * 128 + XTAIL + XPAD) * 2 > GEMV_XLDS_LIMIT) return -7;
+  }
   GemvArgs a;
   a.x = (const _Float16*)x; a.w = w; a.w2 = w2; a.out = out; a.bias = bias; a.bias2 = bias2;
   a.residual = residual; a.gamma = (const _Float16*)gamma; a.eps = eps; a.gamma_offset = gamma_offset;
   a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldo = ldo; a.act = act; a.out_type = out_type;
+  a.att_ws = att_ws; a.att_splits = att_splits; a.att_D = att_D; a.att_G = att_G; a.att_Hkv = att_Hkv;
+  a.att_qlen = att_qlen; a.att_rows_alloc = att_rows_alloc;
   const bool gu = w2 != nullptr;
   switch (qtype) {
     case Q_SYM_INT4: return gemv_launch_sym_int4(a, gu, stream);

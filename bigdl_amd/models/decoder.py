@@ -158,7 +158,7 @@ class KVCache:
     """Fixed-capacity cache: K [L][B,Hkv,Lmax,D], V^T [L][B,Hkv,D,Lmax]; fp16 or e5m2 bytes."""
 
     def __init__(self, cfg: DecoderConfig, batch: int, capacity: int, fp8: bool, device):
-        capacity = (capacity + 127) // 128 * 128
+        capacity = (capacity + 255) // 256 * 256
         dt = torch.uint8 if fp8 else torch.float16
         self.fp8 = fp8
         self.capacity = capacity
@@ -213,7 +213,17 @@ class NativeDecoder:
             self.cache = KVCache(self.cfg, batch, cap, fp8, self.device)
             self._graphs.clear()
             self._static.clear()
+            self._build_rope_table(self.cache.capacity)
         return self.cache
+
+    def _build_rope_table(self, max_pos: int):
+        """cos/sin table [max_pos, rot/2, 2] (fp32) read by the fused RoPE in the attention kernel; trig is
+        evaluated once here in full precision instead of per token on the device."""
+        pos = torch.arange(max_pos, device=self.device, dtype=torch.float32)
+        ang = pos[:, None] * self.inv_freq[None].float()
+        self.rope_table = torch.stack([ang.cos(), ang.sin()], -1).mul_(self.rope_scaling_factor).contiguous()
+        cfg = self.cfg
+        self.fused_rope = cfg.rope_interleaved or (cfg.rot_dim or cfg.head_dim) == cfg.head_dim
 
     # ------------------------------------------------------------------ prefill (eager)
     def _linear_dense(self, x, lin: Lin):
@@ -345,8 +355,8 @@ class NativeDecoder:
         m = batch * q_len
         dev = self.device
         # splits: enough workgroups to cover the chip, never more than one per 128 cached keys
-        max_splits = max(1, self.cache.capacity // 128)
-        splits = max(1, min(max_splits, (512 + batch * cfg.num_kv_heads - 1) // (batch * cfg.num_kv_heads), 16))
+        max_splits = max(1, self.cache.capacity // 256)
+        splits = max(1, min(max_splits, (256 + batch * cfg.num_kv_heads - 1) // (batch * cfg.num_kv_heads), 16))
         st = {
             "tokens": torch.zeros(batch, q_len, dtype=torch.int64, device=dev),
             "h": torch.zeros(m, cfg.hidden_size, dtype=torch.float16, device=dev),
@@ -356,21 +366,28 @@ class NativeDecoder:
             "tmp": torch.zeros(m, cfg.hidden_size, dtype=torch.float16, device=dev),
             "logits": torch.zeros(m, cfg.vocab_size, dtype=torch.float32, device=dev),
             "next": torch.zeros(m, dtype=torch.int64, device=dev),
-            "ws": torch.empty(hip.attn_decode_ws_floats(batch, cfg.num_heads, cfg.num_kv_heads, q_len, cfg.head_dim, splits),
+            "ws": torch.empty(hip.attn_decode_ws_floats(batch, cfg.num_heads, cfg.num_kv_heads, q_len, cfg.head_dim, splits) + 16,
                               dtype=torch.float32, device=dev),
             "counters": torch.zeros(batch * cfg.num_kv_heads, dtype=torch.int32, device=dev),
             "splits": splits,
         }
+        # with several KV splits the cross-split combine is folded into the o_proj GEMV's x staging
+        g = cfg.num_heads // cfg.num_kv_heads
+        rows = g * q_len
+        kp = (cfg.q_size + 127) // 128 * 128
+        st["defer"] = splits > 1 and rows <= 32 and m * (kp + 136) * 2 <= 48 * 1024
+        st["att_partials"] = (st["ws"], splits, cfg.head_dim, g, cfg.num_kv_heads, q_len, (rows + 15) // 16 * 16)
         return st
 
-    def _gemv(self, x, lin: Lin, out, *, gamma=None, residual=None, w2: Lin = None, act=None):
+    def _gemv(self, x, lin: Lin, out, *, gamma=None, residual=None, w2: Lin = None, act=None, att_partials=None):
         """out = epilogue(norm?(x) @ W^T): fused kernel for T16 weights, unfused torch ops otherwise."""
         from ..ops import hip
         cfg = self.cfg
         if lin.fused and (w2 is None or w2.fused):
             return hip.gemv_lowbit(x, lin.w, lin.qtype, lin.n, lin.k, w2=None if w2 is None else w2.w, bias=lin.bias,
                                    bias2=None if w2 is None else w2.bias, residual=residual, gamma=gamma,
-                                   eps=cfg.rms_eps, gamma_offset=cfg.norm_offset, act=act, out=out)
+                                   eps=cfg.rms_eps, gamma_offset=cfg.norm_offset, act=act, out=out,
+                                   att_partials=att_partials)
         xin = x if gamma is None else hip.rms_norm(x, gamma, cfg.rms_eps, offset=cfg.norm_offset)
         y = F.linear(xin, lin.dense())
         if lin.bias is not None:
@@ -395,18 +412,21 @@ class NativeDecoder:
         h.copy_(emb)
         for li, lw in enumerate(self.layers):
             self._gemv(h, lw.qkv, qkv, gamma=lw.input_norm)
-            hip.rope_append(qkv, cache.k[li], cache.v[li], cache.past_len, self.inv_freq, n_heads=cfg.num_heads,
-                            n_kv_heads=cfg.num_kv_heads, head_dim=cfg.head_dim, q_len=q_len, batch=batch,
-                            rot_dim=cfg.rot_dim or cfg.head_dim, interleaved=cfg.rope_interleaved,
-                            attn_scaling=self.rope_scaling_factor)
+            if not self.fused_rope:
+                hip.rope_append(qkv, cache.k[li], cache.v[li], cache.past_len, self.inv_freq, n_heads=cfg.num_heads,
+                                n_kv_heads=cfg.num_kv_heads, head_dim=cfg.head_dim, q_len=q_len, batch=batch,
+                                rot_dim=cfg.rot_dim or cfg.head_dim, interleaved=cfg.rope_interleaved,
+                                attn_scaling=self.rope_scaling_factor)
             hip.attn_decode(qkv, cache.k[li], cache.v[li], cache.past_len, attn, st["ws"], st["counters"],
                             n_heads=cfg.num_heads, n_kv_heads=cfg.num_kv_heads, head_dim=cfg.head_dim, q_len=q_len,
                             batch=batch, scale=self.attn_scale, splits=st["splits"], softcap=cfg.attn_softcap,
-                            window=lw.window)
+                            window=lw.window, rope_table=self.rope_table if self.fused_rope else None,
+                            interleaved=cfg.rope_interleaved, defer_combine=st["defer"] and lw.o.fused)
+            att_partials = st["att_partials"] if st["defer"] and lw.o.fused else None
             if lw.post_attn_out_norm is None:
-                self._gemv(attn, lw.o, h, residual=h)
+                self._gemv(attn, lw.o, h, residual=h, att_partials=att_partials)
             else:
-                self._gemv(attn, lw.o, tmp)
+                self._gemv(attn, lw.o, tmp, att_partials=att_partials)
                 hip.rms_norm(tmp, lw.post_attn_out_norm, cfg.rms_eps, offset=cfg.norm_offset, out=tmp)
                 h.add_(tmp)
             ffn_norm = lw.pre_ffn_norm if lw.pre_ffn_norm is not None else lw.post_norm

@@ -36,8 +36,8 @@ def lib():
                 "(hipcc cross-compiles gfx950 without a GPU)")
         L = ctypes.CDLL(str(_LIB_PATH))
         vp, i64, ci, cf = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
-        L.bigdl_gemv_lowbit.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, cf, cf, ci, ci, ci, ci, ci, ci, ci, ci, vp]
-        L.bigdl_attn_decode.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ci, cf, cf] + [ci] * 10 + [vp]
+        L.bigdl_gemv_lowbit.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, cf, cf, ci, ci, ci, ci, ci, ci, ci, ci, vp, ci, ci, ci, ci, ci, ci, vp]
+        L.bigdl_attn_decode.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, ci, ci, ci, cf, cf] + [ci] * 14 + [vp]
         L.bigdl_attn_decode_ws_floats.argtypes = [ci] * 6
         L.bigdl_attn_decode_ws_floats.restype = i64
         L.bigdl_rope_append.argtypes = [vp, vp, vp, vp, vp, vp, cf] + [ci] * 10 + [vp]
@@ -83,7 +83,7 @@ def _out_type(dtype) -> int:
 
 
 def gemv_lowbit(x, w, qtype, out_features, in_features, *, w2=None, bias=None, bias2=None, residual=None,
-                gamma=None, eps=1e-6, gamma_offset=0.0, act=None, out=None, out_dtype=None):
+                gamma=None, eps=1e-6, gamma_offset=0.0, act=None, out=None, out_dtype=None, att_partials=None):
     """``y = act(rmsnorm?(x) @ dequant(w)^T + bias) [* (x @ dequant(w2)^T + bias2)] [+ residual]``
 
     x: [M, K] fp16 (M <= 64, or <= 32 with w2), row stride multiple of 8.  w/w2: T16 device buffers.
@@ -115,9 +115,18 @@ def gemv_lowbit(x, w, qtype, out_features, in_features, *, w2=None, bias=None, b
         raise ValueError("residual must match out")
     if gamma is not None and (gamma.dtype != torch.float16 or gamma.numel() != k or not gamma.is_contiguous()):
         raise ValueError("gamma must be contiguous fp16 [in_features]")
+    att = (None, 0, 0, 0, 0, 0, 0)
+    if att_partials is not None:
+        # (ws fp32, splits, head_dim, group, n_kv_heads, q_len, rows_alloc): x is combined from the split-KV
+        # attention partials while it is staged (x itself is then only a shape/stride carrier)
+        ws_t, splits, hd, grp, nkv, qlen, rows_alloc = att_partials
+        _need_cuda(ws_t)
+        if ws_t.dtype != torch.float32 or ws_t.numel() < (m // qlen) * nkv * splits * rows_alloc * (hd + 4):
+            raise ValueError("attention partial workspace too small")
+        att = (_ptr(ws_t), splits, hd, grp, nkv, qlen, rows_alloc)
     rc = lib().bigdl_gemv_lowbit(_ptr(x), _ptr(w), _ptr(w2), _ptr(out), _ptr(bias), _ptr(bias2), _ptr(residual),
                                  _ptr(gamma), eps, gamma_offset, m, out_features, k, x.stride(0), out.stride(0),
-                                 qtype, ACT[act], _out_type(out_dtype), _stream())
+                                 qtype, ACT[act], _out_type(out_dtype), *att, _stream())
     _check(rc, "gemv_lowbit")
     return out
 
@@ -325,19 +334,34 @@ def rope_append(qkv, k_cache, v_cache, past_len, inv_freq, *, n_heads, n_kv_head
 
 
 def attn_decode(qkv, k_cache, v_cache, past_len, out, ws, counters, *, n_heads, n_kv_heads, head_dim, q_len, batch,
-                scale, splits, softcap=0.0, window=0, mask=None):
-    _need_cuda(qkv, k_cache, v_cache, past_len, out, ws, counters, mask)
+                scale, splits, softcap=0.0, window=0, mask=None, rope_table=None, rot_dim=None, interleaved=False,
+                position_ids=None, append=False, defer_combine=False):
+    """Split-KV decode attention over the fixed-capacity caches.
+
+    With ``rope_table`` ([max_pos, rot/2, 2] fp32 cos/sin) the kernel also rotates q in registers and
+    rotates + appends the new k / v^T (one launch instead of rope_append + attention); ``append=True``
+    without a table appends unrotated k/v.  Row counts above 32 are processed in token chunks.
+    """
+    _need_cuda(qkv, k_cache, v_cache, past_len, out, ws, counters, mask, rope_table, position_ids)
     lmax = k_cache.shape[2]
-    if qkv.dtype != torch.float16 or out.dtype != torch.float16:
-        raise ValueError("qkv/out must be fp16")
+    if qkv.dtype != torch.float16 or out.dtype != torch.float16 or qkv.dim() != 2 or qkv.stride(1) != 1:
+        raise ValueError("qkv/out must be fp16, qkv 2-D with contiguous rows")
+    if qkv.shape[0] != batch * q_len or qkv.shape[1] < (n_heads + 2 * n_kv_heads) * head_dim:
+        raise ValueError("qkv shape does not match batch/q_len/heads")
     if tuple(out.shape) != (batch * q_len, n_heads * head_dim) or not out.is_contiguous():
         raise ValueError("out must be contiguous [batch*q_len, n_heads*head_dim]")
     if tuple(k_cache.shape) != (batch, n_kv_heads, lmax, head_dim) or tuple(v_cache.shape) != (batch, n_kv_heads, head_dim, lmax):
         raise ValueError("cache shapes must be K [B,Hkv,L,D], V^T [B,Hkv,D,L]")
-    if lmax % 128:
-        raise ValueError("cache capacity must be a multiple of 128")
+    if not (k_cache.is_contiguous() and v_cache.is_contiguous()) or k_cache.dtype != v_cache.dtype:
+        raise ValueError("caches must be contiguous and of one dtype")
+    if lmax % 256:
+        raise ValueError("cache capacity must be a multiple of 256")
     fp8 = k_cache.dtype == torch.uint8
-    need = attn_decode_ws_floats(batch, n_heads, n_kv_heads, q_len, head_dim, splits)
+    if not fp8 and k_cache.dtype != torch.float16:
+        raise ValueError("cache dtype must be float16 or uint8 (e5m2)")
+    g = n_heads // n_kv_heads
+    chunk = max(1, 32 // g)
+    need = attn_decode_ws_floats(batch, n_heads, n_kv_heads, min(q_len, chunk), head_dim, splits)
     if ws.dtype != torch.float32 or ws.numel() < need:
         raise ValueError(f"workspace needs {need} floats")
     if counters.dtype != torch.int32 or counters.numel() < batch * n_kv_heads:
@@ -349,8 +373,27 @@ def attn_decode(qkv, k_cache, v_cache, past_len, out, ws, counters, *, n_heads, 
         if mask.dtype != torch.float16 or not mask.is_contiguous() or mask.shape[0] != batch or mask.shape[-2] != q_len:
             raise ValueError("mask must be contiguous fp16 [B, q_len, L]")
         mask_ld = mask.shape[-1]
-    rc = lib().bigdl_attn_decode(_ptr(qkv), _ptr(k_cache), _ptr(v_cache), _ptr(out), _ptr(ws), _ptr(counters),
-                                 _ptr(past_len), _ptr(mask), mask_ld, scale, softcap, batch, n_heads, n_kv_heads,
-                                 q_len, qkv.stride(0), lmax, head_dim, splits, window, int(fp8), _stream())
-    _check(rc, "attn_decode")
+    rope_max = rot = 0
+    if rope_table is not None:
+        if rope_table.dtype != torch.float32 or rope_table.dim() != 3 or rope_table.shape[2] != 2 or not rope_table.is_contiguous():
+            raise ValueError("rope_table must be contiguous fp32 [max_pos, rot/2, 2]")
+        rope_max, rot = rope_table.shape[0], rope_table.shape[1] * 2
+        if rot_dim is not None and rot_dim != rot:
+            raise ValueError("rot_dim does not match the rope table")
+        if not interleaved and rot != head_dim:
+            raise ValueError("fused rotate-half RoPE needs rot_dim == head_dim (use rope_append otherwise)")
+    if position_ids is not None and (position_ids.dtype != torch.int32 or position_ids.numel() != batch * q_len):
+        raise ValueError("position_ids must be int32 [batch*q_len]")
+    if defer_combine and q_len > chunk:
+        raise ValueError("defer_combine needs all rows in one launch")
+    for off in range(0, q_len, chunk):
+        cnt = min(chunk, q_len - off)
+        do_append = (rope_table is not None or append) and off == 0
+        rc = lib().bigdl_attn_decode(_ptr(qkv), _ptr(k_cache), _ptr(v_cache), _ptr(out), _ptr(ws), _ptr(counters),
+                                     _ptr(past_len), _ptr(mask), mask_ld,
+                                     _ptr(rope_table), _ptr(position_ids), rope_max, rot,
+                                     int(bool(interleaved)), scale, softcap, batch, n_heads, n_kv_heads, q_len, off, cnt,
+                                     qkv.stride(0), lmax, head_dim, splits, window, int(fp8), int(bool(do_append)),
+                                     int(bool(defer_combine)), _stream())
+        _check(rc, "attn_decode")
     return out

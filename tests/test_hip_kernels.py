@@ -202,7 +202,7 @@ def _ref_attention(q, k, v, scale, softcap=0.0, window=0, past=0):
 def test_rope_append_and_attn_decode(hip, fp8, cfg):
     torch.manual_seed(7)
     b, hq, hkv, d, q_len, past = cfg
-    lmax = 1152
+    lmax = 1280
     ld = (hq + 2 * hkv) * d
     cache_dtype = torch.uint8 if fp8 else torch.float16
     kc = torch.zeros(b, hkv, lmax, d, dtype=cache_dtype, device="cuda")
@@ -263,3 +263,79 @@ def test_rope_append_and_attn_decode(hip, fp8, cfg):
         got = out.cpu().float().view(b, c, hq, d).transpose(1, 2)
         torch.testing.assert_close(got, ref, rtol=1e-2, atol=1e-2)
         assert int(counters.abs().sum()) == 0
+
+
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("interleaved", [False, True])
+@pytest.mark.parametrize("cfg", [(1, 32, 32, 128, 1, 700), (2, 8, 2, 128, 3, 255), (1, 4, 4, 64, 6, 254), (1, 16, 2, 128, 9, 40)])
+def test_attn_decode_fused_rope_append_equals_separate(hip, fp8, interleaved, cfg):
+    """One launch (rope in registers + append inside the attention kernel) == rope_append kernel + attention."""
+    torch.manual_seed(8)
+    b, hq, hkv, d, q_len, past = cfg
+    lmax = 1024
+    ld = (hq + 2 * hkv) * d
+    dt = torch.uint8 if fp8 else torch.float16
+    inv_freq = (1.0 / (10000 ** (torch.arange(0, d, 2).float() / d))).cuda()
+    kc = (torch.randn(b, hkv, lmax, d) * 0.5).half().cuda()
+    vc = (torch.randn(b, hkv, d, lmax) * 0.5).half().cuda()
+    if fp8:
+        kq, vq = torch.empty_like(kc, dtype=torch.uint8), torch.empty_like(vc, dtype=torch.uint8)
+        hip.to_e5m2(kc, kq)
+        hip.to_e5m2(vc, vq)
+        kc, vc = kq, vq
+    kc2, vc2 = kc.clone(), vc.clone()
+    qkv = (torch.randn(b * q_len, ld) * 0.5).half().cuda()
+    qkv2 = qkv.clone()
+    past_len = torch.full((b,), past, dtype=torch.int32, device="cuda")
+    scale = 1.0 / math.sqrt(d)
+    splits = 3
+    ws = torch.empty(hip.attn_decode_ws_floats(b, hq, hkv, q_len, d, splits) + 16, dtype=torch.float32, device="cuda")
+    cnt = torch.zeros(b * hkv, dtype=torch.int32, device="cuda")
+    out1 = torch.empty(b * q_len, hq * d, dtype=torch.float16, device="cuda")
+    hip.rope_append(qkv, kc, vc, past_len, inv_freq, n_heads=hq, n_kv_heads=hkv, head_dim=d, q_len=q_len, batch=b,
+                    interleaved=interleaved)
+    hip.attn_decode(qkv, kc, vc, past_len, out1, ws, cnt, n_heads=hq, n_kv_heads=hkv, head_dim=d, q_len=q_len, batch=b,
+                    scale=scale, splits=splits)
+    pos = torch.arange(lmax, device="cuda").float()
+    ang = pos[:, None] * inv_freq[None]
+    table = torch.stack([ang.cos(), ang.sin()], -1).contiguous()
+    out2 = torch.empty_like(out1)
+    hip.attn_decode(qkv2, kc2, vc2, past_len, out2, ws, cnt, n_heads=hq, n_kv_heads=hkv, head_dim=d, q_len=q_len,
+                    batch=b, scale=scale, splits=splits, rope_table=table, interleaved=interleaved)
+    torch.testing.assert_close(out2.float(), out1.float(), rtol=5e-3, atol=5e-3)
+    assert torch.equal(vc2, vc)
+    if fp8:
+        diff = (kc2.view(torch.float8_e5m2).float() - kc.view(torch.float8_e5m2).float()).abs()
+        # table cos/sin vs sincosf can flip an e5m2 rounding: allow one ulp (25 %) on a few entries
+        assert (diff > 0).float().mean() < 0.02
+    else:
+        torch.testing.assert_close(kc2.float(), kc.float(), rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("cfg", [(1, 32, 32, 128, 1, 1000, 5), (2, 8, 2, 128, 2, 300, 3), (1, 4, 4, 64, 3, 513, 2)])
+def test_gemv_combines_attention_partials(hip, cfg):
+    """o_proj GEMV fed with un-combined split-KV partials == attention with in-kernel combine + plain GEMV."""
+    torch.manual_seed(9)
+    b, hq, hkv, d, q_len, past, splits = cfg
+    lmax = 1280
+    ld = (hq + 2 * hkv) * d
+    kc = (torch.randn(b, hkv, lmax, d) * 0.5).half().cuda()
+    vc = (torch.randn(b, hkv, d, lmax) * 0.5).half().cuda()
+    qkv = (torch.randn(b * q_len, ld) * 0.5).half().cuda()
+    past_len = torch.full((b,), past, dtype=torch.int32, device="cuda")
+    ws = torch.zeros(hip.attn_decode_ws_floats(b, hq, hkv, q_len, d, splits) + 16, dtype=torch.float32, device="cuda")
+    cnt = torch.zeros(b * hkv, dtype=torch.int32, device="cuda")
+    att = torch.empty(b * q_len, hq * d, dtype=torch.float16, device="cuda")
+    kw = dict(n_heads=hq, n_kv_heads=hkv, head_dim=d, q_len=q_len, batch=b, scale=1.0 / math.sqrt(d), splits=splits)
+    hip.attn_decode(qkv, kc, vc, past_len, att, ws, cnt, **kw)
+    n, k = 96, hq * d
+    w = torch.randn(n, k) * 0.05
+    dev, _ = _quant_dev(w, Q.SYM_INT4)
+    ref = hip.gemv_lowbit(att, dev, Q.SYM_INT4, n, k, out_dtype=torch.float32)
+    ws.zero_()
+    dummy = torch.zeros_like(att)
+    hip.attn_decode(qkv, kc, vc, past_len, dummy, ws, cnt, defer_combine=True, **kw)
+    g = hq // hkv
+    got = hip.gemv_lowbit(dummy, dev, Q.SYM_INT4, n, k, out_dtype=torch.float32,
+                          att_partials=(ws, splits, d, g, hkv, q_len, (g * q_len + 15) // 16 * 16))
+    torch.testing.assert_close(got, ref, rtol=2e-3, atol=2e-3)
