@@ -154,19 +154,20 @@ __device__ __forceinline__ float frag_sumsq(half8 a) {
 
 typedef float float2v __attribute__((ext_vector_type(2)));
 
-constexpr int GEMV_NW = 8;   // wavefronts per workgroup
 constexpr int XPAD = 8;      // halves of padding per LDS x row (16 B: rows land on different banks)
 constexpr int XTAIL = 128;   // zero halves after each LDS x row: the k-tile "one past the end" reads zeros
 
 // MT = number of 16-row x tiles (M <= 16*MT).  GATE_UP: second weight stream + act(g)*u.
 // XLDS: x (after the optional RMSNorm scaling by gamma) is staged once per workgroup in LDS and the
 // A fragments are read from there; otherwise they are fetched from global memory (large M*K).
-template <int QT, int MT, bool GATE_UP, bool XLDS>
-__global__ __launch_bounds__(GEMV_NW * 64) void gemv_t16_kernel(GemvArgs a) {
+// NW = wavefronts per workgroup (the K split)
+template <int QT, int MT, bool GATE_UP, bool XLDS, int NW>
+__global__ __launch_bounds__(NW * 64) void gemv_t16_kernel(GemvArgs a) {
+  constexpr int GEMV_NW = NW;
   constexpr int NACC = GATE_UP ? 2 : 1;
   constexpr int NSTREAM = GATE_UP ? 2 : 1;
   // weight tiles fetched per wavefront per round trip (per stream): 16 B x 64 lanes x 4 = 4 KiB in flight
-  constexpr int U = GATE_UP ? 2 : 4;
+  constexpr int U = (GATE_UP || NW > 8) ? 2 : 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // carve: red | ssq | lut | x
   float* red = (float*)smem;                                  // [NW][NACC*MT][64][4]
@@ -406,14 +407,20 @@ constexpr size_t GEMV_XLDS_LIMIT = 48 * 1024;   // stage x in LDS when it fits t
 
 template <int QT, int MT, bool GATE_UP>
 static int launch_x(const GemvArgs& a, hipStream_t st) {
-  const dim3 grid((a.N + 15) / 16), block(GEMV_NW * 64);
+  const dim3 grid((a.N + 15) / 16);
   const int Kp = (a.K + 127) / 128 * 128;
-  const size_t fixed = (size_t)GEMV_NW * (GATE_UP ? 2 : 1) * MT * 256 * 4 + MT * 16 * 4 + (QT == Q_NF4 ? 64 * 16 * 2 : 0);
   const size_t xbytes = (size_t)a.M * (Kp + XTAIL + XPAD) * 2;
-  if (xbytes <= GEMV_XLDS_LIMIT) {
-    hipLaunchKernelGGL((gemv_t16_kernel<QT, MT, GATE_UP, true>), grid, block, fixed + xbytes, st, a);
+  auto fixed = [&](int nw) { return (size_t)nw * (GATE_UP ? 2 : 1) * MT * 256 * 4 + MT * 16 * 4 + (QT == Q_NF4 ? 64 * 16 * 2 : 0); };
+  // 16 wavefronts when the grid is small (about one workgroup per CU) and every wavefront still gets
+  // at least two k-tiles: halves the per-wavefront instruction stream of the latency-bound small GEMVs
+  const bool wide = MT == 1 && !GATE_UP && xbytes <= GEMV_XLDS_LIMIT && grid.x <= 256 && Kp / 128 >= 64;
+  if (wide) {
+    if constexpr (MT == 1 && !GATE_UP)
+      hipLaunchKernelGGL((gemv_t16_kernel<QT, MT, GATE_UP, true, 16>), grid, dim3(1024), fixed(16) + xbytes, st, a);
+  } else if (xbytes <= GEMV_XLDS_LIMIT) {
+    hipLaunchKernelGGL((gemv_t16_kernel<QT, MT, GATE_UP, true, 8>), grid, dim3(512), fixed(8) + xbytes, st, a);
   } else {
-    hipLaunchKernelGGL((gemv_t16_kernel<QT, MT, GATE_UP, false>), grid, block, fixed, st, a);
+    hipLaunchKernelGGL((gemv_t16_kernel<QT, MT, GATE_UP, false, 8>), grid, dim3(512), fixed(8), st, a);
   }
   return HIP_CHECK_LAUNCH();
 }
