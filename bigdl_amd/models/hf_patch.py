@@ -1,0 +1,423 @@
+"""Structural rewrites and forward bindings for HuggingFace decoder models, plus the bridge from an HF
+model to the native decoder engine.
+
+The reference keeps one file of forwards per architecture (python/llm/src/ipex_llm/transformers/models/*.py,
+bound in convert.py:1251-2027).  HF's current decoder layers share one calling convention
+(``self_attn(hidden_states, position_embeddings, attention_mask, past_key_values, **kw)``), so the bindings
+here are generic:
+
+* ``merge_qkv``        q/k/v projections -> one ``qkv_proj`` (reference models/common.py:22-52)
+* ``attention_forward`` merged projection, in-place RoPE kernel, HF cache update, HF attention interface
+* ``mlp_forward``      fused gate/up GEMV + activation for few rows (reference models/common.py:118-141)
+* ``rms_norm_forward`` RMSNorm kernel (reference models/common.py:156-174, gemma variant gemma.py:61-72)
+* ``layer_norm_forward`` LayerNorm kernel (reference models/common.py:177-188)
+* ``generate`` of supported families is served by ``NativeDecoder`` (hipGraph decode) when the call is plain
+  greedy/sampling generation on the GPU.
+"""
+from __future__ import annotations
+
+import logging
+import sys
+import types
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .. import qtypes as Q
+
+logger = logging.getLogger("bigdl_amd")
+
+# model types whose attention modules follow the llama layout (q_proj/k_proj/v_proj/o_proj + rotary cos/sin)
+MERGE_QKV_TYPES = {"llama", "mistral", "qwen2", "qwen3", "gemma", "gemma2", "stablelm", "starcoder2", "minicpm",
+                   "mixtral", "qwen2_moe", "olmo", "cohere", "internlm3", "yi", "glm", "granite"}
+NATIVE_ENGINE_TYPES = {"llama", "mistral", "qwen2", "gemma", "gemma2", "phi3", "mixtral", "qwen2_moe", "yi", "granite"}
+
+
+def _is_cuda(t):
+    return t.device.type == "cuda"
+
+
+# ------------------------------------------------------------------------------------------------
+# structural rewrites
+# ------------------------------------------------------------------------------------------------
+def merge_linear(linears):
+    """Concatenate nn.Linear layers along the output dim."""
+    new_weight = torch.cat([l.weight.data for l in linears], dim=0)
+    bias = None
+    if linears[0].bias is not None:
+        bias = torch.cat([l.bias.data for l in linears], dim=0)
+    new = nn.Linear(0, 0, bias=False)
+    new.weight = nn.Parameter(new_weight, requires_grad=False)
+    new.in_features, new.out_features = new_weight.size(1), new_weight.size(0)
+    if bias is not None:
+        new.bias = nn.Parameter(bias, requires_grad=False)
+    return new
+
+
+def merge_qkv_base(module: nn.Module, attention_class):
+    name = attention_class if isinstance(attention_class, str) else attention_class.__name__
+    if module.__class__.__name__ == name and all(isinstance(getattr(module, p, None), nn.Linear)
+                                                   for p in ("q_proj", "k_proj", "v_proj")):
+        module.qkv_proj = merge_linear([module.q_proj, module.k_proj, module.v_proj])
+        module._merged_sizes = (module.q_proj.out_features, module.k_proj.out_features, module.v_proj.out_features)
+        del module.q_proj, module.k_proj, module.v_proj
+
+
+def _attention_classes(model):
+    out = set()
+    for m in model.modules():
+        if all(hasattr(m, p) for p in ("q_proj", "k_proj", "v_proj", "o_proj")) and hasattr(m, "layer_idx"):
+            out.add(m.__class__)
+    return out
+
+
+def optimize_pre(model, qtype=None):
+    cfg = getattr(model, "config", None)
+    mt = getattr(cfg, "model_type", None)
+    if mt in MERGE_QKV_TYPES:
+        for cls in _attention_classes(model):
+            model.apply(lambda m, c=cls: merge_qkv_base(m, c))
+    # multimodal wrappers: recurse into the language model with its own config
+    for attr in ("language_model", "llm"):
+        sub = getattr(model, attr, None)
+        if isinstance(sub, nn.Module) and getattr(getattr(sub, "config", None), "model_type", None) in MERGE_QKV_TYPES \
+                and sub is not model:
+            optimize_pre(sub, qtype)
+    return model
+
+
+# ------------------------------------------------------------------------------------------------
+# forwards
+# ------------------------------------------------------------------------------------------------
+def rms_norm_forward(self, hidden_states):
+    eps = getattr(self, "variance_epsilon", None)
+    if eps is None:
+        eps = getattr(self, "eps", 1e-6)
+    offset = 1.0 if self.__class__.__name__.startswith("Gemma") else 0.0
+    if _is_cuda(hidden_states) and hidden_states.dtype in (torch.float16, torch.bfloat16, torch.float32) \
+            and hidden_states.shape[-1] % 8 == 0 and not torch.is_grad_enabled():
+        from ..ops import hip
+        return hip.rms_norm(hidden_states.contiguous(), self.weight, eps, offset=offset)
+    x = hidden_states.float()
+    x = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps)
+    return (x * (self.weight.float() + offset)).to(hidden_states.dtype)
+
+
+def layer_norm_forward(self, hidden_states):
+    if _is_cuda(hidden_states) and hidden_states.shape[-1] % 8 == 0 and not torch.is_grad_enabled() \
+            and self.weight is not None and hidden_states.dtype in (torch.float16, torch.bfloat16, torch.float32):
+        from ..ops import hip
+        return hip.layer_norm(hidden_states, self.weight, self.bias, self.eps)
+    return F.layer_norm(hidden_states, self.normalized_shape, self.weight, self.bias, self.eps)
+
+
+def _act_name(mlp):
+    fn = getattr(mlp, "act_fn", None)
+    name = type(fn).__name__.lower() if fn is not None else ""
+    cfg_act = getattr(getattr(mlp, "config", None), "hidden_act", None) or getattr(getattr(mlp, "config", None), "hidden_activation", None)
+    if cfg_act in ("silu", "swish", "gelu", "gelu_pytorch_tanh", "gelu_new", "relu", "gelu_tanh", "gelu_fast"):
+        return cfg_act
+    if "silu" in name:
+        return "silu"
+    if "tanh" in name or "newgelu" in name:
+        return "gelu_pytorch_tanh"
+    if "gelu" in name:
+        return "gelu"
+    return None
+
+
+def mlp_forward(self, x):
+    """gate/up/down MLP: one fused kernel for gate+up+act when few rows hit T16 weights on the GPU."""
+    from ..transformers.low_bit_linear import LowBitLinear
+    g, u, d = self.gate_proj, self.up_proj, self.down_proj
+    act = _act_name(self)
+    rows = x.numel() // x.shape[-1]
+    if (_is_cuda(x) and act is not None and rows <= 32 and isinstance(g, LowBitLinear) and isinstance(u, LowBitLinear)
+            and g.weight.qlayout == "t16" and u.weight.qlayout == "t16" and g.qtype == u.qtype
+            and g.mp_group is None and not torch.is_grad_enabled()):
+        from ..ops import hip
+        x2 = x.reshape(rows, x.shape[-1])
+        xh = x2 if x2.dtype == torch.float16 else x2.to(torch.float16)
+        h = hip.gemv_lowbit(xh.contiguous(), g.weight.data, g.qtype, g.out_len, g.in_len, w2=u.weight.data,
+                            bias=None if g.bias is None else g.bias.to(torch.float16),
+                            bias2=None if u.bias is None else u.bias.to(torch.float16), act=act)
+        return d(h.to(x.dtype).view(*x.shape[:-1], g.out_len))
+    return d(self.act_fn(g(x)) * u(x))
+
+
+def _rotate_half(x):
+    x1, x2 = x[..., : x.shape[-1] // 2], x[..., x.shape[-1] // 2:]
+    return torch.cat((-x2, x1), dim=-1)
+
+
+def apply_rotary(q, k, cos, sin):
+    """RoPE on [B,H,S,D] q/k (views allowed) with HF cos/sin [B,S,rot]; in place on the GPU."""
+    rot = cos.shape[-1]
+    if _is_cuda(q) and not torch.is_grad_enabled() and q.stride(-1) == 1 and k.stride(-1) == 1:
+        from ..ops import hip
+        hip.rope_inplace(q, cos=cos, sin=sin, rot_dim=rot)
+        hip.rope_inplace(k, cos=cos, sin=sin, rot_dim=rot)
+        return q, k
+    cos_, sin_ = cos.unsqueeze(1), sin.unsqueeze(1)
+    if rot == q.shape[-1]:
+        return q * cos_ + _rotate_half(q) * sin_, k * cos_ + _rotate_half(k) * sin_
+    qr, qp = q[..., :rot], q[..., rot:]
+    kr, kp = k[..., :rot], k[..., rot:]
+    return (torch.cat([qr * cos_ + _rotate_half(qr) * sin_, qp], -1),
+            torch.cat([kr * cos_ + _rotate_half(kr) * sin_, kp], -1))
+
+
+def attention_forward(self, hidden_states, position_embeddings=None, attention_mask=None, past_key_values=None,
+                      **kwargs):
+    """Generic llama-layout attention over the merged ``qkv_proj``."""
+    from transformers.modeling_utils import ALL_ATTENTION_FUNCTIONS
+    input_shape = hidden_states.shape[:-1]
+    hd = self.head_dim
+    nq, nk, nv = (s // hd for s in self._merged_sizes)
+    qkv = self.qkv_proj(hidden_states).view(*input_shape, nq + nk + nv, hd).transpose(1, 2)
+    q, k, v = qkv.split([nq, nk, nv], dim=1)
+    if getattr(self, "q_norm", None) is not None:      # qwen3 / gemma3 / olmo2 style per-head norms
+        q, k = self.q_norm(q), self.k_norm(k)
+    if position_embeddings is not None:
+        cos, sin = position_embeddings
+        q, k = apply_rotary(q, k, cos, sin)
+    if past_key_values is not None:
+        k, v = past_key_values.update(k, v, self.layer_idx)
+    mod = sys.modules[self.__class__.__module__]
+    eager = getattr(mod, "eager_attention_forward")
+    interface = ALL_ATTENTION_FUNCTIONS.get_interface(self.config._attn_implementation, eager)
+    extra = {}
+    if hasattr(self, "sliding_window"):
+        extra["sliding_window"] = self.sliding_window
+    if getattr(self, "attn_logit_softcapping", None) is not None:
+        extra["softcap"] = self.attn_logit_softcapping
+    attn_output, attn_weights = interface(self, q, k, v, attention_mask,
+                                          dropout=0.0 if not self.training else getattr(self, "attention_dropout", 0.0),
+                                          scaling=self.scaling, **extra, **kwargs)
+    attn_output = attn_output.reshape(*input_shape, -1).contiguous()
+    return self.o_proj(attn_output), attn_weights
+
+
+# ------------------------------------------------------------------------------------------------
+# HF model -> native engine
+# ------------------------------------------------------------------------------------------------
+def decoder_config_from_hf(cfg):
+    from .decoder import DecoderConfig
+    mt = cfg.model_type
+    hd = getattr(cfg, "head_dim", None) or cfg.hidden_size // cfg.num_attention_heads
+    rope_params = getattr(cfg, "rope_parameters", None) or {}
+    rope_theta = rope_params.get("rope_theta", getattr(cfg, "rope_theta", 10000.0)) or 10000.0
+    rope_scaling = getattr(cfg, "rope_scaling", None)
+    if rope_scaling is None and rope_params.get("rope_type", "default") not in ("default", None):
+        rope_scaling = dict(rope_params)
+    partial = rope_params.get("partial_rotary_factor", getattr(cfg, "partial_rotary_factor", 1.0)) or 1.0
+    dc = DecoderConfig(
+        vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size,
+        intermediate_size=getattr(cfg, "intermediate_size", 0) or 0, num_layers=cfg.num_hidden_layers,
+        num_heads=cfg.num_attention_heads, num_kv_heads=getattr(cfg, "num_key_value_heads", None) or cfg.num_attention_heads,
+        head_dim=hd, rms_eps=getattr(cfg, "rms_norm_eps", 1e-6), rope_theta=float(rope_theta),
+        rope_scaling=rope_scaling, max_position=getattr(cfg, "max_position_embeddings", 4096),
+        tie_word_embeddings=bool(getattr(cfg, "tie_word_embeddings", False)),
+        act=getattr(cfg, "hidden_act", None) or getattr(cfg, "hidden_activation", None) or "silu", model_type=mt,
+        rot_dim=int(hd * partial) if partial != 1.0 else None)
+    if mt in ("gemma", "gemma2"):
+        dc.norm_offset = 1.0
+        dc.embed_scale = float(cfg.hidden_size) ** 0.5
+        dc.act = getattr(cfg, "hidden_activation", None) or "gelu_pytorch_tanh"
+    if mt == "gemma2":
+        dc.attn_softcap = float(getattr(cfg, "attn_logit_softcapping", 0.0) or 0.0)
+        dc.final_softcap = float(getattr(cfg, "final_logit_softcapping", 0.0) or 0.0)
+        dc.attn_scale = float(getattr(cfg, "query_pre_attn_scalar", hd)) ** -0.5
+        dc.sliding_window = int(getattr(cfg, "sliding_window", 0) or 0)
+        dc.post_norms = True
+    if mt in ("mistral", "mixtral"):
+        dc.sliding_window = int(getattr(cfg, "sliding_window", 0) or 0)
+    if mt == "granite":
+        dc.logit_scale = 1.0 / float(getattr(cfg, "logits_scaling", 1.0))
+    if mt == "mixtral":
+        dc.num_experts, dc.top_k = cfg.num_local_experts, cfg.num_experts_per_tok
+        dc.moe_intermediate_size = cfg.intermediate_size
+    if mt == "qwen2_moe":
+        dc.num_experts, dc.top_k = cfg.num_experts, cfg.num_experts_per_tok
+        dc.moe_intermediate_size = cfg.moe_intermediate_size
+        dc.shared_expert_intermediate_size = cfg.shared_expert_intermediate_size
+        dc.norm_topk_prob = bool(cfg.norm_topk_prob)
+    return dc
+
+
+def _lin(module):
+    from .decoder import Lin
+    from ..transformers.low_bit_linear import LowBitLinear
+    if isinstance(module, LowBitLinear):
+        return Lin(module.weight, module.bias)
+    return Lin(module.weight.data, getattr(module, "bias", None))
+
+
+def _split_lin_rows(module, sizes):
+    """Split a (not yet device-tiled) merged linear into per-part ``Lin``s by dequantizing: only used for
+    pre-merged architectures (phi3 gate_up_proj) where the engine wants gate and up separately."""
+    from .decoder import Lin
+    from ..transformers.low_bit_linear import LowBitLinear, FP4Params, dequant_weight
+    if isinstance(module, LowBitLinear):
+        w = dequant_weight(module.weight, torch.float32).cpu()
+        qt = module.qtype
+    else:
+        w, qt = module.weight.data.float().cpu(), None
+    outs, off = [], 0
+    for s in sizes:
+        part = w[off:off + s].contiguous()
+        off += s
+        if qt is not None and qt in Q.T16_QTYPES:
+            p = FP4Params(part, qtype=qt).to("cpu").to(module.weight.data.device)
+            outs.append(Lin(p))
+        else:
+            outs.append(Lin(part.to(module.weight.data.device)))
+    return outs
+
+
+def build_native_decoder(model):
+    """Wrap the (already converted, already on the GPU) HF model's weights in a ``NativeDecoder``.  No copies for
+    T16 weights: the engine reads the same device buffers as the LowBitLinear modules."""
+    from .decoder import LayerWeights, NativeDecoder
+    cfg = model.config
+    mt = cfg.model_type
+    dc = decoder_config_from_hf(cfg)
+    base = model.model
+    dev = base.embed_tokens.weight.device
+    f16 = lambda t: t.detach().to(torch.float16).contiguous()  # noqa: E731
+    layers = []
+    for li, layer in enumerate(base.layers):
+        att = layer.self_attn
+        if hasattr(att, "qkv_proj"):
+            qkv = _lin(att.qkv_proj)
+        else:
+            raise NotImplementedError("native engine needs merged qkv (optimize_model=True)")
+        lw = LayerWeights(input_norm=f16(layer.input_layernorm.weight), qkv=qkv, o=_lin(att.o_proj),
+                          post_norm=f16(layer.post_attention_layernorm.weight))
+        mlp = layer.mlp
+        if dc.num_experts:
+            from .moe import MoEWeights
+            lw.moe = MoEWeights.from_hf(mlp, dc, _lin)
+        elif hasattr(mlp, "gate_up_proj"):
+            lw.gate, lw.up = _split_lin_rows(mlp.gate_up_proj, (dc.intermediate_size, dc.intermediate_size))
+            lw.down = _lin(mlp.down_proj)
+        else:
+            lw.gate, lw.up, lw.down = _lin(mlp.gate_proj), _lin(mlp.up_proj), _lin(mlp.down_proj)
+        if mt == "gemma2":
+            lw.post_attn_out_norm = f16(layer.post_attention_layernorm.weight)
+            lw.pre_ffn_norm = f16(layer.pre_feedforward_layernorm.weight)
+            lw.post_ffn_out_norm = f16(layer.post_feedforward_layernorm.weight)
+            lw.post_norm = lw.pre_ffn_norm
+            types_ = getattr(cfg, "layer_types", None)
+            sliding = (types_[li] == "sliding_attention") if types_ else (li % 2 == 0)
+            lw.window = dc.sliding_window if sliding else 0
+        elif dc.sliding_window:
+            lw.window = dc.sliding_window
+        layers.append(lw)
+    embed = base.embed_tokens.weight.detach()
+    if embed.dtype != torch.float16:
+        embed = embed.to(torch.float16)
+    lm_head = _lin(model.lm_head)
+    eng = NativeDecoder(dc, embed, layers, f16(base.norm.weight), lm_head, device=dev)
+    return eng
+
+
+def native_engine_supported(model) -> bool:
+    cfg = getattr(model, "config", None)
+    if cfg is None or getattr(cfg, "model_type", None) not in NATIVE_ENGINE_TYPES:
+        return False
+    if not hasattr(model, "model") or not hasattr(model.model, "layers") or not hasattr(model, "lm_head"):
+        return False
+    first = model.model.layers[0].self_attn
+    if not (hasattr(first, "qkv_proj")):
+        return False
+    hd = getattr(cfg, "head_dim", None) or cfg.hidden_size // cfg.num_attention_heads
+    if hd not in (64, 96, 128, 256):
+        return False
+    if getattr(cfg, "model_type") in ("mixtral", "qwen2_moe"):
+        try:
+            from . import moe  # noqa: F401
+        except ImportError:
+            return False
+    return True
+
+
+_PLAIN_GENERATE_KEYS = {"max_new_tokens", "min_new_tokens", "do_sample", "temperature", "top_k", "top_p",
+                        "repetition_penalty", "eos_token_id", "pad_token_id", "streamer", "attention_mask",
+                        "use_cache", "num_beams", "max_length", "generation_config", "return_dict_in_generate"}
+
+
+def get_native_engine(model):
+    eng = getattr(model, "_native_engine", None)
+    if eng is None:
+        eng = build_native_decoder(model)
+        object.__setattr__(model, "_native_engine", eng)
+    return eng
+
+
+def native_generate(self, inputs=None, **kwargs):
+    """``model.generate`` front door: plain greedy / sampling calls on the GPU go to the native engine."""
+    input_ids = kwargs.pop("input_ids", inputs)
+    orig = self._hf_generate
+    try_native = (isinstance(input_ids, torch.Tensor) and input_ids.dim() == 2
+                  and next(self.parameters()).device.type == "cuda"
+                  and set(kwargs) <= _PLAIN_GENERATE_KEYS and kwargs.get("num_beams", 1) == 1
+                  and not kwargs.get("return_dict_in_generate", False) and native_engine_supported(self))
+    am = kwargs.get("attention_mask")
+    if try_native and am is not None and not bool(am.all()):
+        try_native = False  # left-padded batches go through the HF path
+    if not try_native:
+        if input_ids is not None:
+            kwargs["input_ids"] = input_ids
+        return orig(**kwargs) if inputs is None else orig(inputs, **{k: v for k, v in kwargs.items() if k != "input_ids"})
+    gc = kwargs.get("generation_config") or self.generation_config
+    max_new = kwargs.get("max_new_tokens")
+    if max_new is None:
+        ml = kwargs.get("max_length", getattr(gc, "max_length", None) or 20)
+        max_new = max(1, ml - input_ids.shape[1])
+    from ..transformers.utils import use_quantize_kv_cache
+    eng = get_native_engine(self)
+    out = eng.generate(
+        input_ids, max_new_tokens=max_new, min_new_tokens=kwargs.get("min_new_tokens", 0) or 0,
+        do_sample=kwargs.get("do_sample", getattr(gc, "do_sample", False)) or False,
+        temperature=kwargs.get("temperature", getattr(gc, "temperature", 1.0)) or 1.0,
+        top_k=kwargs.get("top_k", getattr(gc, "top_k", 0)) or 0,
+        top_p=kwargs.get("top_p", getattr(gc, "top_p", 1.0)) or 1.0,
+        repetition_penalty=kwargs.get("repetition_penalty", getattr(gc, "repetition_penalty", 1.0)) or 1.0,
+        eos_token_id=kwargs.get("eos_token_id", getattr(gc, "eos_token_id", None)),
+        pad_token_id=kwargs.get("pad_token_id", getattr(gc, "pad_token_id", None)),
+        streamer=kwargs.get("streamer"), kv_fp8=use_quantize_kv_cache())
+    for attr in ("first_cost", "rest_cost_mean", "first_token_time", "last_token_time", "peak_memory"):
+        object.__setattr__(self, attr, getattr(eng, attr))
+    return out
+
+
+def optimize_post(model):
+    """Bind the optimized forwards; install the native-engine generate front door."""
+    from ..transformers.convert import convert_forward
+    cfg = getattr(model, "config", None)
+    seen = set()
+    for m in model.modules():
+        cls = m.__class__
+        if cls in seen:
+            continue
+        name = cls.__name__
+        if name.endswith("RMSNorm") and hasattr(m, "weight") and m.weight is not None and m.weight.dim() == 1:
+            seen.add(cls)
+            convert_forward(model, cls, rms_norm_forward)
+        elif cls is nn.LayerNorm:
+            seen.add(cls)
+            convert_forward(model, cls, layer_norm_forward)
+        elif hasattr(m, "qkv_proj") and hasattr(m, "_merged_sizes") and hasattr(m, "o_proj"):
+            seen.add(cls)
+            convert_forward(model, cls, attention_forward)
+        elif all(hasattr(m, p) for p in ("gate_proj", "up_proj", "down_proj", "act_fn")) and not list(
+                getattr(m, "experts", [])):
+            seen.add(cls)
+            convert_forward(model, cls, mlp_forward)
+    if hasattr(model, "generate") and not hasattr(model, "_hf_generate") and cfg is not None \
+            and getattr(cfg, "model_type", None) in NATIVE_ENGINE_TYPES:
+        object.__setattr__(model, "_hf_generate", model.generate)
+        model.generate = types.MethodType(native_generate, model)
+    return model
