@@ -127,7 +127,8 @@ class LowBitEmbedding(torch.nn.Embedding):
                          _weight, True, device, dtype)
         from .low_bit_linear import FP4Params
         self.qweight = FP4Params(self.weight.data, requires_grad=False, quantized=False, _shape=None,
-                                 convert_shape_only=convert_shape_only, qtype=qtype, in_features=embedding_dim)
+                                 convert_shape_only=convert_shape_only, qtype=qtype, in_features=embedding_dim,
+                                 host_only=True)
         # rows are gathered individually: keep the host (row-block) layout on every device
         self.qweight.quantize("meta" if self.weight.device.type == "meta" else "cpu")
         self.qweight.requires_grad_(False)
@@ -141,7 +142,7 @@ class LowBitEmbedding(torch.nn.Embedding):
             from .low_bit_linear import FP4Params
             q = self.qweight
             self.qweight = FP4Params(q.data.to(probe.device), quantized=True, _shape=q._shape, qtype=q.qtype,
-                                     qlayout="host")
+                                     host_only=True)
         return self
 
     def forward(self, x: Tensor):

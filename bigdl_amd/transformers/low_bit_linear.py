@@ -76,7 +76,8 @@ class FP4Params(torch.nn.Parameter):
     """
 
     def __new__(cls, data=None, requires_grad=False, quantized=False, _shape=None, convert_shape_only=False,
-                qtype=None, imatrix=None, in_features=None, enable_scale_search=False, qlayout="host"):
+                qtype=None, imatrix=None, in_features=None, enable_scale_search=False, qlayout=None,
+                host_only=False):
         if data is None:
             data = torch.empty(0)
         self = torch.Tensor._make_subclass(cls, data, requires_grad)
@@ -88,13 +89,22 @@ class FP4Params(torch.nn.Parameter):
         self.imatrix = imatrix
         self.in_features = in_features
         self.enable_scale_search = enable_scale_search
-        self.qlayout = qlayout
+        # rows gathered one by one (embeddings) keep the host block order even on the device
+        self.host_only = host_only or (qlayout == "host" and data.device.type == "cuda")
         return self
+
+    @property
+    def qlayout(self) -> str:
+        """"t16" (device tile order) or "host" (ggml block order).  Derived from where the bytes live, because
+        ``nn.Module._apply`` swaps ``.data`` in place and drops attributes of the tensor ``to()`` returned."""
+        if self.quantized and self.data.device.type == "cuda" and self.qtype in Q.T16_QTYPES and not self.host_only:
+            return "t16"
+        return "host"
 
     def _clone_with(self, data, layout=None):
         return FP4Params(data, requires_grad=self.requires_grad, quantized=self.quantized, _shape=self._shape,
                          qtype=self.qtype, enable_scale_search=self.enable_scale_search,
-                         qlayout=layout or self.qlayout)
+                         host_only=self.host_only)
 
     def ggml_mse(self, w, ggml_qtype, device):
         w_quant = ggml_convert_qtype(w, ggml_qtype, device=device, convert_shape_only=self.convert_shape_only,
@@ -122,7 +132,6 @@ class FP4Params(torch.nn.Parameter):
                                                enable_scale_search=self.enable_scale_search)
             self.quantized = True
             self._shape = w.shape
-            self.qlayout = "host"
         return self
 
     def get_shape(self):
@@ -140,7 +149,7 @@ class FP4Params(torch.nn.Parameter):
             return self.quantize("meta")
         if dst == "cuda" and src == "cpu":
             self.quantize("cpu")
-            if self.qtype in Q.T16_QTYPES:
+            if self.qtype in Q.T16_QTYPES and not self.host_only:
                 tiled = ggml_q_format_convet_cpu2xpu(self.data, self._shape, self.qtype)
                 return self._clone_with(tiled.to(device, non_blocking=non_blocking), layout="t16")
             return self._clone_with(self.data.to(device, non_blocking=non_blocking), layout="host")

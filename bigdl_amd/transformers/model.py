@@ -124,7 +124,7 @@ def _assign_state_dict(model, state_dict, strict_missing=None):
             old = params[name]
             if isinstance(old, FP4Params):
                 new = FP4Params(value, requires_grad=False, quantized=True, _shape=old._shape, qtype=old.qtype,
-                                qlayout="host")
+                                host_only=old.host_only)
             else:
                 if old.device.type != "meta" and old.dtype != value.dtype and value.is_floating_point():
                     value = value.to(old.dtype)
