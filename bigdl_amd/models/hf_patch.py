@@ -357,10 +357,27 @@ def get_native_engine(model):
 
 
 def native_generate(self, inputs=None, **kwargs):
-    """``model.generate`` front door: plain greedy / sampling calls on the GPU go to the native engine."""
+    """``model.generate`` front door.  ``lookahead=n`` (or performance mode on a long prompt) selects prompt-lookup
+    decoding, an attached draft model selects self-speculative decoding, plain greedy / sampling calls on the GPU
+    go to the native engine, everything else to HuggingFace's generate."""
+    from ..transformers.lookup import SPEC_ONLY_KWARGS, performance_mode_lookahead
     input_ids = kwargs.pop("input_ids", inputs)
     orig = self._hf_generate
-    try_native = (isinstance(input_ids, torch.Tensor) and input_ids.dim() == 2
+    lookahead = kwargs.pop("lookahead", None)
+    is_ids = isinstance(input_ids, torch.Tensor) and input_ids.dim() == 2
+    if lookahead is None and is_ids:
+        lookahead = performance_mode_lookahead(input_ids.shape)
+    single = is_ids and input_ids.shape[0] == 1 and kwargs.get("num_beams", 1) in (None, 1)
+    if lookahead and single and hasattr(self, "lookup_generate"):
+        for k in SPEC_ONLY_KWARGS:
+            kwargs.pop(k, None)
+        return self.lookup_generate(input_ids, num_output_tokens=lookahead, **kwargs)
+    kwargs.pop("max_matching_ngram_size", None)
+    if getattr(self, "draft_model", None) is not None and single:
+        return self.speculative_generate(input_ids, **kwargs)
+    for k in SPEC_ONLY_KWARGS:
+        kwargs.pop(k, None)
+    try_native = (is_ids
                   and next(self.parameters()).device.type == "cuda"
                   and set(kwargs) <= _PLAIN_GENERATE_KEYS and kwargs.get("num_beams", 1) == 1
                   and not kwargs.get("return_dict_in_generate", False) and native_engine_supported(self))
@@ -416,8 +433,15 @@ def optimize_post(model):
                 getattr(m, "experts", [])):
             seen.add(cls)
             convert_forward(model, cls, mlp_forward)
-    if hasattr(model, "generate") and not hasattr(model, "_hf_generate") and cfg is not None \
-            and getattr(cfg, "model_type", None) in NATIVE_ENGINE_TYPES:
+    install_generate_front_door(model)
+    return model
+
+
+def install_generate_front_door(model):
+    if hasattr(model, "generate") and not hasattr(model, "_hf_generate"):
         object.__setattr__(model, "_hf_generate", model.generate)
         model.generate = types.MethodType(native_generate, model)
+        if not hasattr(model, "lookup_generate"):
+            from ..transformers.lookup import lookup_generate
+            model.lookup_generate = types.MethodType(lookup_generate, model)
     return model
