@@ -183,7 +183,10 @@ def attention_forward(self, hidden_states, position_embeddings=None, attention_m
         cos, sin = position_embeddings
         q, k = apply_rotary(q, k, cos, sin)
     if past_key_values is not None:
-        k, v = past_key_values.update(k, v, self.layer_idx)
+        if getattr(past_key_values, "wants_query", False):     # SnapKV selection scores the prompt with its last queries
+            k, v = past_key_values.update(k, v, self.layer_idx, query_states=q, num_key_value_groups=nq // nk)
+        else:
+            k, v = past_key_values.update(k, v, self.layer_idx)
     mod = sys.modules[self.__class__.__module__]
     eager = getattr(mod, "eager_attention_forward")
     interface = ALL_ATTENTION_FUNCTIONS.get_interface(self.config._attn_implementation, eager)
@@ -433,8 +436,36 @@ def optimize_post(model):
                 getattr(m, "experts", [])):
             seen.add(cls)
             convert_forward(model, cls, mlp_forward)
+    base = getattr(model, "model", None)
+    if isinstance(base, nn.Module) and hasattr(base, "layers") and not getattr(base, "_kv_hook_installed", False) \
+            and any(hasattr(getattr(l, "self_attn", None), "_merged_sizes") for l in base.layers):
+        base.register_forward_pre_hook(kv_cache_pre_hook, with_kwargs=True)
+        object.__setattr__(base, "_kv_hook_installed", True)
     install_generate_front_door(model)
     return model
+
+
+def kv_cache_pre_hook(module, args, kwargs):
+    """Forward pre-hook of the base model: choose the KV cache class by policy (fp8 storage, SnapKV compression,
+    else the block-preallocated cache) when the caller passed none or HF's empty default.  Reference: the cache
+    selection at the top of each model forward, e.g. models/llama.py:73-94."""
+    from transformers.cache_utils import DynamicCache
+    from ..transformers.kv import make_kv_cache
+    from ..transformers.utils import should_use_compresskv, use_quantize_kv_cache
+    use_cache = kwargs.get("use_cache")
+    if use_cache is None:
+        use_cache = getattr(module.config, "use_cache", False)
+    if not use_cache or module.training:
+        return None
+    pkv = kwargs.get("past_key_values")
+    if pkv is not None and not (type(pkv) is DynamicCache and pkv.get_seq_length() == 0):
+        return None
+    ids = kwargs.get("input_ids", args[0] if args else None)
+    emb = kwargs.get("inputs_embeds")
+    seq = ids.shape[1] if ids is not None else (emb.shape[1] if emb is not None else 0)
+    kwargs["past_key_values"] = make_kv_cache(use_quantize_kv_cache(), should_use_compresskv(prompt_len=seq))
+    kwargs["use_cache"] = True
+    return args, kwargs
 
 
 def install_generate_front_door(model):

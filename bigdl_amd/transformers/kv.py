@@ -187,6 +187,8 @@ class DynamicFp8Cache(Cache):
 
 
 class DynamicCompressCache(Cache):
+    wants_query = True
+
     def __init__(self, *args, window_size=32, max_capacity_prompt=1024, kernel_size=7, pooling="maxpool", **kwargs):
         cls = type("CompressLayerCfg", (self._layer_base(),), dict(window_size=window_size, kernel_size=kernel_size,
                                                                      max_capacity_prompt=max_capacity_prompt,

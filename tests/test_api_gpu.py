@@ -103,3 +103,42 @@ def test_layer_level_equivalence(tiny):
         oa = la.self_attn(x, position_embeddings=pe, attention_mask=None)[0]
         ob = lb.self_attn(x.clone(), position_embeddings=pe, attention_mask=None)[0]
         torch.testing.assert_close(ob, oa, rtol=2e-2, atol=5e-3)
+
+
+def test_lookup_and_speculative_on_native_engine(tiny):
+    """Multi-token verification steps of the native engine (graph replay of q_len tokens + KV counter rollback)
+    reproduce its own single-token greedy decoding."""
+    from ipex_llm.transformers import AutoModelForCausalLM
+    from bigdl_amd.transformers.speculative import attach_speculative
+    d, _ = tiny
+    q = AutoModelForCausalLM.from_pretrained(d, load_in_low_bit="sym_int8").half().to("cuda")
+    torch.manual_seed(11)
+    ids = torch.randint(0, 320, (1, 16)).repeat(1, 3).cuda()
+    ref = q.generate(ids, max_new_tokens=24, do_sample=False)
+    out = q.generate(ids, max_new_tokens=24, lookahead=3, max_matching_ngram_size=2)
+    assert out.shape == ref.shape and q.n_drafted > 0
+    assert (out == ref).float().mean() > 0.9
+    draft = AutoModelForCausalLM.from_pretrained(d, load_in_low_bit="sym_int4").half().to("cuda")
+    attach_speculative(q, draft)
+    out2 = q.generate(ids, max_new_tokens=24, max_step_draft=4, th_stop_draft=0.0, min_step_draft=1)
+    assert out2.shape == ref.shape and q.n_drafted > 0 and len(q.verify_time) == len(q.draft_time)
+    assert (out2 == ref).float().mean() > 0.9
+    out3 = q.generate(ids, max_new_tokens=12, do_sample=True, top_k=10)
+    assert out3.shape[1] == ids.shape[1] + 12
+
+
+def test_fp8_kv_cache_module_path(tiny, monkeypatch):
+    from ipex_llm.transformers import AutoModelForCausalLM
+    from bigdl_amd.transformers import kv
+    d, _ = tiny
+    q = AutoModelForCausalLM.from_pretrained(d, load_in_low_bit="sym_int8").half().to("cuda")
+    ids = torch.randint(0, 320, (1, 40)).cuda()
+    with torch.no_grad():
+        ref = q(ids, use_cache=True)
+        monkeypatch.setenv("IPEX_LLM_QUANTIZE_KV_CACHE", "1")
+        out = q(ids, use_cache=True)
+        assert isinstance(out.past_key_values, kv.DynamicFp8Cache)
+        nxt = ref.logits[:, -1:].argmax(-1)
+        a = q(nxt, past_key_values=ref.past_key_values, use_cache=True).logits.float()
+        b = q(nxt, past_key_values=out.past_key_values, use_cache=True).logits.float()
+    assert _rel(b, a) < 0.05
