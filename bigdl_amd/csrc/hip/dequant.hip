@@ -29,7 +29,8 @@ __device__ __forceinline__ void store8_out(void* p, int64_t idx, const float* v)
 
 // one wavefront per 16x128 tile, 4 wavefronts per workgroup
 template <int QT, int OUT>
-__global__ __launch_bounds__(256) void dequant_t16_kernel(const void* w, void* out, int N, int K, int64_t ldo) {
+__global__ __launch_bounds__(256) void dequant_t16_kernel(const void* w, void* out, int N, int K, int64_t ldo, int n_planes,
+                                                          int row0) {
   __shared__ _Float16 nf4_lut[16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int KT = (K + 127) >> 7, NT = (N + 15) >> 4;
@@ -37,10 +38,12 @@ __global__ __launch_bounds__(256) void dequant_t16_kernel(const void* w, void* o
     if (threadIdx.x < 16) nf4_lut[threadIdx.x] = (_Float16)NF4_VALUES[threadIdx.x];
     __syncthreads();
   }
-  const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
-  if (tile >= (int64_t)NT * KT) return;
-  const int nt = (int)(tile / KT), kt = (int)(tile % KT);
-  const T16Planes p = t16_planes(w, QT, N, K);
+  // rows [row0, row0 + N) of a [n_planes, K] buffer (row0 % 16 == 0) -> out rows [0, N)
+  const int64_t ltile = (int64_t)blockIdx.x * 4 + wave;
+  if (ltile >= (int64_t)NT * KT) return;
+  const int nt = (int)(ltile / KT), kt = (int)(ltile % KT);
+  const int64_t tile = ltile + (int64_t)(row0 >> 4) * KT;
+  const T16Planes p = t16_planes(w, QT, n_planes, K);
   const int r = lane & 15, g = lane >> 4;
   const int n = nt * 16 + r;
   constexpr int LO = (QT == Q_SYM_INT8 || QT == Q_FP8_E4M3 || QT == Q_FP8_E5M2) ? 8 : 4;
@@ -217,33 +220,37 @@ __global__ __launch_bounds__(256) void dequant_rows_kernel(const uint8_t* w, con
 using namespace bigdl;
 
 template <int QT>
-static int launch_dq(const void* w, void* out, int N, int K, int64_t ldo, int out_type, hipStream_t st) {
+static int launch_dq(const void* w, void* out, int N, int K, int64_t ldo, int out_type, int n_planes, int row0, hipStream_t st) {
   const int64_t tiles = (int64_t)((N + 15) / 16) * ((K + 127) / 128);
   const dim3 grid((unsigned)((tiles + 3) / 4)), block(256);
   switch (out_type) {
-    case OUT_F16: hipLaunchKernelGGL((dequant_t16_kernel<QT, OUT_F16>), grid, block, 0, st, w, out, N, K, ldo); break;
-    case OUT_BF16: hipLaunchKernelGGL((dequant_t16_kernel<QT, OUT_BF16>), grid, block, 0, st, w, out, N, K, ldo); break;
-    case OUT_F32: hipLaunchKernelGGL((dequant_t16_kernel<QT, OUT_F32>), grid, block, 0, st, w, out, N, K, ldo); break;
+    case OUT_F16: hipLaunchKernelGGL((dequant_t16_kernel<QT, OUT_F16>), grid, block, 0, st, w, out, N, K, ldo, n_planes, row0); break;
+    case OUT_BF16: hipLaunchKernelGGL((dequant_t16_kernel<QT, OUT_BF16>), grid, block, 0, st, w, out, N, K, ldo, n_planes, row0); break;
+    case OUT_F32: hipLaunchKernelGGL((dequant_t16_kernel<QT, OUT_F32>), grid, block, 0, st, w, out, N, K, ldo, n_planes, row0); break;
     default: return -3;
   }
   return HIP_CHECK_LAUNCH();
 }
 
-extern "C" int bigdl_dequant_t16(const void* w, void* out, int N, int K, int64_t ldo, int qtype, int out_type,
-                                 hipStream_t st) {
+// rows [row0, row0 + N) of the T16 buffer of an [n_total, K] matrix -> dense out [N, ldo]
+extern "C" int bigdl_dequant_t16(const void* w, void* out, int N, int K, int64_t ldo, int qtype, int out_type, int n_total,
+                                 int row0, hipStream_t st) {
+  if (n_total <= 0) { n_total = N; row0 = 0; }
+  if ((row0 & 15) || row0 < 0 || row0 + N > (n_total + 15) / 16 * 16) return -1;
+  const int n_planes = n_total;
   if (N <= 0 || K <= 0 || (K & 31) || (ldo & 7) || ((uintptr_t)w & 15) || ((uintptr_t)out & 15)) return -1;
   switch (qtype) {
-    case Q_SYM_INT4: return launch_dq<Q_SYM_INT4>(w, out, N, K, ldo, out_type, st);
-    case Q_ASYM_INT4: return launch_dq<Q_ASYM_INT4>(w, out, N, K, ldo, out_type, st);
-    case Q_WOQ_INT4: return launch_dq<Q_WOQ_INT4>(w, out, N, K, ldo, out_type, st);
-    case Q_FP4: return launch_dq<Q_FP4>(w, out, N, K, ldo, out_type, st);
-    case Q_NF4: return launch_dq<Q_NF4>(w, out, N, K, ldo, out_type, st);
-    case Q_SYM_INT5: return launch_dq<Q_SYM_INT5>(w, out, N, K, ldo, out_type, st);
-    case Q_ASYM_INT5: return launch_dq<Q_ASYM_INT5>(w, out, N, K, ldo, out_type, st);
-    case Q_FP6: return launch_dq<Q_FP6>(w, out, N, K, ldo, out_type, st);
-    case Q_SYM_INT8: return launch_dq<Q_SYM_INT8>(w, out, N, K, ldo, out_type, st);
-    case Q_FP8_E4M3: return launch_dq<Q_FP8_E4M3>(w, out, N, K, ldo, out_type, st);
-    case Q_FP8_E5M2: return launch_dq<Q_FP8_E5M2>(w, out, N, K, ldo, out_type, st);
+    case Q_SYM_INT4: return launch_dq<Q_SYM_INT4>(w, out, N, K, ldo, out_type, n_planes, row0, st);
+    case Q_ASYM_INT4: return launch_dq<Q_ASYM_INT4>(w, out, N, K, ldo, out_type, n_planes, row0, st);
+    case Q_WOQ_INT4: return launch_dq<Q_WOQ_INT4>(w, out, N, K, ldo, out_type, n_planes, row0, st);
+    case Q_FP4: return launch_dq<Q_FP4>(w, out, N, K, ldo, out_type, n_planes, row0, st);
+    case Q_NF4: return launch_dq<Q_NF4>(w, out, N, K, ldo, out_type, n_planes, row0, st);
+    case Q_SYM_INT5: return launch_dq<Q_SYM_INT5>(w, out, N, K, ldo, out_type, n_planes, row0, st);
+    case Q_ASYM_INT5: return launch_dq<Q_ASYM_INT5>(w, out, N, K, ldo, out_type, n_planes, row0, st);
+    case Q_FP6: return launch_dq<Q_FP6>(w, out, N, K, ldo, out_type, n_planes, row0, st);
+    case Q_SYM_INT8: return launch_dq<Q_SYM_INT8>(w, out, N, K, ldo, out_type, n_planes, row0, st);
+    case Q_FP8_E4M3: return launch_dq<Q_FP8_E4M3>(w, out, N, K, ldo, out_type, n_planes, row0, st);
+    case Q_FP8_E5M2: return launch_dq<Q_FP8_E5M2>(w, out, N, K, ldo, out_type, n_planes, row0, st);
     default: return -2;
   }
 }

@@ -42,6 +42,15 @@ struct GemvArgs {
   // combined on the fly while x is staged into LDS (saves the attention kernel's cross-split hand-off).
   const float* att_ws;
   int att_splits, att_D, att_G, att_Hkv, att_qlen, att_rows_alloc;
+  // optional mixture-of-experts mode: blockIdx.y = routed slot (token-major, top_k slots per token).  Slot s is
+  // a one-row product with the weights of expert slot_expert[s] (the experts' [N, K] matrices are stacked by rows
+  // into one [n_total, K] T16 buffer, N % 16 == 0, so expert e starts at tile row e * N/16), reads x row s / slot_xdiv, writes out row s scaled by slot_scale[s].  A negative expert id
+  // (expert owned by another rank) writes a zero row.  The expert ids are read on the device, so the step stays
+  // graph-replayable.
+  const int* slot_expert;
+  const float* slot_scale;
+  int n_total;
+  int slot_xdiv, n_slots;
 };
 
 template <int QT>
@@ -182,10 +191,32 @@ __global__ __launch_bounds__(NW * 64) void gemv_t16_kernel(GemvArgs a) {
   const int Kp = KT * 128;
   const int XS = Kp + XTAIL + XPAD;
   const int64_t nt = blockIdx.x;
+  int orow = 0, n_planes = a.N;
+  int64_t wt = 0;      // first weight tile row of the selected expert
+  float oscale = 1.0f;
+  if (a.slot_expert != nullptr) {
+    const int slot = blockIdx.y;
+    const int e = a.slot_expert[slot];
+    orow = slot;
+    if (e < 0) {
+      const int n0 = (int)nt * 16 + lane;
+      if (threadIdx.x < 16 && n0 < a.N) {
+        const int64_t oi = (int64_t)slot * a.ldo + n0;
+        if (a.out_type == OUT_F16) store_out<OUT_F16>(a.out, oi, 0.0f);
+        else if (a.out_type == OUT_BF16) store_out<OUT_BF16>(a.out, oi, 0.0f);
+        else store_out<OUT_F32>(a.out, oi, 0.0f);
+      }
+      return;
+    }
+    wt = (int64_t)e * (a.N >> 4);
+    n_planes = a.n_total;
+    a.x += (int64_t)(slot / a.slot_xdiv) * a.ldx;
+    if (a.slot_scale != nullptr) oscale = a.slot_scale[slot];
+  }
   T16Planes pl[NSTREAM];
-  pl[0] = t16_planes(a.w, QT, a.N, a.K);
-  if constexpr (GATE_UP) pl[1] = t16_planes(a.w2, QT, a.N, a.K);
-  const int64_t tile0 = nt * KT;
+  pl[0] = t16_planes(a.w, QT, n_planes, a.K);
+  if constexpr (GATE_UP) pl[1] = t16_planes(a.w2, QT, n_planes, a.K);
+  const int64_t tile0 = (wt + nt) * KT;
 
   // ---- 1. put the first round of weight loads in flight before anything else ----
   // this wavefront owns k-tiles wave, wave+NW, ...; indices past the end are clamped to the last tile
@@ -388,7 +419,8 @@ __global__ __launch_bounds__(NW * 64) void gemv_t16_kernel(GemvArgs a) {
       } else {
         v = act_apply(a.act, v);
       }
-      const int64_t oi = (int64_t)m * a.ldo + n;
+      v *= oscale;
+      const int64_t oi = (int64_t)(m + orow) * a.ldo + n;
       if (a.out_type == OUT_F16) {
         if (a.residual) v += load_out<OUT_F16>(a.residual, oi);
         store_out<OUT_F16>(a.out, oi, v);
@@ -407,7 +439,7 @@ constexpr size_t GEMV_XLDS_LIMIT = 48 * 1024;   // stage x in LDS when it fits t
 
 template <int QT, int MT, bool GATE_UP>
 static int launch_x(const GemvArgs& a, hipStream_t st) {
-  const dim3 grid((a.N + 15) / 16);
+  const dim3 grid((a.N + 15) / 16, a.slot_expert ? a.n_slots : 1);
   const int Kp = (a.K + 127) / 128 * 128;
   const size_t xbytes = (size_t)a.M * (Kp + XTAIL + XPAD) * 2;
   auto fixed = [&](int nw) { return (size_t)nw * (GATE_UP ? 2 : 1) * MT * 256 * 4 + MT * 16 * 4 + (QT == Q_NF4 ? 64 * 16 * 2 : 0); };

@@ -18,6 +18,24 @@ int gemv_launch_fp8_e5m2(const GemvArgs& a, bool gate_up, hipStream_t st);
 
 using namespace bigdl;
 
+static int dispatch(const GemvArgs& a, int qtype, hipStream_t stream) {
+  const bool gu = a.w2 != nullptr;
+  switch (qtype) {
+    case Q_SYM_INT4: return gemv_launch_sym_int4(a, gu, stream);
+    case Q_ASYM_INT4: return gemv_launch_asym_int4(a, gu, stream);
+    case Q_WOQ_INT4: return gemv_launch_woq_int4(a, gu, stream);
+    case Q_FP4: return gemv_launch_fp4(a, gu, stream);
+    case Q_NF4: return gemv_launch_nf4(a, gu, stream);
+    case Q_SYM_INT5: return gemv_launch_sym_int5(a, gu, stream);
+    case Q_ASYM_INT5: return gemv_launch_asym_int5(a, gu, stream);
+    case Q_FP6: return gemv_launch_fp6(a, gu, stream);
+    case Q_SYM_INT8: return gemv_launch_sym_int8(a, gu, stream);
+    case Q_FP8_E4M3: return gemv_launch_fp8_e4m3(a, gu, stream);
+    case Q_FP8_E5M2: return gemv_launch_fp8_e5m2(a, gu, stream);
+    default: return -2;
+  }
+}
+
 // Returns 0 on success; negative = rejected on the host before any launch.
 // M <= 64 (<= 32 with w2).  x fp16 with ldx % 8 == 0 and 16-byte aligned rows; K % 32 == 0.
 extern "C" int bigdl_gemv_lowbit(const void* x, const void* w, const void* w2, void* out, const void* bias,
@@ -43,19 +61,32 @@ extern "C" int bigdl_gemv_lowbit(const void* x, const void* w, const void* w2, v
   a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldo = ldo; a.act = act; a.out_type = out_type;
   a.att_ws = att_ws; a.att_splits = att_splits; a.att_D = att_D; a.att_G = att_G; a.att_Hkv = att_Hkv;
   a.att_qlen = att_qlen; a.att_rows_alloc = att_rows_alloc;
-  const bool gu = w2 != nullptr;
-  switch (qtype) {
-    case Q_SYM_INT4: return gemv_launch_sym_int4(a, gu, stream);
-    case Q_ASYM_INT4: return gemv_launch_asym_int4(a, gu, stream);
-    case Q_WOQ_INT4: return gemv_launch_woq_int4(a, gu, stream);
-    case Q_FP4: return gemv_launch_fp4(a, gu, stream);
-    case Q_NF4: return gemv_launch_nf4(a, gu, stream);
-    case Q_SYM_INT5: return gemv_launch_sym_int5(a, gu, stream);
-    case Q_ASYM_INT5: return gemv_launch_asym_int5(a, gu, stream);
-    case Q_FP6: return gemv_launch_fp6(a, gu, stream);
-    case Q_SYM_INT8: return gemv_launch_sym_int8(a, gu, stream);
-    case Q_FP8_E4M3: return gemv_launch_fp8_e4m3(a, gu, stream);
-    case Q_FP8_E5M2: return gemv_launch_fp8_e5m2(a, gu, stream);
-    default: return -2;
-  }
+  a.slot_expert = nullptr; a.slot_scale = nullptr; a.n_total = 0; a.slot_xdiv = 1; a.n_slots = 0;
+  return dispatch(a, qtype, stream);
+}
+
+// Routed-expert products for decode: for every slot s < n_slots (token-major, `slot_xdiv` consecutive slots share
+// one x row; pass 1 when every slot has its own row):
+//   out[s, :] = slot_scale[s] * f(x[s / slot_xdiv, :] . dequant(W[slot_expert[s]])^T)
+// w (and w2 for the fused gate/up + activation form) are T16 buffers of the experts' [N, K] matrices stacked by rows
+// ([n_experts * N, K], N % 16 == 0).  slot_expert (int32, device) entries must be < n_experts; negative = not on
+// this rank (zero row).
+extern "C" int bigdl_gemv_lowbit_moe(const void* x, const void* w, const void* w2, void* out, const int* slot_expert,
+                                     const float* slot_scale, const void* gamma, float eps, float gamma_offset,
+                                     int n_slots, int slot_xdiv, int n_experts, int N, int K, int ldx, int ldo,
+                                     int qtype, int act, int out_type, hipStream_t stream) {
+  if (n_slots <= 0 || n_slots > 65535 || slot_xdiv <= 0 || N <= 0 || K <= 0 || (K & 31) || (ldx & 7) || ((uintptr_t)x & 15) ||
+      ((uintptr_t)w & 15) || (N & 15) || n_experts <= 0 || slot_expert == nullptr)
+    return -1;
+  if (gamma && ((uintptr_t)gamma & 15)) return -1;
+  if (w2 && ((uintptr_t)w2 & 15)) return -1;
+  if (out_type < 0 || out_type > 2) return -3;
+  GemvArgs a;
+  a.x = (const _Float16*)x; a.w = w; a.w2 = w2; a.out = out; a.bias = nullptr; a.bias2 = nullptr;
+  a.residual = nullptr; a.gamma = (const _Float16*)gamma; a.eps = eps; a.gamma_offset = gamma_offset;
+  a.M = 1; a.N = N; a.K = K; a.ldx = ldx; a.ldo = ldo; a.act = act; a.out_type = out_type;
+  a.att_ws = nullptr; a.att_splits = 0; a.att_D = 0; a.att_G = 0; a.att_Hkv = 0; a.att_qlen = 1; a.att_rows_alloc = 0;
+  a.slot_expert = slot_expert; a.slot_scale = slot_scale; a.n_total = n_experts * N; a.slot_xdiv = slot_xdiv;
+  a.n_slots = n_slots;
+  return dispatch(a, qtype, stream);
 }

@@ -285,7 +285,7 @@ class NativeDecoder:
             h = h + o
             x = self._norm(h, lw.pre_ffn_norm if lw.pre_ffn_norm is not None else lw.post_norm)
             if lw.moe is not None:
-                m = lw.moe.forward_dense(x)
+                m = lw.moe.forward_dense(x, self)
             else:
                 g = self._linear_dense(x, lw.gate)
                 u = self._linear_dense(x, lw.up)
@@ -431,8 +431,7 @@ class NativeDecoder:
                 h.add_(tmp)
             ffn_norm = lw.pre_ffn_norm if lw.pre_ffn_norm is not None else lw.post_norm
             if lw.moe is not None:
-                lw.moe.forward_decode(self, h, ffn_norm, tmp)
-                h.add_(tmp)
+                lw.moe.forward_decode(self, h, ffn_norm)
                 continue
             a = act[:, : lw.gate.n]
             self._gemv(h, lw.gate, a, gamma=ffn_norm, w2=lw.up, act=cfg.act)
@@ -569,6 +568,8 @@ class NativeDecoder:
             for lin in (lw.qkv, lw.o, lw.gate, lw.up, lw.down):
                 if lin is not None:
                     tot += lin.nbytes
+            if lw.moe is not None:
+                tot += lw.moe.nbytes
         return tot
 
 
@@ -634,12 +635,34 @@ def build_random_decoder(cfg: DecoderConfig, qtype: int = Q.SYM_INT4, device="cu
     embed = (torch.randn(cfg.vocab_size, h, device=dev, generator=gen) * 0.02).to(torch.float16)
     layers = []
     for _ in range(cfg.num_layers):
-        layers.append(LayerWeights(input_norm=norm(), qkv=lin(cfg.q_size + 2 * cfg.kv_size, h), o=lin(h, cfg.q_size),
-                                   post_norm=norm(), gate=lin(i, h), up=lin(i, h), down=lin(h, i)))
+        lw = LayerWeights(input_norm=norm(), qkv=lin(cfg.q_size + 2 * cfg.kv_size, h), o=lin(h, cfg.q_size),
+                          post_norm=norm())
+        if cfg.num_experts:
+            from .moe import MoEWeights
+            e, mi = cfg.num_experts, cfg.moe_intermediate_size
+            assert qtype in Q.T16_QTYPES, "random MoE decoders are built in a device-tiled format"
+            shared = None
+            shared_router = None
+            if cfg.shared_expert_intermediate_size:
+                si = cfg.shared_expert_intermediate_size
+                shared = (lin(si, h), lin(si, h), lin(h, si))
+                shared_router = torch.randn(1, h, device=dev, generator=gen) / math.sqrt(h)
+            lw.moe = MoEWeights(
+                torch.randn(e, h, device=dev, generator=gen) / math.sqrt(h),
+                _random_t16(e * mi, h, qtype, dev, gen, scale=1.0 / math.sqrt(h)).data,
+                _random_t16(e * mi, h, qtype, dev, gen, scale=1.0 / math.sqrt(h)).data,
+                _random_t16(e * h, mi, qtype, dev, gen, scale=1.0 / math.sqrt(mi)).data,
+                qtype, e, cfg.top_k, h, mi, act=cfg.act, shared=shared, shared_router=shared_router)
+        else:
+            lw.gate, lw.up, lw.down = lin(i, h), lin(i, h), lin(h, i)
+        layers.append(lw)
     lm = lin(cfg.vocab_size, h, lm_head_qtype or qtype)
     return NativeDecoder(cfg, embed, layers, norm(), lm, device=device)
 
 
+MIXTRAL_8X7B = dict(vocab_size=32000, hidden_size=4096, intermediate_size=14336, num_layers=32, num_heads=32,
+                    num_kv_heads=8, head_dim=128, rms_eps=1e-5, max_position=32768, rope_theta=1e6, model_type="mixtral",
+                    num_experts=8, top_k=2, moe_intermediate_size=14336)
 LLAMA2_7B = dict(vocab_size=32000, hidden_size=4096, intermediate_size=11008, num_layers=32, num_heads=32,
                  num_kv_heads=32, head_dim=128, rms_eps=1e-5, max_position=4096, model_type="llama")
 TINY_LLAMA = dict(vocab_size=32000, hidden_size=2048, intermediate_size=5632, num_layers=22, num_heads=32,

@@ -433,7 +433,7 @@ def optimize_post(model):
             seen.add(cls)
             convert_forward(model, cls, attention_forward)
         elif all(hasattr(m, p) for p in ("gate_proj", "up_proj", "down_proj", "act_fn")) and not list(
-                getattr(m, "experts", [])):
+                getattr(m, "experts", [])) and not hasattr(m, "num_experts"):
             seen.add(cls)
             convert_forward(model, cls, mlp_forward)
     base = getattr(model, "model", None)

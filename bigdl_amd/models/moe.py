@@ -1,0 +1,215 @@
+"""Mixture-of-experts feed-forward for the native decoder engine (Mixtral, Qwen2-MoE layouts).
+
+Decode step (graph-replayable, no host round trip): router GEMM -> ``moe_route`` kernel (softmax + top-k on the
+device) -> routed gate/up GEMV with fused activation -> routed down GEMV scaled by the routing weight -> one
+combine kernel (sum over the k slots + gated shared expert + residual).  Only the selected experts' weights are
+streamed: for Mixtral-8x7B that is 2/8 of the expert bytes per token.
+
+Prefill: tokens are bucketed by expert and each non-empty expert runs dequant + dense GEMM on its bucket.
+
+Expert parallelism: ``expert_range=(lo, hi)`` keeps a contiguous slice of the experts on this rank; slots routed
+elsewhere produce zero rows and the partial outputs are summed with one all-reduce (every rank holds all tokens
+during decode, so this replaces the dispatch/return all-to-all pair by a single collective of [tokens, hidden]).
+
+Reference behaviour: python/llm/src/ipex_llm/transformers/models/mixtral.py:60-130 (``mixtral_moeblock_forward``),
+models/qwen2_moe.py:104-149, models/common.py:339-354 (``moe_group_topk`` / ``moe_softmax_topk``).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+from .. import qtypes as Q
+
+
+class MoEWeights:
+    def __init__(self, router, gate, up, down, qtype, num_experts, top_k, hidden, inter, act="silu", normalize=True,
+                 shared=None, shared_router=None, expert_range=None, group=None):
+        """gate/up: T16 buffers of [E*inter, hidden]; down: T16 buffer of [E*hidden, inter] (or dense fp16
+        [E, inter, hidden] / [E, hidden, inter] tensors with qtype = FP16).  shared: (gate Lin, up Lin, down Lin)."""
+        self.router = router.detach().to(torch.float16).contiguous()
+        self.gate, self.up, self.down = gate, up, down
+        self.qtype = qtype
+        self.fused = qtype in Q.T16_QTYPES
+        self.num_experts, self.top_k, self.hidden, self.inter = num_experts, top_k, hidden, inter
+        self.act, self.normalize = act, normalize
+        self.shared = shared
+        self.shared_router = None if shared_router is None else shared_router.detach().to(torch.float16).contiguous()
+        self.expert_range = expert_range        # (lo, hi) of the experts held locally, None = all
+        self.group = group                      # process group for the expert-parallel all-reduce
+        self.n_local = num_experts if expert_range is None else expert_range[1] - expert_range[0]
+
+    # ------------------------------------------------------------------ builders
+    @classmethod
+    def from_hf(cls, mlp, dc, lin_fn):
+        """From a converted HF sparse block (router ``gate`` + ``LowBitExperts`` or dense fused experts)."""
+        from ..transformers.low_bit_experts import LowBitExperts
+        ex = mlp.experts
+        router = mlp.gate.weight
+        normalize = bool(getattr(mlp.gate, "norm_topk_prob", True))
+        if isinstance(ex, LowBitExperts) and ex.gate_proj.weight.qlayout == "t16":
+            gate, up, down, qt = ex.gate_proj.weight.data, ex.up_proj.weight.data, ex.down_proj.weight.data, ex.qtype
+            act = ex._act_name() or "silu"
+        elif isinstance(ex, LowBitExperts):
+            from ..transformers.low_bit_linear import dequant_weight
+            e, i, h = ex.num_experts, ex.intermediate_dim, ex.hidden_dim
+            gate = dequant_weight(ex.gate_proj.weight, torch.float16).view(e, i, h)
+            up = dequant_weight(ex.up_proj.weight, torch.float16).view(e, i, h)
+            down = dequant_weight(ex.down_proj.weight, torch.float16).view(e, h, i)
+            qt, act = Q.FP16, ex._act_name() or "silu"
+        else:
+            i = ex.gate_up_proj.shape[1] // 2
+            gu = ex.gate_up_proj.data.to(torch.float16)
+            gate, up, down = gu[:, :i].contiguous(), gu[:, i:].contiguous(), ex.down_proj.data.to(torch.float16)
+            qt, act = Q.FP16, dc.act
+        shared = shared_router = None
+        if hasattr(mlp, "shared_expert"):
+            se = mlp.shared_expert
+            shared = (lin_fn(se.gate_proj), lin_fn(se.up_proj), lin_fn(se.down_proj))
+            shared_router = mlp.shared_expert_gate.weight
+        return cls(router, gate, up, down, qt, dc.num_experts, dc.top_k, dc.hidden_size, dc.moe_intermediate_size,
+                   act=act, normalize=normalize, shared=shared, shared_router=shared_router)
+
+    def shard_experts(self, rank: int, world: int, group=None):
+        """Keep experts [rank*E/world, (rank+1)*E/world) (expert parallelism).  T16 buffers are re-sliced plane by
+        plane through the dense form once at load time."""
+        assert self.num_experts % world == 0, "expert count must divide the expert-parallel degree"
+        per = self.num_experts // world
+        lo, hi = rank * per, (rank + 1) * per
+        if self.fused:
+            from ..ops.host import slice_t16_rows as requantize_rows
+            self.gate = requantize_rows(self.gate, self.qtype, self.num_experts * self.inter, self.hidden, lo * self.inter, per * self.inter)
+            self.up = requantize_rows(self.up, self.qtype, self.num_experts * self.inter, self.hidden, lo * self.inter, per * self.inter)
+            self.down = requantize_rows(self.down, self.qtype, self.num_experts * self.hidden, self.inter, lo * self.hidden, per * self.hidden)
+        else:
+            self.gate, self.up, self.down = (t[lo:hi].contiguous() for t in (self.gate, self.up, self.down))
+        self.expert_range, self.group, self.n_local = (lo, hi), group, per
+        return self
+
+    # ------------------------------------------------------------------ pieces
+    def route(self, x):
+        from ..ops import hip
+        logits = F.linear(x, self.router)
+        return hip.moe_route(logits, self.top_k, self.normalize, expert_range=self.expert_range)
+
+    def _expert_w(self, which, e, dtype=torch.float16):
+        from ..ops import hip
+        buf = getattr(self, which)
+        n, k = (self.hidden, self.inter) if which == "down" else (self.inter, self.hidden)
+        if self.fused:
+            return hip.dequant_t16(buf, self.qtype, n, k, dtype=dtype, total_rows=self.n_local * n, row0=e * n)
+        return buf[e]
+
+    def _shared_out(self, engine, x):
+        """(shared expert output [T, H], gate logits [T, 1]) or (None, None)"""
+        if self.shared is None:
+            return None, None
+        from ..ops import hip
+        sg, su, sd = self.shared
+        t = x.shape[0]
+        if t <= 32 and sg.fused and su.fused and sd.fused:
+            a = hip.gemv_lowbit(x, sg.w, sg.qtype, sg.n, sg.k, w2=su.w, act=self.act)
+            y = hip.gemv_lowbit(a, sd.w, sd.qtype, sd.n, sd.k)
+        else:
+            a = hip.act_mul(F.linear(x, sg.dense()), F.linear(x, su.dense()), self.act)
+            y = F.linear(a, sd.dense())
+        gl = F.linear(x, self.shared_router) if self.shared_router is not None else None
+        return y, gl
+
+    def _reduce(self, t):
+        if self.group is not None or (self.expert_range is not None and torch.distributed.is_initialized()):
+            torch.distributed.all_reduce(t, group=self.group)
+        return t
+
+    # ------------------------------------------------------------------ decode
+    def forward_decode(self, engine, h, gamma):
+        """h [m, H] fp16 (residual stream), updated in place: h += moe(rmsnorm(h))"""
+        from ..ops import hip
+        cfg = engine.cfg
+        x = hip.rms_norm(h, gamma, cfg.rms_eps, offset=cfg.norm_offset)
+        ids, w = self.route(x)
+        m, k = x.shape[0], self.top_k
+        if self.fused:
+            a = hip.gemv_lowbit_moe(x, self.gate, self.qtype, self.n_local, self.inter, self.hidden, ids.view(-1),
+                                    w2=self.up, slot_xdiv=k, act=self.act)
+            y = hip.gemv_lowbit_moe(a, self.down, self.qtype, self.n_local, self.hidden, self.inter, ids.view(-1),
+                                    slot_scale=w.view(-1))
+        else:
+            y = self._dense_slots(x, ids, w)
+        sy, gl = self._shared_out(engine, x)
+        if self.expert_range is not None:
+            part = torch.empty_like(h)
+            hip.moe_combine(y, k, part)
+            self._reduce(part)
+            y, k = part, 1
+        hip.moe_combine(y, k, h, shared=sy, shared_gate=gl, residual=h)
+        return h
+
+    def _dense_slots(self, x, ids, w):
+        """Unfused fallback for decode with dense expert weights: gather the selected experts and bmm."""
+        m, k = ids.shape
+        sel = ids.view(-1).clamp_min(0).long()
+        xs = x.repeat_interleave(k, 0).unsqueeze(1)                                   # [m*k, 1, H]
+        g = torch.bmm(xs, self.gate[sel].transpose(1, 2))
+        u = torch.bmm(xs, self.up[sel].transpose(1, 2))
+        from ..ops import hip
+        a = hip.act_mul(g.squeeze(1).contiguous(), u.squeeze(1).contiguous(), self.act)
+        y = torch.bmm(a.unsqueeze(1), self.down[sel].transpose(1, 2)).squeeze(1)
+        scale = (w.view(-1) * (ids.view(-1) >= 0)).to(y.dtype)
+        return (y * scale[:, None]).contiguous()
+
+    # ------------------------------------------------------------------ prefill
+    def forward_dense(self, x, engine=None):
+        """x [T, H] fp16 (already normalized) -> moe(x) [T, H]"""
+        from ..ops import hip
+        t, k = x.shape[0], self.top_k
+        ids, w = self.route(x)
+        if self.fused and t * k <= 64:
+            a = hip.gemv_lowbit_moe(x, self.gate, self.qtype, self.n_local, self.inter, self.hidden, ids.view(-1),
+                                    w2=self.up, slot_xdiv=k, act=self.act)
+            y = hip.gemv_lowbit_moe(a, self.down, self.qtype, self.n_local, self.hidden, self.inter, ids.view(-1),
+                                    slot_scale=w.view(-1))
+            out = y.view(t, k, -1).sum(1)
+        else:
+            flat = ids.view(-1).long()
+            local = flat >= 0
+            key = torch.where(local, flat, torch.full_like(flat, self.n_local))      # non-local slots sort last
+            order = torch.argsort(key, stable=True)
+            counts = torch.bincount(key, minlength=self.n_local + 1).tolist()
+            tok = torch.div(order, k, rounding_mode="floor")
+            xs = x[tok]
+            ws = w.view(-1)[order].to(x.dtype)
+            out = torch.zeros_like(x)
+            off = 0
+            for e in range(self.n_local):
+                c = counts[e]
+                if c == 0:
+                    continue
+                xe = xs[off:off + c]
+                a = hip.act_mul(F.linear(xe, self._expert_w("gate", e)), F.linear(xe, self._expert_w("up", e)), self.act)
+                ye = F.linear(a, self._expert_w("down", e))
+                out.index_add_(0, tok[off:off + c], ye * ws[off:off + c, None])
+                off += c
+        if self.expert_range is not None:
+            self._reduce(out)
+        sy, gl = self._shared_out(engine, x)
+        if sy is not None:
+            out = out + (torch.sigmoid(gl.float()).to(sy.dtype) * sy if gl is not None else sy)
+        return out
+
+    @property
+    def nbytes(self):
+        tot = sum(t.numel() * t.element_size() for t in (self.gate, self.up, self.down, self.router))
+        if self.shared is not None:
+            tot += sum(l.nbytes for l in self.shared)
+        return tot
+
+    def active_bytes(self):
+        """Bytes streamed per decoded token (top_k experts + shared expert + router)."""
+        per = sum(t.numel() * t.element_size() for t in (self.gate, self.up, self.down)) // max(1, self.n_local)
+        tot = per * self.top_k + self.router.numel() * 2
+        if self.shared is not None:
+            tot += sum(l.nbytes for l in self.shared)
+        return tot

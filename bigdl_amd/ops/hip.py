@@ -50,8 +50,11 @@ def lib():
         L.bigdl_from_e5m2.argtypes = [vp, vp, i64, ci, i64, i64, ci, vp]
         L.bigdl_repetition_penalty.argtypes = [vp, vp, ci, ci, ci, cf, ci, vp]
         L.bigdl_argmax.argtypes = [vp, vp, i64, ci, i64, ci, vp]
-        L.bigdl_dequant_t16.argtypes = [vp, vp, ci, ci, i64, ci, ci, vp]
+        L.bigdl_dequant_t16.argtypes = [vp, vp, ci, ci, i64, ci, ci, ci, ci, vp]
         L.bigdl_dequant_rows.argtypes = [vp, vp, vp, i64, i64, ci, ci, i64, ci, vp]
+        L.bigdl_gemv_lowbit_moe.argtypes = [vp, vp, vp, vp, vp, vp, vp, cf, cf, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp]
+        L.bigdl_moe_route.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, i64, ci, ci, vp]
+        L.bigdl_moe_combine.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, i64, vp]
         _LIB = L
     return _LIB
 
@@ -131,17 +134,104 @@ def gemv_lowbit(x, w, qtype, out_features, in_features, *, w2=None, bias=None, b
     return out
 
 
-def dequant_t16(w, qtype, out_features, in_features, dtype=torch.float16, out=None):
+def gemv_lowbit_moe(x, w, qtype, n_experts, out_features, in_features, slot_expert, *, w2=None, slot_scale=None,
+                    slot_xdiv=1, gamma=None, eps=1e-6, gamma_offset=0.0, act=None, out=None):
+    """Routed-expert products: ``out[s] = slot_scale[s] * f(x[s // slot_xdiv] @ dequant(W[slot_expert[s]])^T)``.
+
+    w / w2: T16 buffer of the experts' matrices stacked by rows, [n_experts * out_features, in_features].  slot_expert: int32 [n_slots] on
+    the device (values < n_experts; negative = skipped, zero row)."""
+    _need_cuda(x, w, w2, slot_expert, slot_scale, gamma, out)
+    if x.dim() != 2 or x.dtype != torch.float16 or x.stride(1) != 1 or x.shape[1] != in_features:
+        raise ValueError("x must be a 2-D fp16 tensor [rows, in_features] with contiguous rows")
+    if qtype not in Q.T16_QTYPES:
+        raise ValueError(f"qtype {qtype} has no fused GEMV kernel")
+    from .host import device_nbytes
+    if out_features % 16:
+        raise ValueError("expert out_features must be a multiple of 16")
+    need = device_nbytes(qtype, out_features * n_experts, in_features)
+    for ww in (w, w2):
+        if ww is not None and ww.numel() * ww.element_size() != need:
+            raise ValueError("expert weight buffer size does not match n_experts x [out_features, in_features]")
+    if slot_expert.dtype != torch.int32 or not slot_expert.is_contiguous():
+        raise ValueError("slot_expert must be contiguous int32")
+    n_slots = slot_expert.numel()
+    if (n_slots + slot_xdiv - 1) // slot_xdiv > x.shape[0]:
+        raise ValueError("x has too few rows for the slots")
+    if slot_scale is not None and (slot_scale.dtype != torch.float32 or slot_scale.numel() != n_slots
+                                   or not slot_scale.is_contiguous()):
+        raise ValueError("slot_scale must be contiguous fp32 [n_slots]")
+    if gamma is not None and (gamma.dtype != torch.float16 or gamma.numel() != in_features or not gamma.is_contiguous()):
+        raise ValueError("gamma must be contiguous fp16 [in_features]")
+    if out is None:
+        out = torch.empty((n_slots, out_features), dtype=torch.float16, device=x.device)
+    if out.shape != (n_slots, out_features) or out.stride(1) != 1:
+        raise ValueError("bad out tensor")
+    rc = lib().bigdl_gemv_lowbit_moe(_ptr(x), _ptr(w), _ptr(w2), _ptr(out), _ptr(slot_expert), _ptr(slot_scale),
+                                     _ptr(gamma), eps, gamma_offset, n_slots, slot_xdiv, n_experts, out_features,
+                                     in_features, x.stride(0), out.stride(0), qtype, ACT[act], _out_type(out.dtype),
+                                     _stream())
+    _check(rc, "gemv_lowbit_moe")
+    return out
+
+
+def moe_route(logits, top_k, normalize=True, expert_range=None, sigmoid_scores=False, ids=None, weights=None):
+    """Router logits [T, E] -> (expert ids int32 [T, top_k], weights fp32 [T, top_k]): softmax, top-k, optional
+    renormalisation.  ``expert_range=(lo, hi)`` keeps local experts only (others -1, kept ids rebased to lo)."""
+    _need_cuda(logits, ids, weights)
+    if logits.dim() != 2 or logits.stride(1) != 1 or logits.dtype not in (torch.float16, torch.float32):
+        raise ValueError("logits must be 2-D fp16/fp32 with contiguous rows")
+    t, e = logits.shape
+    if ids is None:
+        ids = torch.empty((t, top_k), dtype=torch.int32, device=logits.device)
+    if weights is None:
+        weights = torch.empty((t, top_k), dtype=torch.float32, device=logits.device)
+    if ids.numel() != t * top_k or weights.numel() != t * top_k or ids.dtype != torch.int32 \
+            or weights.dtype != torch.float32 or not ids.is_contiguous() or not weights.is_contiguous():
+        raise ValueError("bad ids / weights buffers")
+    lo, hi = expert_range if expert_range is not None else (0, 0)
+    rc = lib().bigdl_moe_route(_ptr(logits), _ptr(ids), _ptr(weights), t, e, top_k, int(bool(normalize)), lo, hi,
+                               logits.stride(0), int(logits.dtype == torch.float32), int(bool(sigmoid_scores)), _stream())
+    _check(rc, "moe_route")
+    return ids, weights
+
+
+def moe_combine(y, top_k, out, *, shared=None, shared_gate=None, residual=None):
+    """``out[t] = residual[t] + sum_k y[t*top_k + k] + sigmoid(shared_gate[t]) * shared[t]`` (fp16 rows)."""
+    _need_cuda(y, out, shared, shared_gate, residual)
+    t, h = out.shape
+    for z in (y, out, shared, residual):
+        if z is not None and (z.dtype != torch.float16 or not z.is_contiguous() or z.shape[-1] != h):
+            raise ValueError("moe_combine expects contiguous fp16 rows of equal width")
+    if y.shape[0] != t * top_k or (shared is not None and shared.shape[0] != t) \
+            or (residual is not None and residual.shape != out.shape):
+        raise ValueError("moe_combine: row counts do not match")
+    ld_gate = 0
+    if shared_gate is not None:
+        if shared_gate.dtype != torch.float16 or shared_gate.numel() < t:
+            raise ValueError("shared_gate must be fp16 with one logit per token")
+        ld_gate = shared_gate.stride(0) if shared_gate.dim() > 0 else 1
+    rc = lib().bigdl_moe_combine(_ptr(y), _ptr(shared), _ptr(shared_gate), _ptr(residual), _ptr(out), t, top_k, h, ld_gate,
+                                 _stream())
+    _check(rc, "moe_combine")
+    return out
+
+
+def dequant_t16(w, qtype, out_features, in_features, dtype=torch.float16, out=None, total_rows=None, row0=0):
+    """T16 buffer -> dense [out_features, in_features].  With ``total_rows`` the buffer holds a taller
+    [total_rows, in_features] matrix and rows [row0, row0 + out_features) are produced (row0 % 16 == 0)."""
     _need_cuda(w, out)
     if out is None:
         out = torch.empty((out_features, in_features), dtype=dtype, device=w.device)
     if out.shape != (out_features, in_features) or out.stride(1) != 1 or out.dtype != dtype:
         raise ValueError("bad out tensor")
     from .host import device_nbytes
-    if w.numel() * w.element_size() != device_nbytes(qtype, out_features, in_features):
+    total = total_rows if total_rows is not None else out_features
+    if w.numel() * w.element_size() != device_nbytes(qtype, total, in_features):
         raise ValueError("weight buffer size does not match the tiled layout")
+    if row0 % 16 or row0 < 0 or row0 + out_features > (total + 15) // 16 * 16:
+        raise ValueError("bad row range")
     rc = lib().bigdl_dequant_t16(_ptr(w), _ptr(out), out_features, in_features, out.stride(0), qtype,
-                                 _out_type(dtype), _stream())
+                                 _out_type(dtype), total, row0, _stream())
     _check(rc, "dequant_t16")
     return out
 

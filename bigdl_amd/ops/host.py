@@ -12,6 +12,7 @@ from pathlib import Path
 
 import torch
 
+from .. import qtypes as Q
 from ..qtypes import NF4, RTN_QTYPES, SYM_INT8_RTN, ASYM_INT4_RTN
 
 _LIB = None
@@ -194,3 +195,30 @@ def moe_indexes(selected_experts: torch.Tensor, num_experts: int):
     if rc != 0:
         raise ValueError("expert id out of range")
     return offsets, perm
+
+
+def t16_plane_nbytes(qtype: int, n: int, k: int):
+    """Byte sizes of the planes of a tiled device buffer, in storage order (codes, high bits, scales, mins)."""
+    np_, kp = (n + 15) // 16 * 16, (k + 127) // 128 * 128
+    lo_bits = 8 if qtype in (Q.SYM_INT8, Q.FP8E4, Q.FP8E5) else 4
+    hi_bits = {Q.SYM_INT5: 1, Q.ASYM_INT5: 1, Q.FP6: 2}.get(qtype, 0)
+    has_min = qtype in (Q.ASYM_INT4, Q.ASYM_INT5, Q.WOQ_INT4)
+    sizes = [np_ * kp * lo_bits // 8, np_ * kp * hi_bits // 8, np_ * (kp // 32) * 2, np_ * (kp // 32) * 2 if has_min else 0]
+    assert sum(sizes) == device_nbytes(qtype, n, k)
+    return sizes
+
+
+def slice_t16_rows(buf: torch.Tensor, qtype: int, n: int, k: int, row0: int, nrows: int) -> torch.Tensor:
+    """Rows [row0, row0 + nrows) of a tiled [n, k] buffer as a tiled [nrows, k] buffer (both multiples of 16).
+    Planes are tile-row-major, so a row range is one contiguous byte range per plane (any device)."""
+    if row0 % 16 or nrows % 16 or row0 + nrows > (n + 15) // 16 * 16:
+        raise ValueError("row range must be 16-aligned and inside the matrix")
+    np_ = (n + 15) // 16 * 16
+    flat = buf.view(torch.uint8).reshape(-1)
+    parts, off = [], 0
+    for sz in t16_plane_nbytes(qtype, n, k):
+        if sz:
+            per_row = sz // np_
+            parts.append(flat[off + row0 * per_row: off + (row0 + nrows) * per_row])
+        off += sz
+    return torch.cat(parts).contiguous()

@@ -175,6 +175,7 @@ def _replace_with_low_bit_linear(model, qtype, modules_to_not_convert=None, conv
                                  model_config=None, torch_dtype=torch.float32, mixed_precision=False, act_order=False,
                                  enable_scale_search=False):
     from .embedding import CPUEmbedding, LowBitEmbedding
+    from .low_bit_experts import LowBitExperts, is_fused_experts
     from .low_bit_linear import BF16Linear, FP4Params, FP16Linear, LowBitLinear
     has_been_replaced = False
     modules_to_not_convert = modules_to_not_convert or []
@@ -238,6 +239,14 @@ def _replace_with_low_bit_linear(model, qtype, modules_to_not_convert=None, conv
                 has_been_replaced = True
                 model._modules[name].requires_grad_(False)
                 module.weight = None
+        elif is_fused_experts(module) and qtype not in (Q.FP16, Q.BF16) and module.gate_up_proj.shape[-1] % 64 == 0 \
+                and module.down_proj.shape[-1] % 64 == 0:
+            cur_qtype, cur_imatrix = get_cur_qtype_and_imatrix(qtype, full_module_name, None, model_config)
+            cur_qtype = check_hidden_size(cur_qtype, module.gate_up_proj.shape[-1])
+            model._modules[name] = LowBitExperts.from_experts(module, cur_qtype, convert_shape_only,
+                                                              enable_scale_search=enable_scale_search)
+            has_been_replaced = True
+            continue
         elif cpu_embedding and type(module) == nn.Embedding:
             model._modules[name] = CPUEmbedding.from_embedding(module)
         elif embedding_qtype is not None and type(module) == nn.Embedding:

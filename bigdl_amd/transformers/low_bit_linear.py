@@ -199,6 +199,25 @@ def dequant_weight(weight: FP4Params, dtype=torch.float16) -> torch.Tensor:
     return host.dequantize(raw, weight.qtype, (n, k)).to(dtype)
 
 
+def dequant_weight_rows(weight: FP4Params, row0: int, nrows: int, dtype=torch.float16) -> torch.Tensor:
+    """Dense rows [row0, row0 + nrows) of a quantized parameter (one expert of a row-stacked expert matrix)."""
+    n, k = weight._shape
+    raw = weight.data.view(torch.uint8) if weight.data.dtype != torch.uint8 else weight.data
+    if weight.data.device.type == "cuda" and weight.qlayout == "t16" and row0 % 16 == 0:
+        from ..ops import hip
+        return hip.dequant_t16(weight.data, weight.qtype, nrows, k, dtype=dtype, total_rows=n, row0=row0)
+    if weight.data.device.type == "cuda" and weight.qlayout == "t16":
+        return dequant_weight(weight, dtype)[row0:row0 + nrows]
+    row_bytes = raw.numel() // n
+    sl = raw.view(-1)[row0 * row_bytes:(row0 + nrows) * row_bytes]
+    if sl.device.type == "cuda":
+        from ..ops import hip
+        if weight.qtype in (Q.IQ2_XXS, Q.IQ2_XS, Q.IQ1_S, Q.IQ1_M):
+            return host.dequantize(sl.cpu(), weight.qtype, (nrows, k)).to(sl.device, dtype)
+        return hip.dequant_rows(sl, weight.qtype, nrows, k, dtype=dtype)
+    return host.dequantize(sl, weight.qtype, (nrows, k)).to(dtype)
+
+
 def lowbit_matmul(x_2d: torch.Tensor, weight: FP4Params, out_features: int) -> torch.Tensor:
     """``x_2d @ dequant(weight)^T`` -> dtype of x_2d (reference op ``xe_linear.forward_new``)."""
     n, k = weight._shape

@@ -142,3 +142,41 @@ def test_fp8_kv_cache_module_path(tiny, monkeypatch):
         a = q(nxt, past_key_values=ref.past_key_values, use_cache=True).logits.float()
         b = q(nxt, past_key_values=out.past_key_values, use_cache=True).logits.float()
     assert _rel(b, a) < 0.05
+
+
+@pytest.mark.parametrize("family", ["mixtral", "qwen2_moe"])
+def test_moe_models_module_path_and_native_engine(family, tmp_path):
+    """Fused HF experts -> LowBitExperts; routed GEMV decode (module path and hipGraph engine) vs the CPU model."""
+    import copy
+    from transformers import MixtralConfig, MixtralForCausalLM, Qwen2MoeConfig, Qwen2MoeForCausalLM
+    from bigdl_amd.optimize import optimize_model
+    torch.manual_seed(0)
+    if family == "mixtral":
+        cfg = MixtralConfig(vocab_size=320, hidden_size=256, intermediate_size=512, num_hidden_layers=2,
+                            num_attention_heads=4, num_key_value_heads=2, num_local_experts=4, num_experts_per_tok=2,
+                            head_dim=64, max_position_embeddings=512)
+        m = MixtralForCausalLM(cfg).eval()
+    else:
+        cfg = Qwen2MoeConfig(vocab_size=320, hidden_size=256, intermediate_size=512, moe_intermediate_size=128,
+                             shared_expert_intermediate_size=256, num_hidden_layers=2, num_attention_heads=4,
+                             num_key_value_heads=2, num_experts=8, num_experts_per_tok=2, max_position_embeddings=512)
+        m = Qwen2MoeForCausalLM(cfg).eval()
+    q = optimize_model(copy.deepcopy(m), low_bit="sym_int8")
+    ids = torch.randint(0, 320, (1, 9))
+    with torch.no_grad():
+        cpu = q(ids).logits.float()
+    q = q.half().to("cuda")
+    with torch.no_grad():
+        gpu = q(ids.cuda()).logits.float().cpu()          # 9 tokens x 2 slots: routed GEMV path
+        long_ids = torch.randint(0, 320, (1, 70))
+        a = q(long_ids.cuda()).logits.float().cpu()       # bucketed dense path
+    assert _rel(gpu, cpu) < 0.03
+    out_native = q.generate(ids.cuda(), max_new_tokens=8, do_sample=False)
+    assert hasattr(q, "_native_engine")
+    out_hf = q._hf_generate(ids.cuda(), max_new_tokens=8, do_sample=False)
+    assert out_native.shape == out_hf.shape
+    assert (out_native == out_hf).float().mean() > 0.85
+    eng = q._native_engine
+    eng.cache.reset()
+    lg = eng.prefill(long_ids.cuda(), last_only=False)
+    assert _rel(lg.float().cpu(), a) < 0.03

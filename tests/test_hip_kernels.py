@@ -339,3 +339,83 @@ def test_gemv_combines_attention_partials(hip, cfg):
     got = hip.gemv_lowbit(dummy, dev, Q.SYM_INT4, n, k, out_dtype=torch.float32,
                           att_partials=(ws, splits, d, g, hkv, q_len, (g * q_len + 15) // 16 * 16))
     torch.testing.assert_close(got, ref, rtol=2e-3, atol=2e-3)
+
+
+# ---------------------------------------------------------------------------------------------
+# mixture of experts
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg", [(5, 8, 2, True), (3, 60, 4, False), (1, 128, 8, True), (9, 4, 1, True)])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_moe_route_matches_softmax_topk(hip, cfg, dtype):
+    t, e, k, norm = cfg
+    torch.manual_seed(20)
+    logits = (torch.randn(t, e) * 2).to(dtype).cuda()
+    ids, w = hip.moe_route(logits, k, normalize=norm)
+    p = torch.softmax(logits.float(), -1)
+    rv, ri = torch.topk(p, k, dim=-1)
+    if norm:
+        rv = rv / rv.sum(-1, keepdim=True)
+    assert torch.equal(ids.long(), ri)
+    torch.testing.assert_close(w, rv, rtol=1e-4, atol=1e-6)
+    # expert-parallel view: ids outside [lo, hi) are -1, inside are rebased; weights unchanged
+    lo, hi = e // 2, e
+    ids2, w2 = hip.moe_route(logits, k, normalize=norm, expert_range=(lo, hi))
+    exp = torch.where((ri >= lo) & (ri < hi), ri - lo, torch.full_like(ri, -1))
+    assert torch.equal(ids2.long(), exp)
+    torch.testing.assert_close(w2, rv, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["sym_int4", "asym_int4", "sym_int8", "fp6"])
+def test_routed_expert_gemv(hip, name):
+    torch.manual_seed(21)
+    qt = Q.ggml_tensor_qtype[name]
+    e, i, h, t, k = 6, 96, 256, 3, 2
+    gate, up, down = torch.randn(e * i, h) * 0.05, torch.randn(e * i, h) * 0.05, torch.randn(e * h, i) * 0.05
+    gd, gr = _quant_dev(gate, qt)
+    ud, ur = _quant_dev(up, qt)
+    dd, dr = _quant_dev(down, qt)
+    x = torch.randn(t, h).half()
+    ids = torch.tensor([[0, 5], [3, 3], [2, -1]], dtype=torch.int32)
+    wts = torch.rand(t, k)
+    a = hip.gemv_lowbit_moe(x.cuda(), gd, qt, e, i, h, ids.view(-1).cuda(), w2=ud, slot_xdiv=k, act="silu")
+    y = hip.gemv_lowbit_moe(a, dd, qt, e, h, i, ids.view(-1).cuda(), slot_scale=wts.view(-1).cuda())
+    ref_a = torch.zeros(t * k, i)
+    ref_y = torch.zeros(t * k, h)
+    for s in range(t * k):
+        ex = int(ids.view(-1)[s])
+        if ex < 0:
+            continue
+        xs = x[s // k].float()
+        g = gr[ex * i:(ex + 1) * i] @ xs
+        u = ur[ex * i:(ex + 1) * i] @ xs
+        ref_a[s] = torch.nn.functional.silu(g) * u
+        ref_y[s] = (dr[ex * h:(ex + 1) * h] @ a[s].float().cpu()) * wts.view(-1)[s]
+    torch.testing.assert_close(a.float().cpu(), ref_a, rtol=5e-3, atol=5e-3)
+    torch.testing.assert_close(y.float().cpu(), ref_y, rtol=5e-3, atol=5e-3)
+    # fused RMSNorm prologue per slot
+    gamma = (1 + 0.1 * torch.randn(h)).half()
+    a2 = hip.gemv_lowbit_moe(x.cuda(), gd, qt, e, i, h, ids.view(-1).cuda(), w2=ud, slot_xdiv=k, act="silu",
+                             gamma=gamma.cuda(), eps=1e-5)
+    xn = (x.float() * torch.rsqrt(x.float().pow(2).mean(-1, keepdim=True) + 1e-5) * gamma.float())
+    s = 1
+    ex = int(ids.view(-1)[s])
+    ref = torch.nn.functional.silu(gr[ex * i:(ex + 1) * i] @ xn[0]) * (ur[ex * i:(ex + 1) * i] @ xn[0])
+    torch.testing.assert_close(a2[s].float().cpu(), ref, rtol=2e-2, atol=2e-2)
+    # row-range dequant of one expert
+    de = hip.dequant_t16(gd, qt, i, h, dtype=torch.float32, total_rows=e * i, row0=4 * i).cpu()
+    torch.testing.assert_close(de, gr[4 * i:5 * i], rtol=1e-3, atol=1e-6)
+
+
+def test_moe_combine(hip):
+    torch.manual_seed(22)
+    t, k, h = 5, 3, 264
+    y = torch.randn(t * k, h).half().cuda()
+    sh = torch.randn(t, h).half().cuda()
+    gl = torch.randn(t, 1).half().cuda()
+    res = torch.randn(t, h).half().cuda()
+    out = torch.empty(t, h, dtype=torch.float16, device="cuda")
+    hip.moe_combine(y, k, out, shared=sh, shared_gate=gl, residual=res)
+    ref = y.float().view(t, k, h).sum(1) + torch.sigmoid(gl.float()) * sh.float() + res.float()
+    torch.testing.assert_close(out.float(), ref, rtol=2e-3, atol=2e-3)
+    hip.moe_combine(y, k, res, residual=res)            # in place on the residual stream
+    torch.testing.assert_close(res.float(), (ref - torch.sigmoid(gl.float()) * sh.float()), rtol=2e-3, atol=4e-3)
