@@ -68,7 +68,7 @@ class MoEWeights:
         if hasattr(mlp, "shared_expert"):
             se = mlp.shared_expert
             shared = (lin_fn(se.gate_proj), lin_fn(se.up_proj), lin_fn(se.down_proj))
-            shared_router = mlp.shared_expert_gate.weight
+            shared_router = lin_fn(mlp.shared_expert_gate).dense()      # [1, H]; may itself have been quantized
         return cls(router, gate, up, down, qt, dc.num_experts, dc.top_k, dc.hidden_size, dc.moe_intermediate_size,
                    act=act, normalize=normalize, shared=shared, shared_router=shared_router)
 

@@ -344,24 +344,47 @@ def rope_inplace(x, *, position_ids=None, inv_freq=None, cos=None, sin=None, int
     return x
 
 
+def _rows(t, d):
+    """[..., d] -> ([rows, d] view with one row stride, True) or (contiguous copy, False) when no such view exists."""
+    try:
+        return t.view(-1, d), True
+    except RuntimeError:
+        return t.contiguous().view(-1, d), False
+
+
 def to_e5m2(src, dst):
-    """src [..., D] float -> dst uint8 view of identical logical shape (last dim contiguous on both)."""
+    """src [..., D] float -> dst uint8 of identical logical shape (last dim contiguous on both; slices of a
+    larger buffer are fine)."""
     _need_cuda(src, dst)
+    if src.shape != dst.shape or dst.dtype != torch.uint8 or src.stride(-1) != 1 or dst.stride(-1) != 1:
+        raise ValueError("to_e5m2: shapes must match, dst uint8, last dim contiguous")
     d = src.shape[-1]
-    s2, d2 = src.reshape(-1, d), dst.reshape(-1, d)
+    s2, _ = _rows(src, d)
+    d2, direct = _rows(dst, d)
+    if not direct:
+        d2 = torch.empty(s2.shape, dtype=torch.uint8, device=dst.device)
     rc = lib().bigdl_to_e5m2(_ptr(s2), _ptr(d2), s2.shape[0], d, s2.stride(0), d2.stride(0), _out_type(src.dtype),
                              _stream())
     _check(rc, "to_e5m2")
+    if not direct:
+        dst.copy_(d2.view(dst.shape))
     return dst
 
 
 def from_e5m2(src, dst):
     _need_cuda(src, dst)
+    if src.shape != dst.shape or src.dtype != torch.uint8 or src.stride(-1) != 1 or dst.stride(-1) != 1:
+        raise ValueError("from_e5m2: shapes must match, src uint8, last dim contiguous")
     d = src.shape[-1]
-    s2, d2 = src.reshape(-1, d), dst.reshape(-1, d)
+    s2, _ = _rows(src, d)
+    d2, direct = _rows(dst, d)
+    if not direct:
+        d2 = torch.empty(s2.shape, dtype=dst.dtype, device=dst.device)
     rc = lib().bigdl_from_e5m2(_ptr(s2), _ptr(d2), s2.shape[0], d, s2.stride(0), d2.stride(0), _out_type(dst.dtype),
                                _stream())
     _check(rc, "from_e5m2")
+    if not direct:
+        dst.copy_(d2.view(dst.shape))
     return dst
 
 

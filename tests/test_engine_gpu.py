@@ -91,6 +91,15 @@ def test_graph_equals_eager_and_fp8_kv_close():
     c = model.generate(ids, max_new_tokens=12, kv_fp8=True)
     # e5m2 KV perturbs logits slightly; the first tokens of a greedy continuation normally agree
     assert c.shape == a.shape and torch.equal(c[:, :34], a[:, :34])
+    # the fp8 cache written by prefill is what decode reads: logits of the next step stay close to fp16-KV logits
+    lg = {}
+    for fp8 in (False, True):
+        model.ensure_cache(1, 64, fp8=fp8)
+        model.cache.reset()
+        model.prefill(ids)
+        lg[fp8] = model.decode(a[:, 33:34].contiguous(), 1)[0].clone()
+    rel = ((lg[True] - lg[False]).abs().mean() / lg[False].abs().mean()).item()
+    assert rel < 0.1, rel
 
 
 def test_sampling_and_eos():

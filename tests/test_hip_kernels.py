@@ -341,6 +341,24 @@ def test_gemv_combines_attention_partials(hip, cfg):
     torch.testing.assert_close(got, ref, rtol=2e-3, atol=2e-3)
 
 
+def test_e5m2_into_cache_slices(hip):
+    """Writes into / reads from a [B, H, n, D] slice of a larger cache buffer (no single row stride)."""
+    torch.manual_seed(23)
+    b, h, cap, d, n = 2, 3, 40, 64, 7
+    x = torch.randn(b, h, n, d).half().cuda()
+    cache = torch.zeros(b, h, cap, d, dtype=torch.uint8, device="cuda")
+    hip.to_e5m2(x, cache[:, :, 5:5 + n])
+    ref = x.to(torch.float8_e5m2).view(torch.uint8)
+    assert torch.equal(cache[:, :, 5:5 + n], ref) and int(cache[:, :, :5].sum()) == 0
+    out = torch.zeros(b, h, cap, d, dtype=torch.float16, device="cuda")
+    hip.from_e5m2(cache[:, :, 5:5 + n], out[:, :, 5:5 + n])
+    torch.testing.assert_close(out[:, :, 5:5 + n], ref.view(torch.float8_e5m2).half())
+    xt = x.transpose(-1, -2).contiguous()                      # V^T layout: [B, H, D, n] slice of [B, H, D, cap]
+    vc = torch.zeros(b, h, d, cap, dtype=torch.uint8, device="cuda")
+    hip.to_e5m2(xt, vc[:, :, :, 5:5 + n])
+    assert torch.equal(vc[:, :, :, 5:5 + n], xt.to(torch.float8_e5m2).view(torch.uint8))
+
+
 # ---------------------------------------------------------------------------------------------
 # mixture of experts
 # ---------------------------------------------------------------------------------------------
