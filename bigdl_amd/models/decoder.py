@@ -200,6 +200,10 @@ class NativeDecoder:
         self._static = {}
         self.attn_scale = cfg.attn_scale if cfg.attn_scale is not None else 1.0 / math.sqrt(cfg.head_dim)
         self.use_graph = True
+        # tensor parallelism (bigdl_amd/parallel/tensor_parallel.py ``shard_engine``): partial sums of the
+        # row-parallel projections are all-reduced over this group
+        self.tp_group = None
+        self.tp_world = 1
         # timing attributes with the reference's names (utils/benchmark_util_4_47.py:3372-3393)
         self.first_cost = self.rest_cost_mean = self.encoder_time = self.peak_memory = 0.0
         self.first_token_time = 0.0
@@ -234,6 +238,11 @@ class NativeDecoder:
         if lin.bias is not None:
             y = y + lin.bias
         return y
+
+    def _tp_reduce(self, t):
+        if self.tp_group is not None:
+            torch.distributed.all_reduce(t, group=self.tp_group)
+        return t
 
     def _norm(self, x, w, residual=None, res_out=None):
         from ..ops import hip
@@ -279,7 +288,7 @@ class NativeDecoder:
                 kk, vv = self._read_cache(li, past + s)
             attn = self._sdpa(q, kk, vv, past, lw.window)
             attn = attn.transpose(1, 2).reshape(b * s, hq * d)
-            o = self._linear_dense(attn, lw.o)
+            o = self._tp_reduce(self._linear_dense(attn, lw.o))
             if lw.post_attn_out_norm is not None:
                 o = self._norm(o, lw.post_attn_out_norm)
             h = h + o
@@ -290,7 +299,7 @@ class NativeDecoder:
                 g = self._linear_dense(x, lw.gate)
                 u = self._linear_dense(x, lw.up)
                 hip.act_mul(g, u, cfg.act)
-                m = self._linear_dense(g, lw.down)
+                m = self._tp_reduce(self._linear_dense(g, lw.down))
             if lw.post_ffn_out_norm is not None:
                 m = self._norm(m, lw.post_ffn_out_norm)
             h = h + m
@@ -423,11 +432,12 @@ class NativeDecoder:
                             window=lw.window, rope_table=self.rope_table if self.fused_rope else None,
                             interleaved=cfg.rope_interleaved, defer_combine=st["defer"] and lw.o.fused)
             att_partials = st["att_partials"] if st["defer"] and lw.o.fused else None
-            if lw.post_attn_out_norm is None:
+            if lw.post_attn_out_norm is None and self.tp_group is None:
                 self._gemv(attn, lw.o, h, residual=h, att_partials=att_partials)
             else:
-                self._gemv(attn, lw.o, tmp, att_partials=att_partials)
-                hip.rms_norm(tmp, lw.post_attn_out_norm, cfg.rms_eps, offset=cfg.norm_offset, out=tmp)
+                self._tp_reduce(self._gemv(attn, lw.o, tmp, att_partials=att_partials))
+                if lw.post_attn_out_norm is not None:
+                    hip.rms_norm(tmp, lw.post_attn_out_norm, cfg.rms_eps, offset=cfg.norm_offset, out=tmp)
                 h.add_(tmp)
             ffn_norm = lw.pre_ffn_norm if lw.pre_ffn_norm is not None else lw.post_norm
             if lw.moe is not None:
@@ -435,11 +445,12 @@ class NativeDecoder:
                 continue
             a = act[:, : lw.gate.n]
             self._gemv(h, lw.gate, a, gamma=ffn_norm, w2=lw.up, act=cfg.act)
-            if lw.post_ffn_out_norm is None:
+            if lw.post_ffn_out_norm is None and self.tp_group is None:
                 self._gemv(a, lw.down, h, residual=h)
             else:
-                self._gemv(a, lw.down, tmp)
-                hip.rms_norm(tmp, lw.post_ffn_out_norm, cfg.rms_eps, offset=cfg.norm_offset, out=tmp)
+                self._tp_reduce(self._gemv(a, lw.down, tmp))
+                if lw.post_ffn_out_norm is not None:
+                    hip.rms_norm(tmp, lw.post_ffn_out_norm, cfg.rms_eps, offset=cfg.norm_offset, out=tmp)
                 h.add_(tmp)
         self._gemv(h, self.lm_head, st["logits"], gamma=self.final_norm)
         if cfg.logit_scale != 1.0 or cfg.final_softcap > 0:

@@ -106,6 +106,16 @@ class FP4Params(torch.nn.Parameter):
                          qtype=self.qtype, enable_scale_search=self.enable_scale_search,
                          host_only=self.host_only)
 
+    def __deepcopy__(self, memo):
+        if id(self) in memo:
+            return memo[id(self)]
+        new = FP4Params(self.data.clone(), requires_grad=self.requires_grad, quantized=self.quantized,
+                        _shape=self._shape, convert_shape_only=self.convert_shape_only, qtype=self.qtype,
+                        imatrix=self.imatrix, in_features=self.in_features,
+                        enable_scale_search=self.enable_scale_search, host_only=self.host_only)
+        memo[id(self)] = new
+        return new
+
     def ggml_mse(self, w, ggml_qtype, device):
         w_quant = ggml_convert_qtype(w, ggml_qtype, device=device, convert_shape_only=self.convert_shape_only,
                                      enable_scale_search=self.enable_scale_search)

@@ -1,0 +1,140 @@
+"""Multi-process (gloo, world_size 2) checks of tensor parallelism, pipeline parallelism and the collective helpers:
+every distributed result must equal the single-process result."""
+import copy
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+from transformers import LlamaConfig, LlamaForCausalLM
+
+WORLD = 2
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _tiny(layers=4, hidden=128, inter=256):
+    torch.manual_seed(0)
+    cfg = LlamaConfig(vocab_size=320, hidden_size=hidden, intermediate_size=inter, num_hidden_layers=layers,
+                      num_attention_heads=4, num_key_value_heads=2, max_position_embeddings=256,
+                      tie_word_embeddings=False)
+    m = LlamaForCausalLM(cfg).eval()
+    m.generation_config.eos_token_id = None
+    m.generation_config.pad_token_id = 0
+    return m
+
+
+def _boot(rank, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD),
+                      LOCAL_RANK=str(rank), BIGDL_FORCE_CPU="1")
+    torch.set_num_threads(2)
+    from bigdl_amd.parallel import init_distributed
+    return init_distributed("gloo")
+
+
+def _run(fn, *args):
+    port = _free_port()
+    mp.spawn(fn, args=(port, *args), nprocs=WORLD, join=True)
+
+
+# ------------------------------------------------------------------------------------------------
+def _tp_worker(rank, port, low_bit, tmp):
+    _boot(rank, port)
+    from bigdl_amd.optimize import optimize_model
+    from bigdl_amd.parallel.tensor_parallel import tensor_parallel
+    full = optimize_model(_tiny(2, 512, 1024), low_bit=low_bit)       # k-quant blocks need 256-wide column shards
+    ids = torch.load(os.path.join(tmp, "ids.pt"))
+    with torch.no_grad():
+        ref = full(ids).logits
+    sharded = tensor_parallel(copy.deepcopy(full))
+    att = sharded.model.layers[0].self_attn
+    assert att.qkv_proj.out_len == full.model.layers[0].self_attn.qkv_proj.out_len // WORLD
+    assert sharded.model.layers[0].mlp.down_proj.in_len == 1024 // WORLD
+    with torch.no_grad():
+        out = sharded(ids).logits
+        gen = sharded.generate(ids, max_new_tokens=6, do_sample=False)
+        gen_ref = full.generate(ids, max_new_tokens=6, do_sample=False)
+    rel = ((out - ref).abs().mean() / ref.abs().mean()).item()
+    # same quantized weights, different summation order (bf16 layers round their partial sums before the reduce)
+    assert rel < (2e-2 if low_bit == "bf16" else 2e-3), rel
+    assert low_bit == "bf16" or torch.equal(gen, gen_ref)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("low_bit", ["sym_int4", "q4_k", "bf16"])
+def test_tensor_parallel_matches_single_process(tmp_path, low_bit):
+    torch.manual_seed(1)
+    torch.save(torch.randint(0, 320, (2, 9)), tmp_path / "ids.pt")
+    _run(_tp_worker, low_bit, str(tmp_path))
+
+
+# ------------------------------------------------------------------------------------------------
+def _pp_worker(rank, port, tmp):
+    _boot(rank, port)
+    from bigdl_amd.optimize import optimize_model
+    from bigdl_amd.transformers.pipeline_parallel import pipeline_parallel
+    full = optimize_model(_tiny(4), low_bit="sym_int8")
+    ids = torch.load(os.path.join(tmp, "ids.pt"))
+    ref = full.generate(ids, max_new_tokens=8, do_sample=False)
+    long_ids = ids.repeat(1, 3)                                   # > 10 tokens: lm_head keeps the last position only
+    ref_long = full.generate(long_ids, max_new_tokens=4, do_sample=False)
+    stage = pipeline_parallel(copy.deepcopy(full), WORLD, torch.float32)
+    assert len(stage.model.layers) == 2 and stage.layer_start == 2 * rank
+    out = stage.generate(ids, max_new_tokens=8)
+    assert torch.equal(out, ref), (out, ref)
+    out_long = stage.generate(long_ids, max_new_tokens=4)
+    assert torch.equal(out_long, ref_long)
+    assert stage.first_token_time > 0 and len(stage.next_token_time) == 3
+    # serving worker: two requests of different lengths in one micro-batch
+    from bigdl_amd.transformers.pipeline_parallel import PPModelWorker
+    import asyncio
+    w = PPModelWorker(None, rank, WORLD, "sym_int8", max_num_seqs=4, torch_dtype=torch.float32, model=stage)
+
+    async def drive():
+        if rank == 0:
+            await w.add_request("a", ids[0].tolist(), 5)
+            await w.add_request("b", ids[1, 3:].tolist(), 5)
+        return await w.process_step()
+    got = asyncio.run(drive())
+    assert got.shape == (2, 5)
+    assert torch.equal(got[0], ref[0, ids.shape[1]:ids.shape[1] + 5])       # unpadded row equals plain generation
+    single = full.generate(ids[1:2, 3:], max_new_tokens=5, do_sample=False)
+    assert torch.equal(got[1], single[0, -5:])                              # left-padded row too
+    if rank == 0:
+        toks = []
+        while not w.streamer["a"].empty():
+            toks.append(w.streamer["a"].get_nowait())
+        assert [t for t, _ in toks] == got[0].tolist() and toks[-1][1] is True
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pipeline_parallel_generate_matches_single_process(tmp_path):
+    torch.manual_seed(2)
+    torch.save(torch.randint(1, 320, (2, 7)), tmp_path / "ids.pt")
+    _run(_pp_worker, str(tmp_path))
+
+
+# ------------------------------------------------------------------------------------------------
+def _comm_worker(rank, port):
+    _boot(rank, port)
+    from bigdl_amd.parallel import all_reduce_coalesced_, new_groups
+    g = new_groups(tp=2, pp=1)
+    assert g["coords"] == (0, 0, rank)
+    ts = [torch.full((3, 5), float(rank + 1)), torch.full((7,), float(rank + 1)), torch.ones(4, dtype=torch.float64) * rank]
+    all_reduce_coalesced_(ts, bucket_mb=1, average=True)
+    assert torch.allclose(ts[0], torch.full((3, 5), 1.5)) and torch.allclose(ts[1], torch.full((7,), 1.5))
+    assert torch.allclose(ts[2], torch.full((4,), 0.5, dtype=torch.float64))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_groups_and_bucketed_all_reduce():
+    _run(_comm_worker)
