@@ -9,7 +9,7 @@ _LAZY = {
     "init_pipeline_parallel": "pipeline_parallel", "PPModelWorker": "pipeline_parallel",
     "LlamaForCausalLM": "modelling_bigdl", "ChatGLMForCausalLM": "modelling_bigdl",
     "GptneoxForCausalLM": "modelling_bigdl", "BloomForCausalLM": "modelling_bigdl",
-    "StarcoderForCausalLM": "modelling_bigdl",
+    "StarcoderForCausalLM": "modelling_bigdl", "BigdlNativeForCausalLM": "modelling_bigdl",
 }
 
 

@@ -32,6 +32,12 @@ def get_use_vllm():
     return _USE_VLLM
 
 
+def get_enable_ipex():
+    """The reference's CPU IPEX/TorchScript mode (``BIGDL_OPT_IPEX``, convert.py:1208-1248) has no counterpart on
+    this stack; callers that branch on it always take the regular path."""
+    return False
+
+
 def is_auto_gptq_available():
     try:
         import auto_gptq  # noqa: F401

@@ -193,3 +193,69 @@ def test_load_bloom_gguf(tmp_path):
     ids = torch.randint(3, 320, (1, 7))
     with torch.no_grad():
         torch.testing.assert_close(hf(ids).logits, m(ids).logits, rtol=1e-4, atol=1e-4)
+
+
+def _save_tiny_checkpoint(tmp_path):
+    from tokenizers import Tokenizer
+    from tokenizers.models import WordLevel
+    from tokenizers.pre_tokenizers import Whitespace
+    from transformers import PreTrainedTokenizerFast
+    m = _tiny_llama()
+    d = tmp_path / "hf"
+    m.save_pretrained(str(d))
+    vocab = {"<unk>": 0, "<s>": 1, "</s>": 2}
+    vocab.update({f"w{i}": i + 3 for i in range(317)})
+    t = Tokenizer(WordLevel(vocab, unk_token="<unk>"))
+    t.pre_tokenizer = Whitespace()
+    PreTrainedTokenizerFast(tokenizer_object=t, bos_token="<s>", eos_token="</s>", unk_token="<unk>").save_pretrained(str(d))
+    return m, str(d)
+
+
+def test_llm_convert_and_native_wrappers(tmp_path):
+    from ipex_llm import llm_convert
+    from ipex_llm.transformers import BigdlNativeForCausalLM
+    m, d = _save_tiny_checkpoint(tmp_path)
+    out = llm_convert(model=d, outfile=str(tmp_path / "out"), model_family="llama", outtype="int8", model_format="pth")
+    assert out.endswith(".gguf")
+    ld = GGUFFileLoader(out)
+    assert ld.config["general.file_type"] == 7 and ld.tensor_loader.info("blk.0.attn_q.weight")["type"] == G.GGML_Q8_0
+    llm = BigdlNativeForCausalLM.from_pretrained(out, model_family="llama", device="cpu")
+    ids = torch.randint(3, 320, (1, 8))
+    with torch.no_grad():
+        ref = m(ids).logits
+        got = llm.model(ids).logits.float()
+    assert ((got - ref).abs().mean() / ref.abs().mean()).item() < 0.05
+    res = llm("w1 w2 w3", max_tokens=5, temperature=0.0)
+    assert res["usage"]["completion_tokens"] <= 5 and isinstance(res["choices"][0]["text"], str)
+    assert len(llm.embed("w4 w5")) == 256
+
+
+def test_gptq_checkpoint_loads_without_auto_gptq(tmp_path):
+    """A GPTQ-packed checkpoint (qweight / qzeros / scales / g_idx + quantization_config) -> asym_int4 model."""
+    import json
+    from safetensors.torch import save_file
+    from ipex_llm.transformers import AutoModelForCausalLM
+    from bigdl_amd.transformers.gptq import pack_gptq
+    m, d = _save_tiny_checkpoint(tmp_path)
+    sd = {}
+    deq = {}
+    for k, v in m.state_dict().items():
+        if v.dim() == 2 and "proj" in k:
+            qw, qz, sc, gi = pack_gptq(v, group_size=64)
+            base = k[:-len(".weight")]
+            sd.update({base + ".qweight": qw, base + ".qzeros": qz, base + ".scales": sc, base + ".g_idx": gi})
+        else:
+            sd[k] = v.clone()
+    gdir = tmp_path / "gptq"
+    gdir.mkdir()
+    save_file(sd, str(gdir / "model.safetensors"))
+    cfg = json.load(open(d + "/config.json"))
+    cfg["quantization_config"] = {"quant_method": "gptq", "bits": 4, "group_size": 64, "desc_act": False, "sym": False}
+    json.dump(cfg, open(gdir / "config.json", "w"))
+    q = AutoModelForCausalLM.from_pretrained(str(gdir), load_in_4bit=True)
+    assert type(q.model.layers[0].mlp.down_proj).__name__ == "LowBitLinear"
+    ids = torch.randint(3, 320, (1, 8))
+    with torch.no_grad():
+        ref = m(ids).logits
+        got = q(ids).logits.float()
+    assert ((got - ref).abs().mean() / ref.abs().mean()).item() < 0.25        # 4-bit RTN with groups of 64
