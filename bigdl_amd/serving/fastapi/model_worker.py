@@ -1,0 +1,155 @@
+"""Single-GPU serving worker: a request queue drained by one generation loop.
+
+Reference: python/llm/src/ipex_llm/serving/fastapi/model_worker.py:28-210 (``ModelWorker.add_request`` /
+``process_step``: one ``generate`` thread per admitted request with a ``TextIteratorStreamer``).
+
+Here generation runs on the worker's executor thread through ``model.generate`` (the hipGraph decode engine for
+supported families), one request at a time per GPU stream -- decode at batch 1 is weight-bandwidth bound, so a
+second concurrent ``generate`` on the same GPU would only interleave with it -- and text deltas are handed to the
+event loop through an ``asyncio.Queue`` per request.  Requests wait in FIFO order; ``max_queue`` bounds the backlog.
+"""
+from __future__ import annotations
+
+import asyncio
+import threading
+import time
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import torch
+
+
+@dataclass
+class Request:
+    request_id: str
+    prompt: str
+    max_new_tokens: int = 32
+    min_new_tokens: int = 0
+    do_sample: bool = False
+    temperature: Optional[float] = None
+    top_p: Optional[float] = None
+    top_k: Optional[int] = None
+    repetition_penalty: Optional[float] = None
+    stop: List[str] = field(default_factory=list)
+    input_ids: Optional[List[int]] = None
+    arrival: float = field(default_factory=time.time)
+
+
+class _QueueStreamer:
+    """Streamer protocol of ``generate`` -> (delta text, finished) items on an asyncio queue (thread-safe)."""
+
+    def __init__(self, tokenizer, loop, queue, skip_prompt=True):
+        self.tokenizer, self.loop, self.queue = tokenizer, loop, queue
+        self.skip_prompt, self.first = skip_prompt, True
+        self.tokens: List[int] = []
+        self.printed = 0
+        self.n_generated = 0
+
+    def _emit(self, item):
+        self.loop.call_soon_threadsafe(self.queue.put_nowait, item)
+
+    def put(self, value):
+        if self.skip_prompt and self.first:
+            self.first = False
+            return
+        ids = value.reshape(-1).tolist() if isinstance(value, torch.Tensor) else list(value)
+        self.tokens.extend(ids)
+        self.n_generated += len(ids)
+        text = self.tokenizer.decode(self.tokens, skip_special_tokens=True)
+        # hold back a trailing partial character / word piece
+        if text.endswith("�"):
+            return
+        delta = text[self.printed:]
+        if delta:
+            self.printed = len(text)
+            self._emit((delta, False))
+
+    def end(self):
+        text = self.tokenizer.decode(self.tokens, skip_special_tokens=True)
+        self._emit((text[self.printed:], True))
+
+
+class ModelWorker:
+    def __init__(self, checkpoint=None, low_bit="sym_int4", model_type="normal", torch_dtype=torch.float16, model=None,
+                 tokenizer=None, device=None, max_queue: int = 256):
+        self.dtype = torch_dtype
+        self.model_type = model_type
+        self.device = device or ("cuda" if torch.cuda.is_available() else "cpu")
+        if model is None:
+            model, tokenizer = self.load_model(checkpoint, low_bit, model_type)
+        self.model, self.tokenizer = model, tokenizer
+        self.waiting_requests: asyncio.Queue = asyncio.Queue(maxsize=max_queue)
+        self.streamer: Dict[str, asyncio.Queue] = {}
+        self.stats = dict(requests=0, prompt_tokens=0, generated_tokens=0, busy_s=0.0, first_token_s=[], per_token_s=[])
+        self._lock = threading.Lock()
+
+    def load_model(self, model_path, low_bit="sym_int4", model_type="normal"):
+        from transformers import AutoTokenizer
+        from ...transformers import AutoModelForCausalLM
+        try:
+            model = AutoModelForCausalLM.load_low_bit(model_path, torch_dtype=self.dtype)
+        except Exception:
+            model = AutoModelForCausalLM.from_pretrained(model_path, load_in_low_bit=low_bit, torch_dtype=self.dtype,
+                                                         use_cache=True)
+        if self.device != "cpu":
+            model = model.to(self.dtype).to(self.device)
+        tokenizer = AutoTokenizer.from_pretrained(model_path)
+        return model.eval(), tokenizer
+
+    async def add_request(self, req: Request) -> asyncio.Queue:
+        q: asyncio.Queue = asyncio.Queue()
+        self.streamer[req.request_id] = q
+        await self.waiting_requests.put(req)
+        return q
+
+    def _generate(self, req: Request, loop):
+        tok = self.tokenizer
+        if req.input_ids is not None:
+            ids = torch.tensor([req.input_ids])
+        else:
+            ids = tok(req.prompt, return_tensors="pt").input_ids
+        dev = next(p for p in self.model.parameters() if p.numel() > 0).device
+        ids = ids.to(dev)
+        streamer = _QueueStreamer(tok, loop, self.streamer[req.request_id])
+        kw = dict(max_new_tokens=req.max_new_tokens, streamer=streamer)
+        if req.min_new_tokens:
+            kw["min_new_tokens"] = req.min_new_tokens
+        sample = req.do_sample or (req.temperature is not None and req.temperature > 0 and req.temperature != 1.0) \
+            or req.top_p is not None or req.top_k is not None
+        if sample:
+            kw.update(do_sample=True)
+            for k in ("temperature", "top_p", "top_k"):
+                if getattr(req, k) is not None:
+                    kw[k] = getattr(req, k)
+        else:
+            kw["do_sample"] = False
+        if req.repetition_penalty:
+            kw["repetition_penalty"] = req.repetition_penalty
+        t0 = time.time()
+        try:
+            with torch.inference_mode():
+                self.model.generate(ids, **kw)
+        except Exception as e:                      # surface the failure to the waiting client instead of hanging it
+            loop.call_soon_threadsafe(self.streamer[req.request_id].put_nowait, (f"[generation failed: {e}]", True))
+        dt = time.time() - t0
+        with self._lock:
+            s = self.stats
+            s["requests"] += 1
+            s["prompt_tokens"] += ids.shape[1]
+            s["generated_tokens"] += streamer.n_generated
+            s["busy_s"] += dt
+            fc, rc = getattr(self.model, "first_cost", None), getattr(self.model, "rest_cost_mean", None)
+            if fc:
+                s["first_token_s"] = (s["first_token_s"] + [float(fc)])[-1000:]
+            if rc:
+                s["per_token_s"] = (s["per_token_s"] + [float(rc)])[-1000:]
+
+    async def process_step(self):
+        """Take the next waiting request and run it to completion on the executor thread."""
+        req = await self.waiting_requests.get()
+        loop = asyncio.get_running_loop()
+        await loop.run_in_executor(None, self._generate, req, loop)
+        return req.request_id
+
+    def finish(self, request_id: str):
+        self.streamer.pop(request_id, None)
