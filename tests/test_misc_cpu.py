@@ -1,0 +1,48 @@
+"""torch.library fake ops, perplexity harness, benchmark config."""
+import os
+import sys
+
+import torch
+import yaml
+from transformers import LlamaConfig, LlamaForCausalLM
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_registered_ops_trace_on_meta():
+    from bigdl_amd.ops import torch_ops
+    names = torch_ops.registered_ops()
+    for n in ("forward_new", "dequant", "mlp_forward", "dequantize_rows", "rms_norm", "layer_norm", "rotary_half_inplaced",
+              "quantize_key_value", "moe_softmax_topk", "repetition_penalty_logits_process_inplaced"):
+        assert n in names
+    x = torch.empty(2, 5, 256, device="meta", dtype=torch.float16)
+    w = torch.empty(4096, device="meta", dtype=torch.uint8)
+    assert torch.ops.bigdl_amd.forward_new(x, w, 2, 64).shape == (2, 5, 64)
+    assert torch.ops.bigdl_amd.mlp_forward(x[0, :1], w, w, 1, 256, 512, 1, 2).shape == (1, 512)
+    ids, wt = torch.ops.bigdl_amd.moe_softmax_topk(torch.empty(7, 8, device="meta"), 2, True)
+    assert ids.shape == (7, 2) and ids.dtype == torch.int32 and wt.dtype == torch.float32
+
+
+def test_perplexity_low_bit_close_to_dense():
+    sys.path.insert(0, os.path.join(ROOT, "benchmark", "perplexity"))
+    from ppl import BigDLPPL
+    from bigdl_amd.optimize import optimize_model
+    torch.manual_seed(0)
+    cfg = LlamaConfig(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=4,
+                      num_key_value_heads=2, max_position_embeddings=256, tie_word_embeddings=False)
+    m = LlamaForCausalLM(cfg).eval()
+    toks = torch.randint(0, 320, (300,))
+    import copy
+    dense = BigDLPPL(model=copy.deepcopy(m)).perplexity_hf(toks, seq_len=64)
+    q8 = BigDLPPL(model=optimize_model(copy.deepcopy(m), low_bit="sym_int8")).perplexity_hf(toks, seq_len=64)
+    q4 = BigDLPPL(model=optimize_model(copy.deepcopy(m), low_bit="sym_int4")).perplexity_hf(toks, seq_len=64)
+    assert 200 < dense < 500                       # a random model is near uniform over 320 tokens
+    assert abs(q8 - dense) / dense < 0.01 and abs(q4 - dense) / dense < 0.05
+
+
+def test_benchmark_config_schema():
+    conf = yaml.safe_load(open(os.path.join(ROOT, "benchmark", "all_in_one", "config.yaml")))
+    for k in ("repo_id", "local_model_hub", "warm_up", "num_trials", "num_beams", "low_bit", "batch_size", "in_out_pairs",
+              "test_api", "cpu_embedding", "streaming"):
+        assert k in conf
+    assert "1024-128" in conf["in_out_pairs"]
