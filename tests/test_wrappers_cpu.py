@@ -1,0 +1,79 @@
+"""LangChain / LlamaIndex / FastChat wrappers on a tiny low-bit model (the third-party base packages are absent on
+the test boxes; the wrappers then run on their local stand-in bases with the same call surface)."""
+import json
+
+import pytest
+import torch
+from tokenizers import Tokenizer
+from tokenizers.models import WordLevel
+from tokenizers.pre_tokenizers import Whitespace
+from transformers import LlamaConfig, LlamaForCausalLM, PreTrainedTokenizerFast
+
+
+@pytest.fixture(scope="module")
+def tiny(tmp_path_factory):
+    torch.manual_seed(0)
+    cfg = LlamaConfig(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=4,
+                      num_key_value_heads=2, max_position_embeddings=256, tie_word_embeddings=False)
+    m = LlamaForCausalLM(cfg).eval()
+    m.generation_config.eos_token_id = None
+    vocab = {"<unk>": 0, "<s>": 1, "</s>": 2}
+    vocab.update({f"w{i}": i + 3 for i in range(317)})
+    t = Tokenizer(WordLevel(vocab, unk_token="<unk>"))
+    t.pre_tokenizer = Whitespace()
+    tok = PreTrainedTokenizerFast(tokenizer_object=t, bos_token="<s>", eos_token="</s>", unk_token="<unk>")
+    d = str(tmp_path_factory.mktemp("tiny_wrap"))
+    m.save_pretrained(d)
+    tok.save_pretrained(d)
+    return d
+
+
+def _ref(d, prompt, n):
+    from transformers import AutoTokenizer
+    from bigdl_amd.transformers import AutoModelForCausalLM
+    tok = AutoTokenizer.from_pretrained(d)
+    m = AutoModelForCausalLM.from_pretrained(d, load_in_4bit=True)
+    ids = tok(prompt, return_tensors="pt").input_ids
+    out = m.generate(ids, max_new_tokens=n, do_sample=False)
+    return tok.decode(out[0, ids.shape[1]:], skip_special_tokens=True)
+
+
+def test_langchain_llm_and_embeddings(tiny):
+    from ipex_llm.langchain.embeddings import TransformersEmbeddings
+    from ipex_llm.langchain.llms import TransformersLLM
+    llm = TransformersLLM.from_model_id(tiny, model_kwargs={"trust_remote_code": True})
+    assert llm.invoke("w1 w2 w3", max_new_tokens=6, do_sample=False) == _ref(tiny, "w1 w2 w3", 6)
+    full = llm.invoke("w1 w2 w3", max_new_tokens=6, do_sample=False)
+    stop = full.split()[2]
+    assert stop not in llm.invoke("w1 w2 w3", stop=[stop], max_new_tokens=6, do_sample=False)
+    emb = TransformersEmbeddings.from_model_id(tiny)
+    v = emb.embed_query("w4 w5")
+    assert len(v) == 128 and len(emb.embed_documents(["w1", "w2 w3"])) == 2
+
+
+def test_llamaindex_llm(tiny):
+    from ipex_llm.llamaindex.llms import IpexLLM
+    llm = IpexLLM.from_model_id(tiny, max_new_tokens=5, generate_kwargs={"do_sample": False})
+    assert llm.complete("w7 w8").text == _ref(tiny, "w7 w8", 5)
+    pieces = list(llm.stream_complete("w7 w8"))
+    assert pieces[-1].text == llm.complete("w7 w8").text
+    assert llm.metadata.num_output == 5
+
+
+def test_fastchat_worker_protocol(tiny):
+    from ipex_llm.serving.fastchat.ipex_llm_worker import BigDLLLMWorker
+    w = BigDLLLMWorker(model_path=tiny, load_in_low_bit="sym_int4", device="cpu", stream_interval=2)
+    chunks = list(w.generate_stream_gate({"prompt": "w1 w2", "max_new_tokens": 6, "temperature": 0.0, "echo": False}))
+    assert all(c.endswith(b"\0") for c in chunks)
+    last = json.loads(chunks[-1][:-1])
+    assert last["text"] == _ref(tiny, "w1 w2", 6) and last["usage"]["completion_tokens"] == 6
+    assert last["finish_reason"] == "length" and last["error_code"] == 0
+    assert w.generate_gate({"prompt": "w1 w2", "max_new_tokens": 6, "temperature": 0.0, "echo": False})["text"] == last["text"]
+    e = w.get_embeddings({"input": ["w1 w2", "w3"]})
+    assert len(e["embedding"]) == 2 and e["token_num"] == 3
+
+
+def test_vllm_hook_requires_vllm():
+    from ipex_llm.vllm.model_convert import _ipex_llm_convert
+    with pytest.raises(ImportError):
+        _ipex_llm_convert("sym_int4")
