@@ -1,0 +1,245 @@
+// Prefill / multi-token attention on gfx950: flash-style (online softmax, no S x L matrix), GQA-aware, causal or
+// bidirectional, optional additive mask, sliding window and tanh logit soft-capping.
+//
+// Replaces the reference's closed xe_addons.sdp_causal / sdp_non_causal / gemma2_sdp_causal kernels
+// (signatures python/llm/src/ipex_llm/transformers/xpu_ops.py:80-112, dispatcher
+// python/llm/src/ipex_llm/transformers/models/common.py:222-278).
+//
+// Mapping (wave64, v_mfma_f32_16x16x32_f16):
+//  * workgroup = 64 queries of one head (4 wavefronts x 16 queries), K/V visited in tiles of 64 keys staged in LDS
+//    (K row-major, V transposed while it is staged).
+//  * scores are computed transposed, S^T = K . Q^T: the MFMA result then holds, per lane, one query (column) and
+//    16 keys, which is exactly the B-operand layout of the second product O^T += V^T . P^T.  P never leaves
+//    registers, and every per-query quantity of the online softmax (running max, normaliser, rescale factor) is a
+//    per-lane scalar shared by the 4 lanes of a query via two xor-shuffles.
+//  * query blocks are scheduled heaviest first (causal: the last block sees the most keys).
+#include "common.h"
+
+namespace bigdl {
+
+struct PrefillArgs {
+  const _Float16* q; const _Float16* k; const _Float16* v; _Float16* out;
+  const _Float16* mask;              // additive [B, Sq, Lk] (strides m_sb, m_sq; last dim contiguous) or null
+  int B, Hq, Hkv, Sq, Lk;
+  int64_t q_sb, q_sh, q_ss, k_sb, k_sh, k_ss, v_sb, v_sh, v_ss, o_sb, o_ss, m_sb, m_sq;
+  float scale, softcap;
+  int causal, window;
+  int v_transposed;                  // v is [B, Hkv, D, Lk] (v_ss = stride of d, keys contiguous)
+};
+
+constexpr int PF_BM = 64, PF_BN = 64;
+
+template <int D, bool HAS_MASK, bool VT>
+__global__ __launch_bounds__(256) void attn_prefill_kernel(PrefillArgs a) {
+  constexpr int KS = D + 8;          // halves per K row in LDS (16 B pad)
+  constexpr int VS = PF_BN + 8;      // halves per V^T row
+  constexpr int DB = D / 16, STEPS = D / 32, CH = D / 8;
+  __shared__ __attribute__((aligned(16))) _Float16 Ks[PF_BN * KS];
+  __shared__ __attribute__((aligned(16))) _Float16 Vt[D * VS];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int qb = (int)gridDim.x - 1 - (int)blockIdx.x;
+  const int hq = blockIdx.y, b = blockIdx.z;
+  const int hkv = hq / (a.Hq / a.Hkv);
+  const int q0 = qb * PF_BM;
+  const int qi = q0 + wave * 16 + r;                 // this lane's query
+  const int offset = a.Lk - a.Sq;                    // causal alignment: query i sits at key position i + offset
+  const int pos = qi + offset;
+
+  half8 qf[STEPS];
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) {
+    half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    qf[s] = qi < a.Sq ? *(const half8*)(a.q + b * a.q_sb + hq * a.q_sh + (int64_t)qi * a.q_ss + 32 * s + 8 * g) : z;
+  }
+  float4v o[DB];
+#pragma unroll
+  for (int i = 0; i < DB; ++i) o[i] = float4v{0, 0, 0, 0};
+  float m = -INFINITY, l = 0.0f;
+  const float LOG2E = 1.4426950408889634f;
+
+  int kbeg = 0, kend = a.Lk;
+  if (a.causal) kend = min(a.Lk, q0 + PF_BM + offset);
+  if (a.window > 0) kbeg = max(0, q0 + offset - a.window + 1) / PF_BN * PF_BN;
+  const _Float16* kbase = a.k + b * a.k_sb + hkv * a.k_sh;
+  const _Float16* vbase = a.v + b * a.v_sb + hkv * a.v_sh;
+
+  // global -> registers for one K/V tile (issued one tile ahead of its use)
+  constexpr int NCH = PF_BN * CH / 256;
+  half8 kreg[NCH], vreg[NCH];
+  auto load_tile = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = threadIdx.x + 256 * i;
+      const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+      {
+        const int key = c / CH, dc = c % CH;
+        kreg[i] = k0 + key < a.Lk ? *(const half8*)(kbase + (int64_t)(k0 + key) * a.k_ss + 8 * dc) : z;
+        if constexpr (!VT) vreg[i] = k0 + key < a.Lk ? *(const half8*)(vbase + (int64_t)(k0 + key) * a.v_ss + 8 * dc) : z;
+      }
+      if constexpr (VT) {
+        const int d = c / (PF_BN / 8), kc = c % (PF_BN / 8);
+        const _Float16* vp = vbase + (int64_t)d * a.v_ss + k0 + 8 * kc;
+        if (k0 + 8 * kc + 8 <= a.Lk) {
+          vreg[i] = *(const half8*)vp;
+        } else {
+          half8 t = z;
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (k0 + 8 * kc + e < a.Lk) t[e] = vp[e];
+          vreg[i] = t;
+        }
+      }
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = threadIdx.x + 256 * i;
+      const int key = c / CH, dc = c % CH;
+      *(half8*)(Ks + key * KS + 8 * dc) = kreg[i];
+      if constexpr (VT) {
+        const int d = c / (PF_BN / 8), kc = c % (PF_BN / 8);
+        *(half8*)(Vt + d * VS + 8 * kc) = vreg[i];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) Vt[(8 * dc + e) * VS + key] = vreg[i][e];
+      }
+    }
+  };
+
+  if (kbeg < kend) load_tile(kbeg);
+  for (int k0 = kbeg; k0 < kend; k0 += PF_BN) {
+    __syncthreads();                 // the previous tile has been consumed
+    store_tile();
+    __syncthreads();
+    if (k0 + PF_BN < kend) load_tile(k0 + PF_BN);
+
+    // ---- S^T = K . Q^T : lane -> query r, keys 16*kb + 4g + reg ----
+    float4v s[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) s[kb] = float4v{0, 0, 0, 0};
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st)
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        const half8 kf = *(const half8*)(Ks + (16 * kb + r) * KS + 32 * st + 8 * g);
+        s[kb] = mfma16(kf, qf[st], s[kb]);
+      }
+
+    // ---- scale, soft-cap, mask ----
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int key = k0 + 16 * kb + 4 * g + e;
+        float v = s[kb][e] * a.scale;
+        if (a.softcap > 0.0f) v = a.softcap * tanhf(v / a.softcap);
+        if constexpr (HAS_MASK) {
+          if (qi < a.Sq && key < a.Lk) v += (float)a.mask[b * a.m_sb + (int64_t)qi * a.m_sq + key];
+        }
+        bool ok = key < a.Lk;
+        if (a.causal) ok = ok && key <= pos;
+        if (a.window > 0) ok = ok && key > pos - a.window;
+        v = ok ? v * LOG2E : -INFINITY;
+        s[kb][e] = v;
+        mloc = fmaxf(mloc, v);
+      }
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 16));
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+    const float mnew = fmaxf(m, mloc);
+    const float msafe = mnew == -INFINITY ? 0.0f : mnew;
+    const float alpha = exp2f(m - msafe);              // m = -inf -> 0
+    float lsum = 0.0f;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float p = exp2f(s[kb][e] - msafe);
+        s[kb][e] = p;
+        lsum += p;
+      }
+    lsum += __shfl_xor(lsum, 16);
+    lsum += __shfl_xor(lsum, 32);
+    l = l * alpha + lsum;
+    m = mnew;
+#pragma unroll
+    for (int i = 0; i < DB; ++i) o[i] *= alpha;
+
+    // ---- O^T += V^T . P^T : k slot (g, j) = key 32t + 4g + j (j < 4) / 32t + 16 + 4g + j - 4 ----
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      half8 pf;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        pf[e] = (_Float16)s[2 * t][e];
+        pf[4 + e] = (_Float16)s[2 * t + 1][e];
+      }
+#pragma unroll
+      for (int db = 0; db < DB; ++db) {
+        const _Float16* vr = Vt + (16 * db + r) * VS + 32 * t + 4 * g;
+        const half4 v0 = *(const half4*)vr, v1 = *(const half4*)(vr + 16);
+        const half8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        o[db] = mfma16(vf, pf, o[db]);
+      }
+    }
+  }
+
+  if (qi < a.Sq) {
+    const float inv = l > 0.0f ? 1.0f / l : 0.0f;
+    _Float16* op = a.out + b * a.o_sb + (int64_t)qi * a.o_ss + hq * D;
+#pragma unroll
+    for (int db = 0; db < DB; ++db) {
+      half4 h;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) h[e] = (_Float16)(o[db][e] * inv);
+      *(half4*)(op + 16 * db + 4 * g) = h;
+    }
+  }
+}
+
+}  // namespace bigdl
+
+using namespace bigdl;
+
+template <int D>
+static int launch_pf(const PrefillArgs& a, hipStream_t st) {
+  const dim3 grid((a.Sq + PF_BM - 1) / PF_BM, a.Hq, a.B), block(256);
+  if (a.mask) {
+    if (a.v_transposed) hipLaunchKernelGGL((attn_prefill_kernel<D, true, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((attn_prefill_kernel<D, true, false>), grid, block, 0, st, a);
+  } else {
+    if (a.v_transposed) hipLaunchKernelGGL((attn_prefill_kernel<D, false, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((attn_prefill_kernel<D, false, false>), grid, block, 0, st, a);
+  }
+  return HIP_CHECK_LAUNCH();
+}
+
+// q [B, Hq, Sq, D], k / v [B, Hkv, Lk, D] as strided fp16 views (element strides, last dim contiguous);
+// with v_transposed, v is [B, Hkv, D, Lk] (v_ss = stride between d rows; the layout of the engine's V^T cache,
+// which saves the in-kernel transpose).  out [B, Sq, Hq * D] (o_sb, o_ss; heads contiguous).
+// Query i attends to keys <= i + (Lk - Sq) when causal.
+extern "C" int bigdl_attn_prefill(const void* q, const void* k, const void* v, void* out, const void* mask, int B, int Hq,
+                                  int Hkv, int Sq, int Lk, int D, int64_t q_sb, int64_t q_sh, int64_t q_ss, int64_t k_sb,
+                                  int64_t k_sh, int64_t k_ss, int64_t v_sb, int64_t v_sh, int64_t v_ss, int64_t o_sb,
+                                  int64_t o_ss, int64_t m_sb, int64_t m_sq, float scale, float softcap, int causal,
+                                  int window, int v_transposed, hipStream_t st) {
+  if (B <= 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv || Sq <= 0 || Lk <= 0 || B > 65535 || Hq > 65535) return -1;
+  if (causal && Lk < Sq) return -1;
+  if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15) || ((uintptr_t)out & 7)) return -1;
+  if ((q_sb | q_sh | q_ss | k_sb | k_sh | k_ss | v_sb | v_sh | v_ss) & 7) return -1;    // 16-byte row starts
+  if ((o_sb | o_ss) & 3) return -1;
+  PrefillArgs a;
+  a.q = (const _Float16*)q; a.k = (const _Float16*)k; a.v = (const _Float16*)v; a.out = (_Float16*)out;
+  a.mask = (const _Float16*)mask; a.B = B; a.Hq = Hq; a.Hkv = Hkv; a.Sq = Sq; a.Lk = Lk;
+  a.q_sb = q_sb; a.q_sh = q_sh; a.q_ss = q_ss; a.k_sb = k_sb; a.k_sh = k_sh; a.k_ss = k_ss;
+  a.v_sb = v_sb; a.v_sh = v_sh; a.v_ss = v_ss; a.o_sb = o_sb; a.o_ss = o_ss; a.m_sb = m_sb; a.m_sq = m_sq;
+  a.scale = scale; a.softcap = softcap; a.causal = causal; a.window = window; a.v_transposed = v_transposed;
+  switch (D) {
+    case 64: return launch_pf<64>(a, st);
+    case 128: return launch_pf<128>(a, st);
+    default: return -2;
+  }
+}

@@ -20,6 +20,13 @@
 #pragma once
 #include "common.h"
 
+// Compile-time probe used only by benchmark/gemv_probe.hip to attribute kernel time (0 = production kernel):
+// 1 = return after the workgroup set-up, 2 = first round of loads + x staging + reduce/epilogue (no main loop),
+// 3 = all loads, dequantization and MFMA replaced by an xor of the loaded words.
+#ifndef GEMV_PROBE
+#define GEMV_PROBE 0
+#endif
+
 namespace bigdl {
 
 struct GemvArgs {
@@ -218,6 +225,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_t16_kernel(GemvArgs a) {
   if constexpr (GATE_UP) pl[1] = t16_planes(a.w2, QT, n_planes, a.K);
   const int64_t tile0 = (wt + nt) * KT;
 
+  if constexpr (GEMV_PROBE == 1) return;
   // ---- 1. put the first round of weight loads in flight before anything else ----
   // this wavefront owns k-tiles wave, wave+NW, ...; indices past the end are clamped to the last tile
   // (a valid address) and neutralised by reading the zero tail of x.
@@ -301,6 +309,18 @@ __global__ __launch_bounds__(NW * 64) void gemv_t16_kernel(GemvArgs a) {
   for (int j = 0; j < MT; ++j) xrow[j] = min(16 * j + r, a.M - 1) * XS + 8 * g;
 
   auto consume = [&](Tile<QT> (&tt)[NSTREAM][U], int base) {
+    if constexpr (GEMV_PROBE >= 2) {
+      uint32_t x = 0;
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int st = 0; st < NSTREAM; ++st) {
+          const Tile<QT>& t = tt[st][u];
+          x ^= t.lo0[0] ^ t.lo0[1] ^ t.lo0[2] ^ t.lo0[3] ^ (uint32_t)(float)t.d[0] ^ (uint32_t)(float)t.d[3];
+        }
+      acc[0][0][0][0] += __uint_as_float(x & 0x3f800000u);
+      return;
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int kt = wave + GEMV_NW * (base + u);
@@ -363,10 +383,10 @@ __global__ __launch_bounds__(NW * 64) void gemv_t16_kernel(GemvArgs a) {
   };
 
   // ---- 3. main loop: ping-pong between two register sets; a round is fetched while the other is consumed ----
-  for (int base = 0; base < ntw; base += 2 * U) {
-    if (base + U < ntw) fetch(tb, base + U);
+  for (int base = 0; base < (GEMV_PROBE == 2 ? min(ntw, 1) : ntw); base += 2 * U) {
+    if (GEMV_PROBE != 2 && base + U < ntw) fetch(tb, base + U);
     consume(ta, base);
-    if (base + U < ntw) {
+    if (GEMV_PROBE != 2 && base + U < ntw) {
       if (base + 2 * U < ntw) fetch(ta, base + 2 * U);
       consume(tb, base + U);
     }

@@ -282,12 +282,12 @@ class NativeDecoder:
             else:
                 kc[:, :, past:past + s] = k
                 vc[:, :, :, past:past + s] = v.transpose(-1, -2)
+                vt = vc[:, :, :, :s]
             if past == 0:
-                kk, vv = k, v
+                kk = k                       # attention reads the unquantized K / V^T of this call
             else:
-                kk, vv = self._read_cache(li, past + s)
-            attn = self._sdpa(q, kk, vv, past, lw.window)
-            attn = attn.transpose(1, 2).reshape(b * s, hq * d)
+                kk, vt = self._read_cache(li, past + s)
+            attn = self._sdpa(q, kk, vt, past, lw.window).reshape(b * s, hq * d)
             o = self._tp_reduce(self._linear_dense(attn, lw.o))
             if lw.post_attn_out_norm is not None:
                 o = self._norm(o, lw.post_attn_out_norm)
@@ -322,19 +322,28 @@ class NativeDecoder:
 
     def _read_cache(self, li, length):
         from ..ops import hip
+        """-> (K [B,Hkv,L,D], V^T [B,Hkv,D,L]) in fp16"""
         c = self.cache
         k = c.k[li][:, :, :length]
-        v = c.v[li][:, :, :, :length].transpose(-1, -2)
+        vt = c.v[li][:, :, :, :length]
         if c.fp8:
             kf = torch.empty(k.shape, dtype=torch.float16, device=self.device)
             hip.from_e5m2(k, kf)
-            vt = c.v[li][:, :, :, :length].contiguous()
             vf = torch.empty(vt.shape, dtype=torch.float16, device=self.device)
             hip.from_e5m2(vt, vf)
-            return kf, vf.transpose(-1, -2)
-        return k, v
+            return kf, vf
+        return k, vt
 
-    def _sdpa(self, q, k, v, past, window):
+    def _sdpa(self, q, k, vt, past, window):
+        """q [B,Hq,S,D], k [B,Hkv,past+S,D], vt = V^T [B,Hkv,D,past+S] -> [B, S, Hq*D]"""
+        cfg = self.cfg
+        if cfg.head_dim in (64, 128) and vt.stride(2) % 8 == 0 and vt.data_ptr() % 16 == 0:
+            from ..ops import hip
+            return hip.attn_prefill(q, k, vt, scale=self.attn_scale, causal=True, softcap=cfg.attn_softcap, window=window,
+                                    v_transposed=True)
+        return self._sdpa_torch(q, k, vt.transpose(-1, -2), past, window).transpose(1, 2).reshape(q.shape[0], q.shape[2], -1)
+
+    def _sdpa_torch(self, q, k, v, past, window):
         cfg = self.cfg
         s, L = q.shape[2], k.shape[2]
         simple = cfg.attn_softcap == 0 and not window and past == 0

@@ -55,6 +55,7 @@ def lib():
         L.bigdl_gemv_lowbit_moe.argtypes = [vp, vp, vp, vp, vp, vp, vp, cf, cf, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp]
         L.bigdl_moe_route.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, i64, ci, ci, vp]
         L.bigdl_moe_combine.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, i64, vp]
+        L.bigdl_attn_prefill.argtypes = [vp, vp, vp, vp, vp] + [ci] * 6 + [i64] * 13 + [cf, cf, ci, ci, ci, vp]
         _LIB = L
     return _LIB
 
@@ -509,4 +510,47 @@ def attn_decode(qkv, k_cache, v_cache, past_len, out, ws, counters, *, n_heads, 
                                      qkv.stride(0), lmax, head_dim, splits, window, int(fp8), int(bool(do_append)),
                                      int(bool(defer_combine)), _stream())
         _check(rc, "attn_decode")
+    return out
+
+
+def attn_prefill(q, k, v, *, scale, causal=True, mask=None, softcap=0.0, window=0, out=None, v_transposed=False):
+    """Flash-style attention for many query tokens.  q [B, Hq, Sq, D], k / v [B, Hkv, Lk, D]: fp16, any strides with
+    a contiguous last dim (views into a fused qkv buffer or a KV cache are fine); with ``v_transposed`` v is
+    [B, Hkv, D, Lk] (the engine's V^T cache layout, row stride multiple of 8).  mask: optional additive fp16
+    [B, 1 | none, Sq, Lk].  Returns out [B, Sq, Hq * D].  Causal alignment: query i sees keys <= i + (Lk - Sq)."""
+    _need_cuda(q, k, v, mask, out)
+    b, hq, sq, d = q.shape
+    hkv, lk = k.shape[1], k.shape[2]
+    if d not in (64, 128):
+        raise ValueError("attn_prefill supports head_dim 64 and 128")
+    for t in (q, k, v):
+        if t.dtype != torch.float16 or t.stride(-1) != 1:
+            raise ValueError("q / k / v must be fp16 with a contiguous last dim")
+    vshape = (b, hkv, d, lk) if v_transposed else (b, hkv, lk, d)
+    if tuple(v.shape) != vshape or k.shape[0] != b or k.shape[3] != d or hq % hkv:
+        raise ValueError("inconsistent q / k / v shapes")
+    if v_transposed and (v.stride(2) % 8 or v.data_ptr() % 16):
+        raise ValueError("transposed v needs 16-byte aligned rows")
+    if causal and lk < sq:
+        raise ValueError("causal attention needs at least as many keys as queries")
+    if out is None:
+        out = torch.empty((b, sq, hq * d), dtype=torch.float16, device=q.device)
+    if out.shape != (b, sq, hq * d) or out.stride(-1) != 1 or out.dtype != torch.float16:
+        raise ValueError("bad out tensor")
+    m_sb = m_sq = 0
+    if mask is not None:
+        if mask.dim() == 4:
+            if mask.shape[1] != 1:
+                raise ValueError("per-head masks are not supported")
+            mask = mask[:, 0]
+        if mask.dtype != torch.float16 or mask.stride(-1) != 1 or mask.shape[-2:] != (sq, lk) or mask.shape[0] not in (1, b):
+            raise ValueError("mask must be additive fp16 [B, (1,) Sq, Lk] with a contiguous last dim")
+        m_sb = mask.stride(0) if mask.shape[0] == b else 0
+        m_sq = mask.stride(1)
+    rc = lib().bigdl_attn_prefill(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(mask), b, hq, hkv, sq, lk, d,
+                                  q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
+                                  v.stride(0), v.stride(1), v.stride(2), out.stride(0), out.stride(1), m_sb, m_sq,
+                                  float(scale), float(softcap or 0.0), int(bool(causal)), int(window or 0),
+                                  int(bool(v_transposed)), _stream())
+    _check(rc, "attn_prefill")
     return out

@@ -437,3 +437,66 @@ def test_moe_combine(hip):
     torch.testing.assert_close(out.float(), ref, rtol=2e-3, atol=2e-3)
     hip.moe_combine(y, k, res, residual=res)            # in place on the residual stream
     torch.testing.assert_close(res.float(), (ref - torch.sigmoid(gl.float()) * sh.float()), rtol=2e-3, atol=4e-3)
+
+
+# ---------------------------------------------------------------------------------------------
+# prefill attention
+# ---------------------------------------------------------------------------------------------
+def _sdpa_ref(q, k, v, scale, causal, mask=None, softcap=0.0, window=0):
+    b, hq, sq, d = q.shape
+    hkv, lk = k.shape[1], k.shape[2]
+    kk = k.float().repeat_interleave(hq // hkv, 1)
+    vv = v.float().repeat_interleave(hq // hkv, 1)
+    s = torch.matmul(q.float(), kk.transpose(-1, -2)) * scale
+    if softcap:
+        s = softcap * torch.tanh(s / softcap)
+    if mask is not None:
+        s = s + mask.float()
+    qi = torch.arange(sq, device=q.device)[:, None] + (lk - sq)
+    ki = torch.arange(lk, device=q.device)[None]
+    ok = torch.ones(sq, lk, dtype=torch.bool, device=q.device)
+    if causal:
+        ok &= ki <= qi
+    if window:
+        ok &= ki > qi - window
+    s = s.masked_fill(~ok, float("-inf"))
+    p = torch.softmax(s, -1).nan_to_num(0.0)
+    return torch.matmul(p, vv).transpose(1, 2).reshape(b, sq, hq * d)
+
+
+@pytest.mark.parametrize("cfg", [(1, 8, 8, 128, 200, 200, True), (2, 8, 2, 64, 77, 77, True), (1, 4, 4, 128, 64, 300, True),
+                                 (1, 4, 2, 128, 130, 130, False), (2, 4, 1, 64, 33, 90, False)])
+def test_attn_prefill_matches_reference(hip, cfg):
+    b, hq, hkv, d, sq, lk, causal = cfg
+    torch.manual_seed(30)
+    # strided views into a fused qkv buffer, as the engine passes them
+    qkv = torch.randn(b, lk, (hq + 2 * hkv) * d, device="cuda").half()
+    q = qkv[:, lk - sq:, : hq * d].view(b, sq, hq, d).transpose(1, 2)
+    k = qkv[..., hq * d:(hq + hkv) * d].view(b, lk, hkv, d).transpose(1, 2)
+    v = qkv[..., (hq + hkv) * d:].view(b, lk, hkv, d).transpose(1, 2)
+    scale = d ** -0.5
+    out = hip.attn_prefill(q, k, v, scale=scale, causal=causal)
+    ref = _sdpa_ref(q, k, v, scale, causal)
+    torch.testing.assert_close(out.float(), ref, rtol=2e-2, atol=2e-3)
+    # V^T input (the engine's cache layout): a [B, Hkv, D, cap] buffer of which the first lk keys are valid
+    cap = (lk + 255) // 256 * 256
+    vt = torch.zeros(b, hkv, d, cap, device="cuda", dtype=torch.float16)
+    vt[..., :lk] = v.transpose(-1, -2)
+    out2 = hip.attn_prefill(q, k, vt[..., :lk], scale=scale, causal=causal, v_transposed=True)
+    torch.testing.assert_close(out2.float(), ref, rtol=2e-2, atol=2e-3)
+
+
+def test_attn_prefill_mask_softcap_window(hip):
+    torch.manual_seed(31)
+    b, hq, hkv, d, s = 2, 4, 2, 128, 150
+    q, k, v = (torch.randn(b, h, s, d, device="cuda").half() for h in (hq, hkv, hkv))
+    scale = d ** -0.5
+    out = hip.attn_prefill(q, k, v, scale=scale, causal=True, softcap=30.0, window=40)
+    torch.testing.assert_close(out.float(), _sdpa_ref(q, k, v, scale, True, softcap=30.0, window=40), rtol=2e-2, atol=2e-3)
+    # left-padded batch: additive mask hides the first keys of row 1; fully masked query rows give zeros
+    mask = torch.zeros(b, 1, s, s, device="cuda", dtype=torch.float16)
+    mask[1, :, :, :20] = float("-inf")
+    out = hip.attn_prefill(q, k, v, scale=scale, causal=True, mask=mask)
+    ref = _sdpa_ref(q, k, v, scale, True, mask=mask)
+    torch.testing.assert_close(out.float(), ref, rtol=2e-2, atol=2e-3)
+    assert float(out[1, :20].abs().max()) == 0.0
