@@ -57,19 +57,6 @@ __device__ __forceinline__ half8 load_kv8(const void* base, int64_t elem_off) {
   }
 }
 
-__device__ __forceinline__ uint8_t f16_to_e5m2(_Float16 h) {
-  // round-to-nearest-even on the dropped 8 mantissa bits, saturate to the largest finite value
-  union { _Float16 h; uint16_t u; } c;
-  c.h = h;
-  uint32_t u = c.u;
-  const uint32_t sign = u & 0x8000u;
-  uint32_t mag = u & 0x7fffu;
-  if (mag > 0x7c00u) return (uint8_t)((sign >> 8) | 0x7f);   // NaN
-  mag += 0x7fu + ((mag >> 8) & 1u);
-  if (mag >= 0x7c00u) mag = 0x7b00u;
-  return (uint8_t)((sign | mag) >> 8);
-}
-
 // D = head dim (multiple of 32), RT = number of 16-row tiles
 template <int D, bool FP8, int RT>
 __global__ __launch_bounds__(ATT_NW * 64) void attn_decode_kernel(AttnArgs a) {

@@ -200,9 +200,152 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(PrefillArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// RoPE + KV-cache append for a whole prompt, one launch per layer:
+//   q heads : rotated in place in the fused qkv buffer
+//   k heads : rotated in place (the attention of this call reads them unquantized) and copied to the K cache
+//             [B, Hkv, Lmax, D] as fp16 or e5m2
+//   v heads : transposed through LDS and written to the V^T cache [B, Hkv, D, Lmax] (fp16 or e5m2) and, when the
+//             cache is e5m2, also to an fp16 V^T scratch [B, Hkv, D, S_alloc] for this call's attention
+// cos/sin come from a table [max_pos, rot/2, 2] (fp32, attention scaling folded in).
+// ---------------------------------------------------------------------------------------------
+struct PrefillRopeArgs {
+  _Float16* qkv; void* kc; void* vc; _Float16* vt_scratch;
+  const float* table; const int64_t* position_ids;     // [B, S] or null (past + t)
+  int B, Hq, Hkv, S, D, past, Lmax, rot, interleaved, fp8;
+  int64_t ld, vt_ld;                                   // qkv row stride; scratch row stride (keys per d row)
+  int max_pos;
+};
+
+constexpr int PR_TOK = 64;
+
+__global__ __launch_bounds__(256) void prefill_rope_append_kernel(PrefillRopeArgs a) {
+  __shared__ __attribute__((aligned(16))) _Float16 tile[PR_TOK * (256 + 8)];   // V transpose staging, D <= 256
+  const int t0 = blockIdx.x * PR_TOK, head = blockIdx.y, b = blockIdx.z;
+  const int D = a.D, CH = D / 8;
+  const bool is_q = head < a.Hq, is_k = !is_q && head < a.Hq + a.Hkv;
+  _Float16* base = a.qkv + ((int64_t)b * a.S) * a.ld + (int64_t)head * D;
+  if (is_q || is_k) {
+    const int hk = head - a.Hq;
+    const int half_rot = a.rot / 2;
+    for (int it = threadIdx.x; it < PR_TOK * CH; it += 256) {
+      const int tl = it / CH, c = it % CH, t = t0 + tl;
+      if (t >= a.S) continue;
+      const int d0 = 8 * c;
+      int pos = a.past + t;
+      if (a.position_ids) pos = (int)a.position_ids[(int64_t)b * a.S + t];
+      pos = min(max(pos, 0), a.max_pos - 1);
+      _Float16* row = base + (int64_t)t * a.ld;
+      const int64_t kdst = (((int64_t)b * a.Hkv + hk) * a.Lmax + a.past + t) * D;
+      auto put_k = [&](int d, half8 v) {
+        if (!is_k) return;
+        if (a.fp8) {
+          uint2v pk;
+          uint32_t w[2] = {0, 0};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) w[e >> 2] |= (uint32_t)f16_to_e5m2(v[e]) << (8 * (e & 3));
+          pk.x = w[0]; pk.y = w[1];
+          *(uint2v*)((uint8_t*)a.kc + kdst + d) = pk;
+        } else {
+          *(half8*)((_Float16*)a.kc + kdst + d) = v;
+        }
+      };
+      if (d0 >= a.rot) {                                     // beyond the rotary dim: pass through
+        put_k(d0, *(const half8*)(row + d0));
+      } else if (a.interleaved) {                            // adjacent pairs inside the chunk
+        half8 x = *(const half8*)(row + d0), y;
+        const float* cs = a.table + ((int64_t)pos * half_rot + d0 / 2) * 2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float c0 = cs[2 * e], s0 = cs[2 * e + 1];
+          const float x0 = (float)x[2 * e], x1 = (float)x[2 * e + 1];
+          y[2 * e] = (_Float16)(x0 * c0 - x1 * s0);
+          y[2 * e + 1] = (_Float16)(x1 * c0 + x0 * s0);
+        }
+        *(half8*)(row + d0) = y;
+        put_k(d0, y);
+      } else if (d0 < half_rot) {                            // half layout: pair (i, i + rot/2)
+        half8 x = *(const half8*)(row + d0), z = *(const half8*)(row + d0 + half_rot), y0, y1;
+        const float* cs = a.table + ((int64_t)pos * half_rot + d0) * 2;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float c0 = cs[2 * e], s0 = cs[2 * e + 1];
+          const float x0 = (float)x[e], x1 = (float)z[e];
+          y0[e] = (_Float16)(x0 * c0 - x1 * s0);
+          y1[e] = (_Float16)(x1 * c0 + x0 * s0);
+        }
+        *(half8*)(row + d0) = y0;
+        *(half8*)(row + d0 + half_rot) = y1;
+        put_k(d0, y0);
+        put_k(d0 + half_rot, y1);
+      }                                                      // chunks in [rot/2, rot) are written by their partner
+    }
+    return;
+  }
+  // ---- V: [tokens, D] -> V^T rows ----
+  const int hv = head - a.Hq - a.Hkv;
+  const int TS = D + 8;
+  for (int it = threadIdx.x; it < PR_TOK * CH; it += 256) {
+    const int tl = it / CH, c = it % CH, t = t0 + tl;
+    half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (t < a.S) v = *(const half8*)(base + (int64_t)t * a.ld + 8 * c);
+    *(half8*)(tile + tl * TS + 8 * c) = v;
+  }
+  __syncthreads();
+  const int ntok = min(PR_TOK, a.S - t0);
+  // each item: one d row, 8 consecutive tokens
+  for (int it = threadIdx.x; it < D * (PR_TOK / 8); it += 256) {
+    const int d = it / (PR_TOK / 8), tc = it % (PR_TOK / 8);
+    if (8 * tc >= ntok) continue;
+    half8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = tile[(8 * tc + e) * TS + d];
+    const int64_t row = ((int64_t)b * a.Hkv + hv) * D + d;
+    const int key = a.past + t0 + 8 * tc;
+    const bool full = 8 * tc + 8 <= ntok;
+    if (a.fp8) {
+      uint8_t* dst = (uint8_t*)a.vc + row * a.Lmax + key;
+      if (full && (((uintptr_t)dst) & 7) == 0) {
+        uint32_t w[2] = {0, 0};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w[e >> 2] |= (uint32_t)f16_to_e5m2(v[e]) << (8 * (e & 3));
+        uint2v pk; pk.x = w[0]; pk.y = w[1];
+        *(uint2v*)dst = pk;
+      } else {
+        for (int e = 0; e < 8 && 8 * tc + e < ntok; ++e) dst[e] = f16_to_e5m2(v[e]);
+      }
+      if (a.vt_scratch) {
+        _Float16* sd = a.vt_scratch + row * a.vt_ld + t0 + 8 * tc;
+        if (full && (((uintptr_t)sd) & 15) == 0) *(half8*)sd = v;
+        else for (int e = 0; e < 8 && 8 * tc + e < ntok; ++e) sd[e] = v[e];
+      }
+    } else {
+      _Float16* dst = (_Float16*)a.vc + row * a.Lmax + key;
+      if (full && (((uintptr_t)dst) & 15) == 0) *(half8*)dst = v;
+      else for (int e = 0; e < 8 && 8 * tc + e < ntok; ++e) dst[e] = v[e];
+    }
+  }
+}
+
 }  // namespace bigdl
 
 using namespace bigdl;
+
+// qkv [B, S, ld] fp16 (heads: Hq q, Hkv k, Hkv v; head h at column h*D).  past + S <= Lmax (validated here).
+extern "C" int bigdl_prefill_rope_append(void* qkv, void* kc, void* vc, void* vt_scratch, const float* table,
+                                         const int64_t* position_ids, int B, int Hq, int Hkv, int S, int D, int past,
+                                         int Lmax, int rot, int interleaved, int fp8, int64_t ld, int64_t vt_ld,
+                                         int max_pos, hipStream_t st) {
+  if (B <= 0 || S <= 0 || D <= 0 || (D & 7) || D > 256 || rot < 0 || rot > D || (rot & 15) || past < 0 || past + S > Lmax) return -1;
+  if ((ld & 7) || ((uintptr_t)qkv & 15) || ((uintptr_t)kc & 15) || ((uintptr_t)vc & 15) || table == nullptr || max_pos <= 0) return -1;
+  if (B > 65535 || Hq + 2 * Hkv > 65535) return -1;
+  PrefillRopeArgs a;
+  a.qkv = (_Float16*)qkv; a.kc = kc; a.vc = vc; a.vt_scratch = (_Float16*)vt_scratch; a.table = table;
+  a.position_ids = position_ids; a.B = B; a.Hq = Hq; a.Hkv = Hkv; a.S = S; a.D = D; a.past = past; a.Lmax = Lmax;
+  a.rot = rot; a.interleaved = interleaved; a.fp8 = fp8; a.ld = ld; a.vt_ld = vt_ld; a.max_pos = max_pos;
+  hipLaunchKernelGGL(prefill_rope_append_kernel, dim3((S + PR_TOK - 1) / PR_TOK, Hq + 2 * Hkv, B), dim3(256), 0, st, a);
+  return HIP_CHECK_LAUNCH();
+}
 
 template <int D>
 static int launch_pf(const PrefillArgs& a, hipStream_t st) {

@@ -84,6 +84,19 @@ __device__ __forceinline__ float act_apply(int act, float x) {
   }
 }
 
+__device__ __forceinline__ uint8_t f16_to_e5m2(_Float16 h) {
+  // round-to-nearest-even on the dropped 8 mantissa bits, saturate to the largest finite value
+  union { _Float16 h; uint16_t u; } c;
+  c.h = h;
+  uint32_t u = c.u;
+  const uint32_t sign = u & 0x8000u;
+  uint32_t mag = u & 0x7fffu;
+  if (mag > 0x7c00u) return (uint8_t)((sign >> 8) | 0x7f);   // NaN
+  mag += 0x7fu + ((mag >> 8) & 1u);
+  if (mag >= 0x7c00u) mag = 0x7b00u;
+  return (uint8_t)((sign | mag) >> 8);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

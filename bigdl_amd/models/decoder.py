@@ -268,21 +268,15 @@ class NativeDecoder:
             qkv = self._linear_dense(x, lw.qkv).view(b, s, (hq + 2 * hkv) * d)
             q = qkv[..., : hq * d].view(b, s, hq, d).transpose(1, 2)
             k = qkv[..., hq * d: (hq + hkv) * d].view(b, s, hkv, d).transpose(1, 2)
-            v = qkv[..., (hq + hkv) * d:].view(b, s, hkv, d).transpose(1, 2)
-            rot = cfg.rot_dim or d
-            hip.rope_inplace(q, position_ids=pos, inv_freq=self.inv_freq, interleaved=cfg.rope_interleaved, rot_dim=rot,
-                             scaling=self.rope_scaling_factor)
-            hip.rope_inplace(k, position_ids=pos, inv_freq=self.inv_freq, interleaved=cfg.rope_interleaved, rot_dim=rot,
-                             scaling=self.rope_scaling_factor)
             kc, vc = cache.k[li], cache.v[li]
-            if cache.fp8:
-                hip.to_e5m2(k, kc[:, :, past:past + s])
-                vt = v.transpose(-1, -2).contiguous()
-                hip.to_e5m2(vt, vc[:, :, :, past:past + s])
-            else:
-                kc[:, :, past:past + s] = k
-                vc[:, :, :, past:past + s] = v.transpose(-1, -2)
-                vt = vc[:, :, :, :s]
+            # one launch: RoPE on q / k in place, K -> cache, V -> V^T cache (+ fp16 V^T scratch for e5m2 caches)
+            rot = cfg.rot_dim or d
+            scratch = None
+            if cache.fp8 and past == 0:
+                scratch = self._vt_scratch(b, hkv, d, s)
+            hip.prefill_rope_append(qkv, kc, vc, self.rope_table, n_heads=hq, n_kv_heads=hkv, head_dim=d, past=past,
+                                    rot_dim=rot, interleaved=cfg.rope_interleaved, vt_scratch=scratch)
+            vt = scratch[..., :s] if scratch is not None else vc[:, :, :, :s]
             if past == 0:
                 kk = k                       # attention reads the unquantized K / V^T of this call
             else:
@@ -319,6 +313,13 @@ class NativeDecoder:
         if cfg.final_softcap > 0:
             logits = torch.tanh(logits / cfg.final_softcap) * cfg.final_softcap
         return logits
+
+    def _vt_scratch(self, b, hkv, d, s):
+        need = (s + 7) // 8 * 8
+        t = getattr(self, "_vt_buf", None)
+        if t is None or t.shape[0] != b or t.shape[3] < need:
+            self._vt_buf = t = torch.empty(b, hkv, d, need, dtype=torch.float16, device=self.device)
+        return t
 
     def _read_cache(self, li, length):
         from ..ops import hip

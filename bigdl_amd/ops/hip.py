@@ -55,6 +55,7 @@ def lib():
         L.bigdl_gemv_lowbit_moe.argtypes = [vp, vp, vp, vp, vp, vp, vp, cf, cf, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp]
         L.bigdl_moe_route.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, i64, ci, ci, vp]
         L.bigdl_moe_combine.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, i64, vp]
+        L.bigdl_prefill_rope_append.argtypes = [vp, vp, vp, vp, vp, vp] + [ci] * 10 + [i64, i64, ci, vp]
         L.bigdl_attn_prefill.argtypes = [vp, vp, vp, vp, vp] + [ci] * 6 + [i64] * 13 + [cf, cf, ci, ci, ci, vp]
         _LIB = L
     return _LIB
@@ -554,3 +555,39 @@ def attn_prefill(q, k, v, *, scale, causal=True, mask=None, softcap=0.0, window=
                                   int(bool(v_transposed)), _stream())
     _check(rc, "attn_prefill")
     return out
+
+
+def prefill_rope_append(qkv, k_cache, v_cache, rope_table, *, n_heads, n_kv_heads, head_dim, past, rot_dim=None,
+                        interleaved=False, position_ids=None, vt_scratch=None):
+    """One launch per layer for a prompt: rotate q and k in place in ``qkv`` [B, S, (Hq+2Hkv)*D], copy k to the K
+    cache [B, Hkv, Lmax, D] and v transposed to the V^T cache [B, Hkv, D, Lmax] (fp16 or e5m2 by the cache dtype);
+    ``vt_scratch`` [B, Hkv, D, S_alloc] fp16 additionally receives V^T unquantized (for e5m2 caches)."""
+    _need_cuda(qkv, k_cache, v_cache, rope_table, position_ids, vt_scratch)
+    b, s, width = qkv.shape
+    d = head_dim
+    if qkv.dtype != torch.float16 or qkv.stride(2) != 1 or qkv.stride(0) != s * qkv.stride(1) or width != (n_heads + 2 * n_kv_heads) * d:
+        raise ValueError("qkv must be fp16 [B, S, (Hq+2Hkv)*D] with uniform row stride")
+    fp8 = k_cache.dtype == torch.uint8
+    lmax = k_cache.shape[2]
+    if tuple(k_cache.shape) != (b, n_kv_heads, lmax, d) or tuple(v_cache.shape) != (b, n_kv_heads, d, lmax) \
+            or not k_cache.is_contiguous() or not v_cache.is_contiguous() or v_cache.dtype != k_cache.dtype:
+        raise ValueError("cache shapes do not match")
+    if past + s > lmax:
+        raise ValueError("KV cache capacity exceeded")
+    rot = d if rot_dim is None else rot_dim
+    if rope_table.dtype != torch.float32 or not rope_table.is_contiguous() or (rot and rope_table.shape[1] != rot // 2):
+        raise ValueError("rope table must be fp32 [max_pos, rot/2, 2]")
+    if position_ids is not None:
+        position_ids = position_ids.to(torch.int64).contiguous()
+        if position_ids.numel() != b * s:
+            raise ValueError("position_ids must be [B, S]")
+    vt_ld = 0
+    if vt_scratch is not None:
+        if vt_scratch.dtype != torch.float16 or vt_scratch.shape[:3] != (b, n_kv_heads, d) or vt_scratch.shape[3] < s \
+                or not vt_scratch.is_contiguous():
+            raise ValueError("vt_scratch must be contiguous fp16 [B, Hkv, D, >= S]")
+        vt_ld = vt_scratch.shape[3]
+    rc = lib().bigdl_prefill_rope_append(_ptr(qkv), _ptr(k_cache), _ptr(v_cache), _ptr(vt_scratch), _ptr(rope_table),
+                                         _ptr(position_ids), b, n_heads, n_kv_heads, s, d, past, lmax, rot,
+                                         int(bool(interleaved)), int(fp8), qkv.stride(1), vt_ld, rope_table.shape[0], _stream())
+    _check(rc, "prefill_rope_append")

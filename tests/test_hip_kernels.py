@@ -500,3 +500,42 @@ def test_attn_prefill_mask_softcap_window(hip):
     ref = _sdpa_ref(q, k, v, scale, True, mask=mask)
     torch.testing.assert_close(out.float(), ref, rtol=2e-2, atol=2e-3)
     assert float(out[1, :20].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("cfg", [(1, 8, 2, 128, 100, 0, 128, False), (2, 4, 4, 64, 70, 0, 64, True), (1, 4, 2, 128, 37, 19, 64, False),
+                                 (1, 4, 1, 96, 64, 0, 96, False)])
+def test_prefill_rope_append(hip, fp8, cfg):
+    b, hq, hkv, d, s, past, rot, inter = cfg
+    torch.manual_seed(32)
+    lmax = 256
+    qkv = torch.randn(b, s, (hq + 2 * hkv) * d, device="cuda").half()
+    ref = qkv.clone()
+    inv = 1.0 / (10000.0 ** (torch.arange(0, rot, 2, device="cuda").float() / rot))
+    ang = torch.arange(lmax, device="cuda").float()[:, None] * inv[None]
+    table = torch.stack([ang.cos(), ang.sin()], -1).contiguous()
+    dt = torch.uint8 if fp8 else torch.float16
+    kc = torch.zeros(b, hkv, lmax, d, dtype=dt, device="cuda")
+    vc = torch.zeros(b, hkv, d, lmax, dtype=dt, device="cuda")
+    scratch = torch.zeros(b, hkv, d, (s + 7) // 8 * 8, dtype=torch.float16, device="cuda") if fp8 else None
+    hip.prefill_rope_append(qkv, kc, vc, table, n_heads=hq, n_kv_heads=hkv, head_dim=d, past=past, rot_dim=rot,
+                            interleaved=inter, vt_scratch=scratch)
+    # reference: separate RoPE kernel on q / k views, plain copies into the caches
+    pos = torch.arange(past, past + s, device="cuda")[None].expand(b, s)
+    q_ref = ref[..., : hq * d].view(b, s, hq, d).transpose(1, 2)
+    k_ref = ref[..., hq * d:(hq + hkv) * d].view(b, s, hkv, d).transpose(1, 2)
+    v_ref = ref[..., (hq + hkv) * d:].view(b, s, hkv, d).transpose(1, 2)
+    hip.rope_inplace(q_ref, position_ids=pos, inv_freq=inv, interleaved=inter, rot_dim=rot)
+    hip.rope_inplace(k_ref, position_ids=pos, inv_freq=inv, interleaved=inter, rot_dim=rot)
+    torch.testing.assert_close(qkv.float(), ref.float(), rtol=3e-3, atol=3e-3)       # q, k rotated in place; v untouched
+    if fp8:
+        k_deq = kc[:, :, past:past + s].view(torch.float8_e5m2).float()
+        v_deq = vc[:, :, :, past:past + s].view(torch.float8_e5m2).float()
+        assert ((k_deq - k_ref.float()).abs() <= 0.13 * k_ref.float().abs() + 1e-3).all()
+        assert torch.equal(v_deq, v_ref.transpose(-1, -2).to(torch.float8_e5m2).float())
+        assert torch.equal(scratch[..., :s], v_ref.transpose(-1, -2))
+    else:
+        torch.testing.assert_close(kc[:, :, past:past + s].float(), k_ref.float(), rtol=3e-3, atol=3e-3)
+        assert torch.equal(vc[:, :, :, past:past + s], v_ref.transpose(-1, -2))
+    assert int(kc[:, :, :past].float().abs().sum()) == 0 and int(kc[:, :, past + s:].float().abs().sum()) == 0
+    assert int(vc[:, :, :, past + s:].float().abs().sum()) == 0
