@@ -27,10 +27,13 @@ struct PrefillArgs {
   int v_transposed;                  // v is [B, Hkv, D, Lk] (v_ss = stride of d, keys contiguous)
 };
 
-constexpr int PF_BM = 64, PF_BN = 64;
+constexpr int PF_BN = 64;
 
-template <int D, bool HAS_MASK, bool VT>
+// QB = 16-query blocks per wavefront: every K / V^T fragment read from LDS feeds QB MFMAs, which is what keeps the
+// kernel off the LDS-bandwidth limit (QB = 2: 128 queries per workgroup).
+template <int D, bool HAS_MASK, bool VT, int QB>
 __global__ __launch_bounds__(256) void attn_prefill_kernel(PrefillArgs a) {
+  constexpr int BM = 64 * QB;
   constexpr int KS = D + 8;          // halves per K row in LDS (16 B pad)
   constexpr int VS = PF_BN + 8;      // halves per V^T row
   constexpr int DB = D / 16, STEPS = D / 32, CH = D / 8;
@@ -39,28 +42,43 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(PrefillArgs a) {
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, g = lane >> 4;
-  const int qb = (int)gridDim.x - 1 - (int)blockIdx.x;
   const int hq = blockIdx.y, b = blockIdx.z;
+  // causal work grows with the query block index.  Workgroups are dispatched x-fastest; when more than one of them
+  // shares a CU, the first half of the heads walks its query blocks heaviest-first and the second half
+  // lightest-first, so that the workgroups landing on one CU add up to the same number of key tiles.
+  const bool flip = (int)(blockIdx.y + gridDim.y * blockIdx.z) * 2 >= (int)(gridDim.y * gridDim.z);
+  const int qb = flip ? (int)blockIdx.x : (int)gridDim.x - 1 - (int)blockIdx.x;
   const int hkv = hq / (a.Hq / a.Hkv);
-  const int q0 = qb * PF_BM;
-  const int qi = q0 + wave * 16 + r;                 // this lane's query
+  const int q0 = qb * BM;
   const int offset = a.Lk - a.Sq;                    // causal alignment: query i sits at key position i + offset
-  const int pos = qi + offset;
-
-  half8 qf[STEPS];
+  int qi[QB], pos[QB];
 #pragma unroll
-  for (int s = 0; s < STEPS; ++s) {
-    half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-    qf[s] = qi < a.Sq ? *(const half8*)(a.q + b * a.q_sb + hq * a.q_sh + (int64_t)qi * a.q_ss + 32 * s + 8 * g) : z;
+  for (int u = 0; u < QB; ++u) {
+    qi[u] = q0 + (wave * QB + u) * 16 + r;           // this lane's queries
+    pos[u] = qi[u] + offset;
   }
-  float4v o[DB];
+
+  half8 qf[QB][STEPS];
 #pragma unroll
-  for (int i = 0; i < DB; ++i) o[i] = float4v{0, 0, 0, 0};
-  float m = -INFINITY, l = 0.0f;
+  for (int u = 0; u < QB; ++u)
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+      half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+      qf[u][s] = qi[u] < a.Sq ? *(const half8*)(a.q + b * a.q_sb + hq * a.q_sh + (int64_t)qi[u] * a.q_ss + 32 * s + 8 * g) : z;
+    }
+  float4v o[QB][DB];
+  float m[QB], l[QB];
+#pragma unroll
+  for (int u = 0; u < QB; ++u) {
+    m[u] = -INFINITY;
+    l[u] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < DB; ++i) o[u][i] = float4v{0, 0, 0, 0};
+  }
   const float LOG2E = 1.4426950408889634f;
 
   int kbeg = 0, kend = a.Lk;
-  if (a.causal) kend = min(a.Lk, q0 + PF_BM + offset);
+  if (a.causal) kend = min(a.Lk, q0 + BM + offset);
   if (a.window > 0) kbeg = max(0, q0 + offset - a.window + 1) / PF_BN * PF_BN;
   const _Float16* kbase = a.k + b * a.k_sb + hkv * a.k_sh;
   const _Float16* vbase = a.v + b * a.v_sb + hkv * a.v_sh;
@@ -115,89 +133,119 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(PrefillArgs a) {
     store_tile();
     __syncthreads();
     if (k0 + PF_BN < kend) load_tile(k0 + PF_BN);
+    // wavefronts whose queries all precede this tile have nothing to add (uniform per wavefront)
+    const int wq_last = q0 + (wave * QB + QB) * 16 - 1 + offset;
+    if (a.causal && k0 > wq_last) continue;
 
-    // ---- S^T = K . Q^T : lane -> query r, keys 16*kb + 4g + reg ----
-    float4v s[4];
+    // ---- S^T = K . Q^T : lane -> query r of block u, keys 16*kb + 4g + reg ----
+    float4v s[QB][4];
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb) s[kb] = float4v{0, 0, 0, 0};
+    for (int u = 0; u < QB; ++u)
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) s[u][kb] = float4v{0, 0, 0, 0};
 #pragma unroll
     for (int st = 0; st < STEPS; ++st)
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb) {
         const half8 kf = *(const half8*)(Ks + (16 * kb + r) * KS + 32 * st + 8 * g);
-        s[kb] = mfma16(kf, qf[st], s[kb]);
+#pragma unroll
+        for (int u = 0; u < QB; ++u) s[u][kb] = mfma16(kf, qf[u][st], s[u][kb]);
       }
 
-    // ---- scale, soft-cap, mask ----
-    float mloc = -INFINITY;
+    // ---- scale, soft-cap, mask, online softmax (all per-lane scalars per query block) ----
+    half8 pf[QB][2];
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb)
+    for (int u = 0; u < QB; ++u) {
+      float mloc = -INFINITY;
+      const int wq0 = q0 + (wave * QB + u) * 16 + offset;
+      // interior tile: every key of the tile is visible to every query of this block (uniform branch)
+      const bool interior = !HAS_MASK && a.softcap <= 0.0f && k0 + PF_BN <= a.Lk && (!a.causal || k0 + PF_BN - 1 <= wq0) &&
+                            (a.window <= 0 || k0 > wq0 + 15 - a.window);
+      if (interior) {
+        const float sc = a.scale * LOG2E;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int key = k0 + 16 * kb + 4 * g + e;
-        float v = s[kb][e] * a.scale;
-        if (a.softcap > 0.0f) v = a.softcap * tanhf(v / a.softcap);
-        if constexpr (HAS_MASK) {
-          if (qi < a.Sq && key < a.Lk) v += (float)a.mask[b * a.m_sb + (int64_t)qi * a.m_sq + key];
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float v = s[u][kb][e] * sc;
+            s[u][kb][e] = v;
+            mloc = fmaxf(mloc, v);
+          }
+      } else {
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int key = k0 + 16 * kb + 4 * g + e;
+            float v = s[u][kb][e] * a.scale;
+            if (a.softcap > 0.0f) v = a.softcap * tanhf(v / a.softcap);
+            if constexpr (HAS_MASK) {
+              if (qi[u] < a.Sq && key < a.Lk) v += (float)a.mask[b * a.m_sb + (int64_t)qi[u] * a.m_sq + key];
+            }
+            bool ok = key < a.Lk;
+            if (a.causal) ok = ok && key <= pos[u];
+            if (a.window > 0) ok = ok && key > pos[u] - a.window;
+            v = ok ? v * LOG2E : -INFINITY;
+            s[u][kb][e] = v;
+            mloc = fmaxf(mloc, v);
+          }
+      }
+      mloc = fmaxf(mloc, __shfl_xor(mloc, 16));
+      mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+      const float mnew = fmaxf(m[u], mloc);
+      const float msafe = mnew == -INFINITY ? 0.0f : mnew;
+      const float alpha = exp2f(m[u] - msafe);              // m = -inf -> 0
+      float lsum = 0.0f;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float p = exp2f(s[u][kb][e] - msafe);
+          s[u][kb][e] = p;
+          lsum += p;
         }
-        bool ok = key < a.Lk;
-        if (a.causal) ok = ok && key <= pos;
-        if (a.window > 0) ok = ok && key > pos - a.window;
-        v = ok ? v * LOG2E : -INFINITY;
-        s[kb][e] = v;
-        mloc = fmaxf(mloc, v);
-      }
-    mloc = fmaxf(mloc, __shfl_xor(mloc, 16));
-    mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-    const float mnew = fmaxf(m, mloc);
-    const float msafe = mnew == -INFINITY ? 0.0f : mnew;
-    const float alpha = exp2f(m - msafe);              // m = -inf -> 0
-    float lsum = 0.0f;
+      lsum += __shfl_xor(lsum, 16);
+      lsum += __shfl_xor(lsum, 32);
+      l[u] = l[u] * alpha + lsum;
+      m[u] = mnew;
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb)
+      for (int i = 0; i < DB; ++i) o[u][i] *= alpha;
+      // P^T as B operand: k slot (g, j) = key 32t + 4g + j (j < 4) / 32t + 16 + 4g + j - 4
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float p = exp2f(s[kb][e] - msafe);
-        s[kb][e] = p;
-        lsum += p;
-      }
-    lsum += __shfl_xor(lsum, 16);
-    lsum += __shfl_xor(lsum, 32);
-    l = l * alpha + lsum;
-    m = mnew;
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int i = 0; i < DB; ++i) o[i] *= alpha;
+        for (int e = 0; e < 4; ++e) {
+          pf[u][t][e] = (_Float16)s[u][2 * t][e];
+          pf[u][t][4 + e] = (_Float16)s[u][2 * t + 1][e];
+        }
+    }
 
-    // ---- O^T += V^T . P^T : k slot (g, j) = key 32t + 4g + j (j < 4) / 32t + 16 + 4g + j - 4 ----
+    // ---- O^T += V^T . P^T ----
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      half8 pf;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        pf[e] = (_Float16)s[2 * t][e];
-        pf[4 + e] = (_Float16)s[2 * t + 1][e];
-      }
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int db = 0; db < DB; ++db) {
         const _Float16* vr = Vt + (16 * db + r) * VS + 32 * t + 4 * g;
         const half4 v0 = *(const half4*)vr, v1 = *(const half4*)(vr + 16);
         const half8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        o[db] = mfma16(vf, pf, o[db]);
+#pragma unroll
+        for (int u = 0; u < QB; ++u) o[u][db] = mfma16(vf, pf[u][t], o[u][db]);
       }
-    }
   }
 
-  if (qi < a.Sq) {
-    const float inv = l > 0.0f ? 1.0f / l : 0.0f;
-    _Float16* op = a.out + b * a.o_sb + (int64_t)qi * a.o_ss + hq * D;
 #pragma unroll
-    for (int db = 0; db < DB; ++db) {
-      half4 h;
+  for (int u = 0; u < QB; ++u)
+    if (qi[u] < a.Sq) {
+      const float inv = l[u] > 0.0f ? 1.0f / l[u] : 0.0f;
+      _Float16* op = a.out + b * a.o_sb + (int64_t)qi[u] * a.o_ss + hq * D;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) h[e] = (_Float16)(o[db][e] * inv);
-      *(half4*)(op + 16 * db + 4 * g) = h;
+      for (int db = 0; db < DB; ++db) {
+        half4 h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[e] = (_Float16)(o[u][db][e] * inv);
+        *(half4*)(op + 16 * db + 4 * g) = h;
+      }
     }
-  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -347,17 +395,24 @@ extern "C" int bigdl_prefill_rope_append(void* qkv, void* kc, void* vc, void* vt
   return HIP_CHECK_LAUNCH();
 }
 
-template <int D>
-static int launch_pf(const PrefillArgs& a, hipStream_t st) {
-  const dim3 grid((a.Sq + PF_BM - 1) / PF_BM, a.Hq, a.B), block(256);
+template <int D, int QB>
+static int launch_pf_qb(const PrefillArgs& a, hipStream_t st) {
+  const dim3 grid((a.Sq + 64 * QB - 1) / (64 * QB), a.Hq, a.B), block(256);
   if (a.mask) {
-    if (a.v_transposed) hipLaunchKernelGGL((attn_prefill_kernel<D, true, true>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((attn_prefill_kernel<D, true, false>), grid, block, 0, st, a);
+    if (a.v_transposed) hipLaunchKernelGGL((attn_prefill_kernel<D, true, true, QB>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((attn_prefill_kernel<D, true, false, QB>), grid, block, 0, st, a);
   } else {
-    if (a.v_transposed) hipLaunchKernelGGL((attn_prefill_kernel<D, false, true>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((attn_prefill_kernel<D, false, false>), grid, block, 0, st, a);
+    if (a.v_transposed) hipLaunchKernelGGL((attn_prefill_kernel<D, false, true, QB>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((attn_prefill_kernel<D, false, false, QB>), grid, block, 0, st, a);
   }
   return HIP_CHECK_LAUNCH();
+}
+
+template <int D>
+static int launch_pf(const PrefillArgs& a, hipStream_t st) {
+  // QB = 2 (128 queries per workgroup) halves the LDS traffic per MFMA but needs 240 VGPRs (one wavefront per
+  // SIMD); measured slower than QB = 1 from 1K to 8K tokens on MI355X, so QB = 1 is used throughout.
+  return launch_pf_qb<D, 1>(a, st);
 }
 
 // q [B, Hq, Sq, D], k / v [B, Hkv, Lk, D] as strided fp16 views (element strides, last dim contiguous);
