@@ -425,10 +425,10 @@ class NativeDecoder:
         from ..ops import hip
         cfg, cache = self.cfg, self.cache
         h, qkv, attn, act, tmp = st["h"], st["qkv"], st["attn"], st["act"], st["tmp"]
-        emb = F.embedding(st["tokens"].view(-1), self.embed)
-        if cfg.embed_scale != 1.0:
-            emb = emb * cfg.embed_scale
-        h.copy_(emb)
+        if cfg.embed_scale != 1.0 or self.embed.dtype != h.dtype:
+            h.copy_(F.embedding(st["tokens"].view(-1), self.embed) * cfg.embed_scale)
+        else:
+            torch.index_select(self.embed, 0, st["tokens"].view(-1), out=h)      # gather straight into the residual stream
         for li, lw in enumerate(self.layers):
             self._gemv(h, lw.qkv, qkv, gamma=lw.input_norm)
             if not self.fused_rope:
@@ -465,10 +465,12 @@ class NativeDecoder:
         self._gemv(h, self.lm_head, st["logits"], gamma=self.final_norm)
         if cfg.logit_scale != 1.0 or cfg.final_softcap > 0:
             st["logits"].copy_(self._finish_logits(st["logits"]))
-        hip.argmax(st["logits"], out=st["next"])
-        cache.past_len.add_(q_len)
         if chain and q_len == 1:
-            st["tokens"].copy_(st["next"].view(batch, 1))
+            # the greedy token is written where the next replay reads its input; "next" aliases that buffer
+            hip.argmax(st["logits"], out=st["tokens"].view(-1))
+        else:
+            hip.argmax(st["logits"], out=st["next"])
+        cache.past_len.add_(q_len)
 
     def _get_graph(self, batch: int, q_len: int, chain: bool):
         key = (batch, q_len, chain)
@@ -511,7 +513,7 @@ class NativeDecoder:
         else:
             g.replay()
         self.cache.host_len += q_len
-        return st["logits"], st["next"]
+        return st["logits"], (st["tokens"].view(-1) if chain and q_len == 1 else st["next"])
 
     # ------------------------------------------------------------------ generation
     @torch.no_grad()
