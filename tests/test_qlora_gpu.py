@@ -1,0 +1,74 @@
+"""QLoRA on the GPU: frozen low-bit base (device-tiled weights, dequant + bf16 GEMM forward, grad @ dequant(W)
+backward), bf16 adapters, ReLoRA merge with re-quantization on the device."""
+import pytest
+import torch
+from transformers import LlamaConfig, LlamaForCausalLM
+
+pytestmark = pytest.mark.gpu
+
+
+def _qmodel(low_bit):
+    from bigdl_amd.optimize import optimize_model
+    torch.manual_seed(0)
+    cfg = LlamaConfig(vocab_size=320, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                      num_key_value_heads=2, max_position_embeddings=128, tie_word_embeddings=False)
+    m = optimize_model(LlamaForCausalLM(cfg), low_bit=low_bit, optimize_llm=False, modules_to_not_convert=["lm_head"])
+    return m.to("cuda")
+
+
+@pytest.mark.parametrize("mode,low_bit", [("qlora", "nf4"), ("qalora", "sym_int4")])
+def test_qlora_training_on_gpu(mode, low_bit):
+    from bigdl_amd.transformers.low_bit_linear import LowBitLinear, dequant_weight
+    from bigdl_amd.transformers.qlora import LoraConfig, get_peft_model, prepare_model_for_kbit_training
+    model = prepare_model_for_kbit_training(_qmodel(low_bit), use_gradient_checkpointing=True)
+    pm = get_peft_model(model, LoraConfig(r=8, lora_alpha=16, target_modules=["q_proj", "k_proj", "v_proj", "o_proj",
+                                                                              "up_proj", "down_proj", "gate_proj"],
+                                          lora_dropout=0.0, training_mode=mode))
+    base = pm.base_model.model.layers[0].self_attn.q_proj.base_layer
+    assert isinstance(base, LowBitLinear) and base.weight.qlayout == "t16" and base.compute_dtype == torch.bfloat16
+    before = base.weight.data.clone()
+    ids = torch.randint(0, 320, (4, 32), device="cuda")
+    opt = torch.optim.AdamW([p for p in pm.parameters() if p.requires_grad], lr=5e-3)
+    pm.train()
+    losses = []
+    for _ in range(12):
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = pm(input_ids=ids, labels=ids).loss
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        losses.append(loss.item())
+    assert losses[-1] < losses[0] - 0.2, losses
+    assert torch.equal(base.weight.data, before)                    # the quantized base never changes
+    assert all(p.grad is None for n, p in pm.named_parameters() if "lora_" not in n)
+    # activation gradient of the frozen matmul = grad_out @ dequant(W)
+    x = torch.randn(5, 256, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+    base.train()
+    y = base(x)
+    g = torch.randn_like(y)
+    y.backward(g)
+    ref = g.float() @ dequant_weight(base.weight, torch.float32)
+    torch.testing.assert_close(x.grad.float(), ref, rtol=3e-2, atol=3e-2)
+
+
+def test_relora_merge_requantizes_on_gpu():
+    from bigdl_amd.transformers.qlora import LoraConfig, get_peft_model
+    from bigdl_amd.transformers.relora import merge_and_reinit
+    pm = get_peft_model(_qmodel("sym_int8"), LoraConfig(r=4, lora_alpha=8, target_modules=["q_proj", "v_proj"],
+                                                        training_mode="relora"))
+    ids = torch.randint(0, 320, (2, 16), device="cuda")
+    opt = torch.optim.AdamW([p for p in pm.parameters() if p.requires_grad], lr=1e-2)
+    for _ in range(3):
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            pm(input_ids=ids, labels=ids).loss.backward()
+        opt.step()
+        opt.zero_grad()
+    pm.eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        before = pm(input_ids=ids).logits.float()
+    merge_and_reinit(pm)
+    base = pm.base_model.model.layers[0].self_attn.q_proj.base_layer
+    assert base.weight.data.device.type == "cuda" and base.weight.qlayout == "t16"
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        after = pm(input_ids=ids).logits.float()
+    assert ((after - before).abs().mean() / before.abs().mean()).item() < 0.03
