@@ -78,6 +78,10 @@ def optimize_pre(model, qtype=None):
     if mt in MERGE_QKV_TYPES:
         for cls in _attention_classes(model):
             model.apply(lambda m, c=cls: merge_qkv_base(m, c))
+    if mt == "rwkv" and hasattr(model, "rwkv") and hasattr(model.rwkv, "_rescale_layers") and not model.training:
+        # HF divides output / value weights of deeper blocks in place at the first inference call; that has to
+        # happen on the dense weights, before they become quantized byte buffers (reference convert.py:1035-1048)
+        model.rwkv._rescale_layers()
     # multimodal wrappers: recurse into the language model with its own config
     for attr in ("language_model", "llm"):
         sub = getattr(model, attr, None)
@@ -436,6 +440,9 @@ def optimize_post(model):
                 getattr(m, "experts", [])) and not hasattr(m, "num_experts"):
             seen.add(cls)
             convert_forward(model, cls, mlp_forward)
+    if getattr(cfg, "model_type", None) == "rwkv":
+        from .rwkv import bind_rwkv
+        bind_rwkv(model)
     base = getattr(model, "model", None)
     if isinstance(base, nn.Module) and hasattr(base, "layers") and not getattr(base, "_kv_hook_installed", False) \
             and any(hasattr(getattr(l, "self_attn", None), "_merged_sizes") for l in base.layers):

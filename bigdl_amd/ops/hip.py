@@ -55,6 +55,9 @@ def lib():
         L.bigdl_gemv_lowbit_moe.argtypes = [vp, vp, vp, vp, vp, vp, vp, cf, cf, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp]
         L.bigdl_moe_route.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, i64, ci, ci, vp]
         L.bigdl_moe_combine.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, i64, vp]
+        L.bigdl_rwkv_time_shift.argtypes = [vp, vp, vp, vp, i64, ci, ci, ci, vp]
+        L.bigdl_rwkv4_wkv.argtypes = [vp] * 8 + [ci] * 5 + [vp]
+        L.bigdl_rwkv5_wkv.argtypes = [vp] * 7 + [ci] * 4 + [vp]
         L.bigdl_prefill_rope_append.argtypes = [vp, vp, vp, vp, vp, vp] + [ci] * 10 + [i64, i64, ci, vp]
         L.bigdl_attn_prefill.argtypes = [vp, vp, vp, vp, vp] + [ci] * 6 + [i64] * 13 + [cf, cf, ci, ci, ci, vp]
         _LIB = L
@@ -591,3 +594,48 @@ def prefill_rope_append(qkv, k_cache, v_cache, rope_table, *, n_heads, n_kv_head
                                          _ptr(position_ids), b, n_heads, n_kv_heads, s, d, past, lmax, rot,
                                          int(bool(interleaved)), int(fp8), qkv.stride(1), vt_ld, rope_table.shape[0], _stream())
     _check(rc, "prefill_rope_append")
+
+
+def rwkv_time_shift(hidden, shifted, mix):
+    """hidden / shifted [B, T, C], mix [n, C] -> [n, B, T, C]: hidden * mix[i] + shifted * (1 - mix[i])."""
+    _need_cuda(hidden, shifted, mix)
+    hidden, shifted = hidden.contiguous(), shifted.contiguous().view_as(hidden)
+    mix = mix.reshape(-1, hidden.shape[-1]).to(hidden.dtype).contiguous()
+    out = torch.empty((mix.shape[0], *hidden.shape), dtype=hidden.dtype, device=hidden.device)
+    rc = lib().bigdl_rwkv_time_shift(_ptr(hidden), _ptr(shifted), _ptr(mix), _ptr(out), hidden.numel() // hidden.shape[-1],
+                                     hidden.shape[-1], mix.shape[0], _out_type(hidden.dtype), _stream())
+    _check(rc, "rwkv_time_shift")
+    return out
+
+
+def rwkv_linear_attention_v4(time_decay, time_first, key, value, num_state=None, den_state=None, max_state=None):
+    """RWKV-4 wkv.  time_decay is the raw parameter (the kernel uses -exp(time_decay)); key / value [B, T, C];
+    the three fp32 [B, C] states are read (when given) and updated in place."""
+    _need_cuda(time_decay, time_first, key, value, num_state, den_state, max_state)
+    b, t, c = key.shape
+    key, value = key.contiguous(), value.to(key.dtype).contiguous()
+    w = (-torch.exp(time_decay.float())).contiguous()
+    u = time_first.float().contiguous()
+    out = torch.empty_like(key)
+    has = num_state is not None
+    for s_ in (num_state, den_state, max_state):
+        if s_ is not None and (s_.dtype != torch.float32 or not s_.is_contiguous() or s_.shape != (b, c)):
+            raise ValueError("wkv states must be contiguous fp32 [B, C]")
+    rc = lib().bigdl_rwkv4_wkv(_ptr(w), _ptr(u), _ptr(key), _ptr(value), _ptr(out), _ptr(num_state), _ptr(den_state),
+                               _ptr(max_state), b, t, c, _out_type(key.dtype), int(has), _stream())
+    _check(rc, "rwkv4_wkv")
+    return out
+
+
+def rwkv_linear_attention_v5(time_decay, time_first, receptance, key, value, state):
+    """RWKV-5 wkv.  time_decay (already exp(-exp(w))) / time_first [H, S]; r / k / v [B, H, T, S] fp32;
+    state [B, H, S, S] fp32 updated in place.  Returns [B, T, H, S] fp32."""
+    _need_cuda(time_decay, time_first, receptance, key, value, state)
+    b, h, t, s_ = key.shape
+    args = [x.float().contiguous() for x in (time_decay.reshape(h, s_), time_first.reshape(h, s_), receptance, key, value)]
+    if state.dtype != torch.float32 or not state.is_contiguous() or state.shape != (b, h, s_, s_):
+        raise ValueError("state must be contiguous fp32 [B, H, S, S]")
+    out = torch.empty((b, t, h, s_), dtype=torch.float32, device=key.device)
+    rc = lib().bigdl_rwkv5_wkv(*map(_ptr, args), _ptr(state), _ptr(out), b, h, t, s_, _stream())
+    _check(rc, "rwkv5_wkv")
+    return out

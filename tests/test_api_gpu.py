@@ -181,3 +181,27 @@ def test_moe_models_module_path_and_native_engine(family, tmp_path):
     lg = eng.prefill(long_ids.cuda(), last_only=False)
     # the module path's lm_head keeps only the last position for long inputs
     assert a.shape[1] == 1 and _rel(lg[:, -1:].float().cpu(), a) < 0.03
+
+
+def test_rwkv_model_uses_recurrence_kernels():
+    """HF RWKV-4: low-bit linears + the wkv / time-shift kernels reproduce the fp32 CPU model, with and without state."""
+    import copy
+    from transformers import RwkvConfig, RwkvForCausalLM
+    from bigdl_amd.optimize import optimize_model
+    torch.manual_seed(0)
+    cfg = RwkvConfig(vocab_size=320, hidden_size=256, num_hidden_layers=2, attention_hidden_size=256, intermediate_size=512,
+                     context_length=128)
+    m = RwkvForCausalLM(cfg).eval()
+    ids = torch.randint(0, 320, (1, 12))
+    q = optimize_model(copy.deepcopy(m), low_bit="sym_int8")
+    assert hasattr(q.rwkv.blocks[0].attention, "_hf_forward")
+    with torch.no_grad():
+        ref = q(ids).logits.float()                      # CPU path of the same quantized model
+    q = q.to("cuda")
+    with torch.no_grad():
+        out = q(ids.cuda(), use_cache=True)
+        assert _rel(out.logits.float().cpu(), ref) < 0.02
+        nxt = out.logits[:, -1:].argmax(-1)
+        step = q(nxt, state=out.state, use_cache=True).logits.float().cpu()
+        full = q(torch.cat([ids.cuda(), nxt], 1)).logits[:, -1:].float().cpu()
+    assert _rel(step, full) < 0.02

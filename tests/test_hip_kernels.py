@@ -539,3 +539,50 @@ def test_prefill_rope_append(hip, fp8, cfg):
         assert torch.equal(vc[:, :, :, past:past + s], v_ref.transpose(-1, -2))
     assert int(kc[:, :, :past].float().abs().sum()) == 0 and int(kc[:, :, past + s:].float().abs().sum()) == 0
     assert int(vc[:, :, :, past + s:].float().abs().sum()) == 0
+
+
+# ---------------------------------------------------------------------------------------------
+# RWKV recurrences
+# ---------------------------------------------------------------------------------------------
+def test_rwkv4_wkv_and_time_shift(hip):
+    from transformers.models.rwkv.modeling_rwkv import rwkv_linear_attention_cpu
+    torch.manual_seed(40)
+    b, t, c = 2, 37, 192
+    td, tf = torch.randn(c) * 0.5, torch.randn(c) * 0.5
+    k, v = torch.randn(b, t, c), torch.randn(b, t, c)
+    ref, ref_state = rwkv_linear_attention_cpu(td, tf, k, v, state=None, return_state=True)
+    num = torch.zeros(b, c, device="cuda")
+    den = torch.zeros(b, c, device="cuda")
+    mx = torch.full((b, c), -1e38, device="cuda")
+    out = hip.rwkv_linear_attention_v4(td.cuda(), tf.cuda(), k.cuda(), v.cuda(), num, den, mx)
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=1e-4)
+    # the (num, den, max) triple is only defined up to the shared exponent: compare the ratio and continue a step
+    k2, v2 = torch.randn(b, 1, c), torch.randn(b, 1, c)
+    ref2, _ = rwkv_linear_attention_cpu(td, tf, k2, v2, state=ref_state, return_state=True)
+    out2 = hip.rwkv_linear_attention_v4(td.cuda(), tf.cuda(), k2.cuda(), v2.cuda(), num, den, mx)
+    torch.testing.assert_close(out2.cpu(), ref2, rtol=1e-4, atol=1e-4)
+    h16 = hip.rwkv_linear_attention_v4(td.cuda(), tf.cuda(), k.cuda().half(), v.cuda().half())
+    torch.testing.assert_close(h16.float().cpu(), ref, rtol=2e-2, atol=2e-2)
+    hidden, shifted, mix = torch.randn(b, t, c).cuda(), torch.randn(b, t, c).cuda(), torch.rand(3, c).cuda()
+    ts = hip.rwkv_time_shift(hidden, shifted, mix)
+    for i in range(3):
+        torch.testing.assert_close(ts[i], hidden * mix[i] + shifted * (1 - mix[i]), rtol=1e-5, atol=1e-5)
+
+
+def test_rwkv5_wkv(hip):
+    torch.manual_seed(41)
+    b, h, t, s = 2, 3, 19, 64
+    r, k, v = (torch.randn(b, h, t, s) * 0.5 for _ in range(3))
+    w = torch.rand(h, s) * 0.5 + 0.4
+    u = torch.randn(h, s) * 0.3
+    state0 = torch.randn(b, h, s, s) * 0.1
+    st = state0.clone()
+    ref = torch.zeros(b, t, h, s)
+    for ti in range(t):
+        kv = k[:, :, ti, :, None] * v[:, :, ti, None, :]                       # [b, h, i, j]
+        ref[:, ti] = torch.einsum("bhi,bhij->bhj", r[:, :, ti], u[None, :, :, None] * kv + st)
+        st = st * w[None, :, :, None] + kv
+    dev_state = state0.clone().cuda()
+    out = hip.rwkv_linear_attention_v5(w.cuda(), u.cuda(), r.cuda(), k.cuda(), v.cuda(), dev_state)
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(dev_state.cpu(), st, rtol=1e-4, atol=1e-4)
