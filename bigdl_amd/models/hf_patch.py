@@ -191,6 +191,9 @@ def attention_forward(self, hidden_states, position_embeddings=None, attention_m
             k, v = past_key_values.update(k, v, self.layer_idx, query_states=q, num_key_value_groups=nq // nk)
         else:
             k, v = past_key_values.update(k, v, self.layer_idx)
+    native = _native_attention(self, q, k, v, attention_mask, kwargs)
+    if native is not None:
+        return self.o_proj(native), None
     mod = sys.modules[self.__class__.__module__]
     eager = getattr(mod, "eager_attention_forward")
     interface = ALL_ATTENTION_FUNCTIONS.get_interface(self.config._attn_implementation, eager)
@@ -204,6 +207,30 @@ def attention_forward(self, hidden_states, position_embeddings=None, attention_m
                                           scaling=self.scaling, **extra, **kwargs)
     attn_output = attn_output.reshape(*input_shape, -1).contiguous()
     return self.o_proj(attn_output), attn_weights
+
+
+def _native_attention(module, q, k, v, attention_mask, kwargs):
+    """The MFMA flash-attention kernel for the module path: fp16 tensors on the GPU, head_dim 64 / 128, inference.
+    HF hands over either no mask (pure causal) or an additive / boolean [B, 1, Sq, Lk] mask that already contains the
+    causal and sliding-window structure.  Returns [B, Sq, Hq*D] or None when the case is not covered."""
+    if not _is_cuda(q) or q.dtype != torch.float16 or torch.is_grad_enabled() or q.shape[-1] not in (64, 128) \
+            or kwargs.get("output_attentions") or module.training:
+        return None
+    if q.stride(-1) != 1 or k.stride(-1) != 1 or v.stride(-1) != 1 or any(t.stride(i) % 8 for t in (q, k, v) for i in (0, 1, 2)):
+        return None
+    mask = attention_mask
+    if mask is not None:
+        if mask.dim() != 4 or mask.shape[1] != 1 or mask.shape[-2] != q.shape[2] or mask.shape[-1] != k.shape[2]:
+            return None
+        if mask.dtype == torch.bool:
+            mask = torch.zeros(mask.shape, dtype=torch.float16, device=mask.device).masked_fill_(~mask, float("-inf"))
+        elif mask.dtype != torch.float16:
+            mask = mask.to(torch.float16)
+        if mask.stride(-1) != 1:
+            mask = mask.contiguous()
+    from ..ops import hip
+    softcap = getattr(module, "attn_logit_softcapping", None) or 0.0
+    return hip.attn_prefill(q, k, v, scale=module.scaling, causal=mask is None, mask=mask, softcap=softcap)
 
 
 # ------------------------------------------------------------------------------------------------

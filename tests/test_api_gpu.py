@@ -205,3 +205,26 @@ def test_rwkv_model_uses_recurrence_kernels():
         step = q(nxt, state=out.state, use_cache=True).logits.float().cpu()
         full = q(torch.cat([ids.cuda(), nxt], 1)).logits[:, -1:].float().cpu()
     assert _rel(step, full) < 0.02
+
+
+def test_left_padded_batch_on_module_path(tiny):
+    """Padded batches go through the HF forward with an additive mask -> masked flash-attention kernel."""
+    from ipex_llm.transformers import AutoModelForCausalLM
+    d, _ = tiny
+    q = AutoModelForCausalLM.from_pretrained(d, load_in_low_bit="sym_int8").half().to("cuda")
+    q.generation_config.pad_token_id = 0
+    torch.manual_seed(3)
+    a, b = torch.randint(1, 320, (1, 12)).cuda(), torch.randint(1, 320, (1, 7)).cuda()
+    ids = torch.zeros(2, 12, dtype=torch.long, device="cuda")
+    ids[0] = a[0]
+    ids[1, 5:] = b[0]
+    mask = torch.ones(2, 12, dtype=torch.long, device="cuda")
+    mask[1, :5] = 0
+    with torch.no_grad():
+        batch = q(input_ids=ids, attention_mask=mask).logits.float()
+        one_a = q(input_ids=a).logits.float()
+        one_b = q(input_ids=b).logits.float()
+    assert _rel(batch[0, -1], one_a[0, -1]) < 0.02 and _rel(batch[1, -1], one_b[0, -1]) < 0.02
+    out = q.generate(ids, attention_mask=mask, max_new_tokens=6, do_sample=False)
+    solo = q.generate(b, max_new_tokens=6, do_sample=False)
+    assert (out[1, 12:] == solo[0, 7:]).float().mean() > 0.8
