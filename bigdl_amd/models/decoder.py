@@ -169,10 +169,33 @@ class KVCache:
                   for _ in range(cfg.num_layers)]
         self.past_len = torch.zeros(batch, dtype=torch.int32, device=device)
         self.host_len = 0  # host mirror of past_len (uniform across the batch)
+        # continuous batching: every batch row is a slot with its own length; rows whose `active` entry is 0 do not
+        # advance when a decode step runs (their output is ignored)
+        self.active = torch.ones(batch, dtype=torch.int32, device=device)
+        self.active_host = [1] * batch
+        self.slot_len = None  # list of per-slot lengths on the host once slot mode is on
 
     def reset(self):
         self.past_len.zero_()
         self.host_len = 0
+        self.active.fill_(1)
+        self.active_host = [1] * self.batch
+        self.slot_len = None
+
+    def enable_slots(self):
+        """Switch to per-slot bookkeeping: all slots empty and inactive."""
+        self.past_len.zero_()
+        self.active.zero_()
+        self.active_host = [0] * self.batch
+        self.host_len = 0
+        self.slot_len = [0] * self.batch
+
+    def set_active(self, slot: int, on: bool):
+        self.active[slot] = 1 if on else 0
+        self.active_host[slot] = 1 if on else 0
+        if not on:
+            self.past_len[slot] = 0
+            self.slot_len[slot] = 0
 
     def crop(self, length: int):
         """Drop everything after `length` tokens (speculative rejection): just a counter update."""
@@ -249,13 +272,18 @@ class NativeDecoder:
         return hip.rms_norm(x, w, self.cfg.rms_eps, offset=self.cfg.norm_offset, residual=residual, res_out=res_out)
 
     @torch.no_grad()
-    def prefill(self, input_ids: torch.Tensor, last_only: bool = True):
+    def prefill(self, input_ids: torch.Tensor, last_only: bool = True, slot: Optional[int] = None):
         """input_ids [B, S] (device).  Fills the cache from position past_len and returns logits
-        ([B, 1, V] if last_only else [B, S, V])."""
+        ([B, 1, V] if last_only else [B, S, V]).  With ``slot`` (continuous batching) input_ids is one sequence
+        [1, S] that is appended to cache row ``slot`` only."""
         from ..ops import hip
         cfg, cache = self.cfg, self.cache
         b, s = input_ids.shape
-        past = cache.host_len
+        if slot is not None:
+            assert b == 1 and cache.slot_len is not None, "slot prefill takes one sequence on a cache in slot mode"
+            past = cache.slot_len[slot]
+        else:
+            past = cache.host_len
         assert past + s <= cache.capacity, "KV cache capacity exceeded"
         h = F.embedding(input_ids, self.embed).to(torch.float16)
         if cfg.embed_scale != 1.0:
@@ -269,6 +297,8 @@ class NativeDecoder:
             q = qkv[..., : hq * d].view(b, s, hq, d).transpose(1, 2)
             k = qkv[..., hq * d: (hq + hkv) * d].view(b, s, hkv, d).transpose(1, 2)
             kc, vc = cache.k[li], cache.v[li]
+            if slot is not None:
+                kc, vc = kc[slot:slot + 1], vc[slot:slot + 1]
             # one launch: RoPE on q / k in place, K -> cache, V -> V^T cache (+ fp16 V^T scratch for e5m2 caches)
             rot = cfg.rot_dim or d
             scratch = None
@@ -280,7 +310,7 @@ class NativeDecoder:
             if past == 0:
                 kk = k                       # attention reads the unquantized K / V^T of this call
             else:
-                kk, vt = self._read_cache(li, past + s)
+                kk, vt = self._read_cache(li, past + s, slot)
             attn = self._sdpa(q, kk, vt, past, lw.window).reshape(b * s, hq * d)
             o = self._tp_reduce(self._linear_dense(attn, lw.o))
             if lw.post_attn_out_norm is not None:
@@ -297,8 +327,12 @@ class NativeDecoder:
             if lw.post_ffn_out_norm is not None:
                 m = self._norm(m, lw.post_ffn_out_norm)
             h = h + m
-        cache.past_len.add_(s)
-        cache.host_len += s
+        if slot is not None:
+            cache.past_len[slot] += s
+            cache.slot_len[slot] += s
+        else:
+            cache.past_len.add_(s)
+            cache.host_len += s
         h = h.view(b, s, -1)
         if last_only:
             h = h[:, -1:, :]
@@ -321,12 +355,13 @@ class NativeDecoder:
             self._vt_buf = t = torch.empty(b, hkv, d, need, dtype=torch.float16, device=self.device)
         return t
 
-    def _read_cache(self, li, length):
-        from ..ops import hip
+    def _read_cache(self, li, length, slot=None):
         """-> (K [B,Hkv,L,D], V^T [B,Hkv,D,L]) in fp16"""
+        from ..ops import hip
         c = self.cache
-        k = c.k[li][:, :, :length]
-        vt = c.v[li][:, :, :, :length]
+        rows = slice(None) if slot is None else slice(slot, slot + 1)
+        k = c.k[li][rows, :, :length]
+        vt = c.v[li][rows, :, :, :length]
         if c.fp8:
             kf = torch.empty(k.shape, dtype=torch.float16, device=self.device)
             hip.from_e5m2(k, kf)
@@ -470,7 +505,7 @@ class NativeDecoder:
             hip.argmax(st["logits"], out=st["tokens"].view(-1))
         else:
             hip.argmax(st["logits"], out=st["next"])
-        cache.past_len.add_(q_len)
+        cache.past_len.add_(cache.active, alpha=q_len)
 
     def _get_graph(self, batch: int, q_len: int, chain: bool):
         key = (batch, q_len, chain)
@@ -504,7 +539,11 @@ class NativeDecoder:
         """One decode step for `tokens` [B, q_len] (None: reuse the chained token already on the device).
         Returns (logits [B*q_len, V] fp32 view of a static buffer, next_tokens [B*q_len])."""
         batch = self.cache.batch
-        assert self.cache.host_len + q_len <= self.cache.capacity, "KV cache capacity exceeded"
+        c = self.cache
+        if c.slot_len is not None:
+            assert max(c.slot_len) + q_len <= c.capacity, "KV cache capacity exceeded"
+        else:
+            assert c.host_len + q_len <= c.capacity, "KV cache capacity exceeded"
         g, st = self._get_graph(batch, q_len, chain)
         if tokens is not None:
             st["tokens"].copy_(tokens.view(batch, q_len))
@@ -512,7 +551,10 @@ class NativeDecoder:
             self._decode_body(st, batch, q_len, chain)
         else:
             g.replay()
-        self.cache.host_len += q_len
+        if c.slot_len is not None:
+            c.slot_len = [n + q_len * a for n, a in zip(c.slot_len, c.active_host)]
+        else:
+            c.host_len += q_len
         return st["logits"], (st["tokens"].view(-1) if chain and q_len == 1 else st["next"])
 
     # ------------------------------------------------------------------ generation

@@ -1,0 +1,162 @@
+"""Continuous batching on the native decoder engine.
+
+The reference gets iteration-level batching from two places: its vLLM integration
+(python/llm/src/ipex_llm/vllm/xpu/engine/engine.py:40-246) and the pipeline-parallel serving worker that keeps
+``max_num_seqs`` sequences per batch in flight with partial prefill
+(python/llm/src/ipex_llm/transformers/pipeline_parallel.py:482-521, 621-700, 807-927).  On one MI355X the same
+effect falls out of the engine's fixed-capacity KV cache: every batch row is a *slot* with its own length counter
+on the device, a new request is prefilled straight into a free slot, and all occupied slots advance together with
+one hipGraph replay per token.  Batch-1 decode leaves the GPU latency bound (about 1.7 ms / token for a 7B int4
+model), the same graph at 32 slots costs little more, so throughput scales with occupancy.
+
+``ContinuousBatcher`` is the scheduler: ``submit`` queues a request, ``step`` admits waiting requests into free
+slots (at most ``max_prefill_per_step`` per step, the reference's ``max_prefilled_seqs``), runs one decode step over
+all slots and returns the new token of every running request.
+"""
+from __future__ import annotations
+
+import collections
+import time
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional
+
+import torch
+
+
+@dataclass
+class SeqRequest:
+    request_id: str
+    input_ids: List[int]
+    max_new_tokens: int = 32
+    min_new_tokens: int = 0
+    eos_token_id: Optional[List[int]] = None
+    do_sample: bool = False
+    temperature: float = 1.0
+    top_k: int = 0
+    top_p: float = 1.0
+    # filled in by the scheduler
+    output_ids: List[int] = field(default_factory=list)
+    slot: int = -1
+    finished: bool = False
+    finish_reason: Optional[str] = None
+    arrival: float = field(default_factory=time.perf_counter)
+    first_token_time: Optional[float] = None
+    finish_time: Optional[float] = None
+
+
+class ContinuousBatcher:
+    """Iteration-level scheduler over ``max_num_seqs`` cache slots of one ``NativeDecoder``."""
+
+    def __init__(self, engine, max_num_seqs: int = 8, max_seq_len: int = 4096, kv_fp8: bool = False,
+                 max_prefill_per_step: int = 1, on_token: Optional[Callable[[SeqRequest, int], None]] = None):
+        self.engine = engine
+        self.max_num_seqs = max_num_seqs
+        self.max_seq_len = max_seq_len
+        self.max_prefill_per_step = max(1, max_prefill_per_step)
+        self.on_token = on_token
+        self.waiting: collections.deque = collections.deque()
+        self.running: Dict[int, SeqRequest] = {}
+        self.free_slots = list(range(max_num_seqs))[::-1]
+        cache = engine.ensure_cache(max_num_seqs, max_seq_len, fp8=kv_fp8)
+        cache.enable_slots()
+        self.cache = cache
+        self._tokens = None      # the engine's static [B, 1] token buffer (input of the next decode step)
+        self.steps = 0
+        self.generated = 0
+
+    # ------------------------------------------------------------------ queue
+    def submit(self, req: SeqRequest) -> SeqRequest:
+        if len(req.input_ids) + req.max_new_tokens > self.cache.capacity:
+            raise ValueError(f"request {req.request_id}: prompt + max_new_tokens exceeds the slot capacity "
+                             f"({self.cache.capacity})")
+        if isinstance(req.eos_token_id, int):
+            req.eos_token_id = [req.eos_token_id]
+        self.waiting.append(req)
+        return req
+
+    def has_work(self) -> bool:
+        return bool(self.waiting or self.running)
+
+    # ------------------------------------------------------------------ one iteration
+    def _token_buffer(self):
+        if self._tokens is None:
+            _, st = self.engine._get_graph(self.max_num_seqs, 1, True)
+            self._tokens = st["tokens"]
+        return self._tokens
+
+    def _pick(self, req: SeqRequest, logits_row: torch.Tensor) -> int:
+        if req.do_sample:
+            from ..models.decoder import sample_logits
+            return int(sample_logits(logits_row[None].float(), req.temperature, req.top_k, req.top_p)[0])
+        return int(logits_row.argmax(-1))
+
+    def _emit(self, req: SeqRequest, token: int, now: float, out: Dict[str, int]):
+        req.output_ids.append(token)
+        out[req.request_id] = token
+        self.generated += 1
+        if req.first_token_time is None:
+            req.first_token_time = now
+        n = len(req.output_ids)
+        if req.eos_token_id and token in req.eos_token_id and n >= req.min_new_tokens:
+            req.finished, req.finish_reason = True, "stop"
+        elif n >= req.max_new_tokens:
+            req.finished, req.finish_reason = True, "length"
+        if self.on_token is not None:
+            self.on_token(req, token)
+        if req.finished:
+            req.finish_time = now
+            self.cache.set_active(req.slot, False)
+            self.running.pop(req.slot, None)
+            self.free_slots.append(req.slot)
+
+    def step(self) -> Dict[str, int]:
+        """Admit, decode once, return {request_id: new token}."""
+        eng, out = self.engine, {}
+        tokens = self._token_buffer()
+        # decode first: the sequences that are already running advance by one token
+        if self.running:
+            logits, nxt = eng.decode(None, 1, chain=True)
+            host = nxt.tolist()                       # one device sync per iteration
+            now = time.perf_counter()
+            for slot, req in list(self.running.items()):
+                tok = host[slot]
+                if req.do_sample:
+                    tok = self._pick(req, logits[slot])
+                    tokens[slot, 0] = tok
+                self._emit(req, tok, now, out)
+        # then admit: prefill writes the prompt into the slot's cache rows and yields the slot's first token
+        admitted = 0
+        while self.waiting and self.free_slots and admitted < self.max_prefill_per_step:
+            req = self.waiting.popleft()
+            slot = self.free_slots.pop()
+            req.slot = slot
+            self.cache.set_active(slot, False)        # clears the slot's length counters
+            ids = torch.tensor([req.input_ids], dtype=torch.int64, device=eng.device)
+            logits = eng.prefill(ids, last_only=True, slot=slot)[0, -1]
+            tok = self._pick(req, logits)
+            tokens[slot, 0] = tok
+            self.cache.set_active(slot, True)
+            self.running[slot] = req
+            admitted += 1
+            self._emit(req, tok, time.perf_counter(), out)
+        self.steps += 1
+        return out
+
+    def run_until_done(self, max_steps: int = 1 << 30) -> None:
+        n = 0
+        while self.has_work() and n < max_steps:
+            self.step()
+            n += 1
+
+
+def generate_batch(engine, prompts: List[List[int]], max_new_tokens: int = 32, max_num_seqs: int = 8,
+                   eos_token_id=None, kv_fp8: bool = False, **sampling) -> List[List[int]]:
+    """Run ``prompts`` (token id lists of any lengths) through a ``ContinuousBatcher``; returns the new tokens of
+    each prompt in order."""
+    cap = max(len(p) for p in prompts) + max_new_tokens + 1
+    cb = ContinuousBatcher(engine, max_num_seqs=min(max_num_seqs, len(prompts)), max_seq_len=cap, kv_fp8=kv_fp8,
+                           max_prefill_per_step=max_num_seqs)
+    reqs = [cb.submit(SeqRequest(str(i), list(p), max_new_tokens=max_new_tokens, eos_token_id=eos_token_id, **sampling))
+            for i, p in enumerate(prompts)]
+    cb.run_until_done()
+    return [r.output_ids for r in reqs]

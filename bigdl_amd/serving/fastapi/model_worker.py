@@ -153,3 +153,76 @@ class ModelWorker:
 
     def finish(self, request_id: str):
         self.streamer.pop(request_id, None)
+
+
+class BatchedModelWorker(ModelWorker):
+    """Serving worker with iteration-level batching: up to ``max_num_seqs`` requests decode together in the slots of
+    one native-engine KV cache (``bigdl_amd/serving/continuous.py``); requests are admitted between decode steps.
+    Takes the place of the reference's vLLM-backed serving for families the native engine covers; other models fall
+    back to the one-request-at-a-time loop of ``ModelWorker``."""
+
+    def __init__(self, *args, max_num_seqs: int = 16, max_seq_len: int = 4096, max_prefilled_seqs: int = 1, **kw):
+        super().__init__(*args, **kw)
+        from ...models.hf_patch import get_native_engine, native_engine_supported
+        from ...transformers.utils import use_quantize_kv_cache
+        self.batcher = None
+        if self.device != "cpu" and native_engine_supported(self.model):
+            from ..continuous import ContinuousBatcher
+            self.batcher = ContinuousBatcher(get_native_engine(self.model), max_num_seqs=max_num_seqs,
+                                             max_seq_len=max_seq_len, kv_fp8=use_quantize_kv_cache(),
+                                             max_prefill_per_step=max_prefilled_seqs, on_token=self._on_token)
+        self._loop = None
+        self._text: Dict[str, _QueueStreamer] = {}
+
+    def _on_token(self, seq, token):
+        st = self._text.get(seq.request_id)
+        if st is None:
+            return
+        st.put([token])
+        if seq.finished:
+            st.end()
+            self._text.pop(seq.request_id, None)
+            with self._lock:
+                s = self.stats
+                s["requests"] += 1
+                s["prompt_tokens"] += len(seq.input_ids)
+                s["generated_tokens"] += len(seq.output_ids)
+                if seq.first_token_time is not None:
+                    s["first_token_s"] = (s["first_token_s"] + [seq.first_token_time - seq.arrival])[-1000:]
+                    if len(seq.output_ids) > 1:
+                        s["per_token_s"] = (s["per_token_s"] + [(seq.finish_time - seq.first_token_time)
+                                                                / (len(seq.output_ids) - 1)])[-1000:]
+
+    def _admit(self, req: Request, loop):
+        from ..continuous import SeqRequest
+        ids = req.input_ids if req.input_ids is not None else self.tokenizer(req.prompt).input_ids
+        st = _QueueStreamer(self.tokenizer, loop, self.streamer[req.request_id], skip_prompt=False)
+        self._text[req.request_id] = st
+        sample = req.do_sample or (req.temperature is not None and req.temperature > 0 and req.temperature != 1.0) \
+            or req.top_p is not None or req.top_k is not None
+        eos = getattr(self.model.generation_config, "eos_token_id", None) or self.tokenizer.eos_token_id
+        try:
+            self.batcher.submit(SeqRequest(req.request_id, list(ids), max_new_tokens=req.max_new_tokens,
+                                           min_new_tokens=req.min_new_tokens, eos_token_id=eos, do_sample=bool(sample),
+                                           temperature=req.temperature or 1.0, top_k=req.top_k or 0, top_p=req.top_p or 1.0))
+        except ValueError as e:
+            self._text.pop(req.request_id, None)
+            loop.call_soon_threadsafe(self.streamer[req.request_id].put_nowait, (f"[generation failed: {e}]", True))
+
+    def _iterate(self):
+        t0 = time.time()
+        with torch.inference_mode():
+            self.batcher.step()
+        with self._lock:
+            self.stats["busy_s"] += time.time() - t0
+
+    async def process_step(self):
+        if self.batcher is None:
+            return await super().process_step()
+        loop = asyncio.get_running_loop()
+        if not self.batcher.has_work():
+            self._admit(await self.waiting_requests.get(), loop)        # idle: block until a request arrives
+        while not self.waiting_requests.empty():
+            self._admit(self.waiting_requests.get_nowait(), loop)
+        await loop.run_in_executor(None, self._iterate)
+        return None

@@ -1,0 +1,100 @@
+"""Continuous-batching scheduler logic on a fake engine (slot admission, eviction, per-slot lengths)."""
+import torch
+
+from bigdl_amd.serving.continuous import ContinuousBatcher, SeqRequest, generate_batch
+
+
+class _FakeCache:
+    def __init__(self, batch, capacity):
+        self.batch, self.capacity = batch, capacity
+        self.slot_len = None
+        self.active_host = [1] * batch
+
+    def enable_slots(self):
+        self.slot_len = [0] * self.batch
+        self.active_host = [0] * self.batch
+
+    def set_active(self, slot, on):
+        self.active_host[slot] = 1 if on else 0
+        if not on:
+            self.slot_len[slot] = 0
+
+
+class _FakeEngine:
+    """Next token = (sum of the slot's tokens so far) % vocab: depends on the whole per-slot history, so any mix-up
+    between slots or a stale cache row changes the output."""
+    vocab = 97
+    device = torch.device("cpu")
+
+    def ensure_cache(self, batch, needed, fp8=False):
+        self.cache = _FakeCache(batch, needed)
+        self.hist = [[] for _ in range(batch)]
+        self.tokens = torch.zeros(batch, 1, dtype=torch.int64)
+        return self.cache
+
+    def _get_graph(self, batch, q_len, chain):
+        return None, {"tokens": self.tokens}
+
+    def _logits(self, hist):
+        lg = torch.zeros(self.vocab)
+        lg[sum(hist) % self.vocab] = 1.0
+        return lg
+
+    def prefill(self, ids, last_only=True, slot=None):
+        assert self.cache.slot_len[slot] == 0
+        self.hist[slot] = ids[0].tolist()
+        self.cache.slot_len[slot] += ids.shape[1]
+        return self._logits(self.hist[slot])[None, None]
+
+    def decode(self, tokens, q_len=1, chain=False):
+        lg = torch.zeros(self.cache.batch, self.vocab)
+        for s in range(self.cache.batch):
+            if self.cache.active_host[s]:
+                self.hist[s].append(int(self.tokens[s, 0]))
+                self.cache.slot_len[s] += 1
+                lg[s] = self._logits(self.hist[s])
+        nxt = lg.argmax(-1)
+        self.tokens[:, 0] = nxt
+        return lg, nxt
+
+
+def _expected(prompt, n, vocab=97):
+    h, out = list(prompt), []
+    for _ in range(n):
+        t = sum(h) % vocab
+        out.append(t)
+        h.append(t)
+    return out
+
+
+def test_more_requests_than_slots_all_finish_with_their_own_history():
+    prompts = [[i + 1, 2 * i + 3, 5] + [7] * i for i in range(7)]
+    outs = generate_batch(_FakeEngine(), prompts, max_new_tokens=6, max_num_seqs=3)
+    for p, o in zip(prompts, outs):
+        assert o == _expected(p, 6)
+
+
+def test_eos_frees_the_slot_and_callbacks_fire():
+    eng = _FakeEngine()
+    seen = []
+    cb = ContinuousBatcher(eng, max_num_seqs=2, max_seq_len=64, on_token=lambda r, t: seen.append((r.request_id, t)))
+    exp = _expected([1, 2, 3], 8)
+    a = cb.submit(SeqRequest("a", [1, 2, 3], max_new_tokens=8, eos_token_id=exp[2]))
+    b = cb.submit(SeqRequest("b", [4, 4], max_new_tokens=5))
+    c = cb.submit(SeqRequest("c", [9], max_new_tokens=4))
+    cb.run_until_done()
+    assert a.output_ids == exp[:3] and a.finish_reason == "stop"
+    assert b.output_ids == _expected([4, 4], 5) and b.finish_reason == "length"
+    assert c.output_ids == _expected([9], 4)
+    assert sorted(t for r, t in seen if r == "c") == sorted(c.output_ids)
+    assert not cb.has_work() and sorted(cb.free_slots) == [0, 1]
+    assert cb.generated == 3 + 5 + 4
+
+
+def test_capacity_is_checked_at_submit():
+    cb = ContinuousBatcher(_FakeEngine(), max_num_seqs=1, max_seq_len=8)
+    try:
+        cb.submit(SeqRequest("x", [1] * 6, max_new_tokens=6))
+    except ValueError:
+        return
+    raise AssertionError("over-capacity request was accepted")
