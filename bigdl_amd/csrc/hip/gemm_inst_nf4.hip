@@ -1,0 +1,6 @@
+// Instantiation unit of the fused low-bit MFMA GEMM for one weight format (one file per format so that the
+// formats compile in parallel).
+#include "gemm_kernel.h"
+namespace bigdl {
+int gemm_launch_nf4(const GemmArgs& a, int bm, int mblocks, hipStream_t st) { return gemm_launch_qt<Q_NF4>(a, bm, mblocks, st); }
+}  // namespace bigdl

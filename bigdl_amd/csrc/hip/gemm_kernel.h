@@ -1,0 +1,235 @@
+// Dequant-fused MFMA GEMM for mid-size row counts on gfx950:  y[M,N] = f(x[M,K] . dequant(W)[N,K]^T), 16 < M <= ~512,
+// and its grouped (mixture-of-experts) form where every 64/128-row block of x belongs to one expert.
+//
+// Takes the place of the reference's closed xe_linear.forward_new for prefill-sized inputs / xe_batch.batch_forward
+// (call sites python/llm/src/ipex_llm/transformers/low_bit_linear.py:657-668) and of the per-expert Python loop of
+// python/llm/src/ipex_llm/transformers/models/qwen2_moe.py:400-445.
+//
+// Why a second kernel next to the skinny one (gemv_kernel.h): above 64 rows x no longer fits next to the K-split
+// partials in LDS and re-reading it per 16-row weight tile would make the kernel L2 bound.  Here a workgroup owns
+// a BM x 128 output tile:
+//  * x tile [BM][128 k] goes global -> VGPR -> LDS in full 256-byte rows, double buffered, XOR-swizzled per 16-byte
+//    slot (slot ^= row & 15) so that the ds_read_b128 of an A fragment is bank-conflict free;
+//  * the T16 weight layout already is the MFMA B-operand order, so each of the 4 wavefronts streams its own two
+//    16-row weight tiles HBM -> VGPR (no LDS, no redundancy inside the workgroup), dequantises them with the same
+//    register bit tricks as the skinny kernel, folds the block scale in as a packed fp16 multiply, and reuses
+//    every B fragment for all BM/16 row tiles (8 MFMAs per dequantised fragment at BM = 128);
+//  * v_mfma_f32_16x16x32_f16 accumulates over all of K in fp32 registers; one barrier per 128-deep k tile;
+//  * small grids split K across workgroups (fp32 slabs + a reduce/epilogue kernel) to cover the 256 CUs.
+#pragma once
+#include "gemv_kernel.h"
+
+namespace bigdl {
+
+struct GemmArgs {
+  const _Float16* x;      // [*, ldx]
+  const void* w;          // T16 buffer ([N, K], or experts stacked by rows in grouped mode)
+  void* out;              // [Mtot, ldo]
+  float* partial;         // [splitk][Mtot][N] fp32 when splitk > 1
+  const void* bias;       // [N] fp16 or null (dense mode)
+  const void* residual;   // [Mtot, ldo] or null
+  int M, N, K, ldx, ldo, act, out_type;
+  int splitk, kt_per_split;
+  // grouped mode (blk_expert != null): m-block b covers sorted rows [blk_row0[b], +blk_rows[b]) of expert
+  // blk_expert[b] (< 0: unused block); x row of sorted row i is x_rows[i] (null: i); out row is i
+  const int* blk_expert;
+  const int* blk_row0;
+  const int* blk_rows;
+  const int* x_rows;
+  const float* row_scale;  // [Mtot] multiplied into the output rows (routing weights), or null
+  int n_total;             // rows of the stacked weight buffer
+};
+
+template <int QT, int MT>
+__global__ __launch_bounds__(256, 2) void gemm_t16_kernel(GemmArgs a) {
+  constexpr int NT = 2;            // 16-column weight tiles per wavefront
+  constexpr int BM = MT * 16;
+  constexpr int BN = 4 * NT * 16;  // 4 wavefronts side by side along N
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* As = smem;                                               // [2][BM][256 B]
+  _Float16* nf4_lut = (_Float16*)(smem + 2 * BM * 256);           // [64][16] (nf4 only)
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int KT = (a.K + 127) >> 7;
+  const int nblocks = (a.N + BN - 1) / BN;
+  const int nb = blockIdx.x % nblocks, sp = blockIdx.x / nblocks;
+  const int mb = blockIdx.y;
+
+  int row0 = mb * BM, rows = min(BM, a.M - row0);
+  int64_t wt = 0;
+  int n_planes = a.N;
+  if (a.blk_expert != nullptr) {
+    const int e = a.blk_expert[mb];
+    if (e < 0) return;
+    row0 = a.blk_row0[mb];
+    rows = a.blk_rows[mb];
+    wt = (int64_t)e * (a.N >> 4);
+    n_planes = a.n_total;
+  }
+  const int kt0 = sp * a.kt_per_split, kt1 = min(KT, kt0 + a.kt_per_split);
+  const T16Planes pl = t16_planes(a.w, QT, n_planes, a.K);
+
+  const _Float16* lut = nullptr;
+  if constexpr (QT == Q_NF4) {
+    for (int i = threadIdx.x; i < 64 * 16; i += 256) nf4_lut[i] = (_Float16)NF4_VALUES[i & 15];
+    lut = nf4_lut + lane * 16;
+  }
+
+  // this wavefront's weight tile rows (clamped: a tile past N is loaded from the last valid one and never stored)
+  const int ntiles = (a.N + 15) >> 4;
+  int nt_idx[NT];
+  int64_t tbase[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    nt_idx[n] = nb * (BN / 16) + wave * NT + n;
+    tbase[n] = (wt + min(nt_idx[n], ntiles - 1)) * KT;
+  }
+
+  // x staging: thread t moves 16 bytes of row (16 p + t / 16), slot t % 16, for p = 0 .. MT-1
+  const int srow = threadIdx.x >> 4, sslot = threadIdx.x & 15;
+  // element offsets into x (32 bits: the host checks rows * ldx < 2^31); ~0u marks a row past the block
+  uint32_t xsrc[MT];
+#pragma unroll
+  for (int p = 0; p < MT; ++p) {
+    const int row = 16 * p + srow;
+    if (row < rows) {
+      const int64_t xr = a.x_rows != nullptr ? a.x_rows[row0 + row] : row0 + row;
+      xsrc[p] = (uint32_t)(xr * a.ldx + sslot * 8);
+    } else {
+      xsrc[p] = ~0u;
+    }
+  }
+  const int swz = ((sslot ^ srow) & 15) << 4;   // (16 p + srow) & 15 == srow
+  uint4v areg[MT];
+  auto gload_a = [&](int kt) {
+    const int k = kt * 128 + sslot * 8;
+#pragma unroll
+    for (int p = 0; p < MT; ++p) {
+      uint4v v = {0, 0, 0, 0};
+      if (xsrc[p] != ~0u && k < a.K) v = *(const uint4v*)(a.x + xsrc[p] + kt * 128);
+      areg[p] = v;
+    }
+  };
+  auto store_a = [&](int stage) {
+    char* base = As + stage * BM * 256 + srow * 256 + swz;
+#pragma unroll
+    for (int p = 0; p < MT; ++p) *(uint4v*)(base + p * 16 * 256) = areg[p];
+  };
+
+  float4v acc[MT][NT];
+#pragma unroll
+  for (int j = 0; j < MT; ++j)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[j][n] = float4v{0, 0, 0, 0};
+
+  Tile<QT> ta[NT], tb[NT];
+  auto fetch_b = [&](Tile<QT> (&tt)[NT], int kt) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n) load_tile<QT>(tt[n], pl, tbase[n] + kt, lane);
+  };
+  auto compute = [&](Tile<QT> (&tt)[NT], int stage) {
+    const char* abase = As + stage * BM * 256 + r * 256;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      half8 bf[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const half8 code = decode_step<QT>(tt[n], s, lut);
+        _Float16 d = tt[n].d[s];
+        if constexpr (post_scale<QT>() != 1.0f) d = (_Float16)fminf((float)d * post_scale<QT>(), 65504.0f);
+        if constexpr (has_min<QT>()) bf[n] = code * d + tt[n].m[s];
+        else bf[n] = code * d;
+      }
+      const int aoff = (((4 * s + g) ^ r) & 15) << 4;
+#pragma unroll
+      for (int j = 0; j < MT; ++j) {
+        const half8 af = *(const half8*)(abase + j * 16 * 256 + aoff);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[j][n] = mfma16(af, bf[n], acc[j][n]);
+      }
+    }
+  };
+
+  // prologue
+  gload_a(kt0);
+  fetch_b(ta, kt0);
+  store_a(0);
+  __syncthreads();
+  for (int kt = kt0; kt < kt1; kt += 2) {
+    // even step: compute stage 0 with ta, prefetch kt + 1 into stage 1 / tb
+    const bool more1 = kt + 1 < kt1;
+    if (more1) { gload_a(kt + 1); fetch_b(tb, kt + 1); }
+    compute(ta, 0);
+    if (more1) store_a(1);
+    __syncthreads();
+    if (!more1) break;
+    const bool more2 = kt + 2 < kt1;
+    if (more2) { gload_a(kt + 2); fetch_b(ta, kt + 2); }
+    compute(tb, 1);
+    if (more2) store_a(0);
+    __syncthreads();
+  }
+
+  // epilogue
+  const int64_t mtot = a.M;
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int ncol = nt_idx[n] * 16 + r;
+    if (nt_idx[n] >= ntiles || ncol >= a.N) continue;
+    float bias = 0.0f;
+    if (a.bias != nullptr && a.splitk == 1) bias = (float)((const _Float16*)a.bias)[ncol];
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int m = 16 * j + 4 * g + q;
+        if (m >= rows) continue;
+        const int64_t orow = row0 + m;
+        float v = acc[j][n][q];
+        if (a.splitk > 1) {
+          a.partial[((int64_t)sp * mtot + orow) * a.N + ncol] = v;
+          continue;
+        }
+        v = act_apply(a.act, v + bias);
+        if (a.row_scale != nullptr) v *= a.row_scale[orow];
+        const int64_t oi = orow * a.ldo + ncol;
+        if (a.out_type == OUT_F16) {
+          if (a.residual) v += load_out<OUT_F16>(a.residual, oi);
+          store_out<OUT_F16>(a.out, oi, v);
+        } else if (a.out_type == OUT_BF16) {
+          if (a.residual) v += load_out<OUT_BF16>(a.residual, oi);
+          store_out<OUT_BF16>(a.out, oi, v);
+        } else {
+          if (a.residual) v += load_out<OUT_F32>(a.residual, oi);
+          store_out<OUT_F32>(a.out, oi, v);
+        }
+      }
+    }
+  }
+}
+
+template <int QT, int MT>
+static int gemm_launch_mt(const GemmArgs& a, int mblocks, hipStream_t st) {
+  constexpr int BM = MT * 16;
+  const size_t lds = 2 * BM * 256 + (QT == Q_NF4 ? 64 * 16 * 2 : 0);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)gemm_t16_kernel<QT, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return -101;
+    attr_set = true;
+  }
+  const int nblocks = (a.N + 127) / 128;
+  const dim3 grid(nblocks * a.splitk, mblocks);
+  hipLaunchKernelGGL((gemm_t16_kernel<QT, MT>), grid, dim3(256), lds, st, a);
+  return HIP_CHECK_LAUNCH();
+}
+
+template <int QT>
+static int gemm_launch_qt(const GemmArgs& a, int bm, int mblocks, hipStream_t st) {
+  if (bm == 64) return gemm_launch_mt<QT, 4>(a, mblocks, st);
+  return gemm_launch_mt<QT, 8>(a, mblocks, st);
+}
+
+}  // namespace bigdl

@@ -1,0 +1,163 @@
+// Host entry points of the dequant-fused MFMA GEMM (kernel: gemm_kernel.h; one instantiation unit per weight
+// format: gemm_inst_*.hip), its split-K reduce/epilogue kernel and the device-side block table of the grouped
+// (mixture-of-experts) form.
+#include "gemm_kernel.h"
+#include <stdlib.h>
+
+namespace bigdl {
+int gemm_launch_sym_int4(const GemmArgs& a, int bm, int mblocks, hipStream_t st);
+int gemm_launch_asym_int4(const GemmArgs& a, int bm, int mblocks, hipStream_t st);
+int gemm_launch_woq_int4(const GemmArgs& a, int bm, int mblocks, hipStream_t st);
+int gemm_launch_fp4(const GemmArgs& a, int bm, int mblocks, hipStream_t st);
+int gemm_launch_nf4(const GemmArgs& a, int bm, int mblocks, hipStream_t st);
+int gemm_launch_sym_int5(const GemmArgs& a, int bm, int mblocks, hipStream_t st);
+int gemm_launch_asym_int5(const GemmArgs& a, int bm, int mblocks, hipStream_t st);
+int gemm_launch_fp6(const GemmArgs& a, int bm, int mblocks, hipStream_t st);
+int gemm_launch_sym_int8(const GemmArgs& a, int bm, int mblocks, hipStream_t st);
+int gemm_launch_fp8_e4m3(const GemmArgs& a, int bm, int mblocks, hipStream_t st);
+int gemm_launch_fp8_e5m2(const GemmArgs& a, int bm, int mblocks, hipStream_t st);
+
+// out[m][n] = epilogue(sum_s partial[s][m][n])
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs a) {
+  const int64_t total = (int64_t)a.M * a.N;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int64_t m = i / a.N;
+  const int n = (int)(i - m * a.N);
+  float v = 0.0f;
+  for (int s = 0; s < a.splitk; ++s) v += a.partial[(int64_t)s * total + i];
+  if (a.bias != nullptr) v += (float)((const _Float16*)a.bias)[n];
+  v = act_apply(a.act, v);
+  if (a.row_scale != nullptr) v *= a.row_scale[m];
+  const int64_t oi = m * a.ldo + n;
+  if (a.out_type == OUT_F16) {
+    if (a.residual) v += load_out<OUT_F16>(a.residual, oi);
+    store_out<OUT_F16>(a.out, oi, v);
+  } else if (a.out_type == OUT_BF16) {
+    if (a.residual) v += load_out<OUT_BF16>(a.residual, oi);
+    store_out<OUT_BF16>(a.out, oi, v);
+  } else {
+    if (a.residual) v += load_out<OUT_F32>(a.residual, oi);
+    store_out<OUT_F32>(a.out, oi, v);
+  }
+}
+
+// counts[e] rows of expert e, rows sorted by expert -> table of m-blocks of at most bm rows; unused entries get
+// expert -1.  One wavefront: E is at most a few hundred.
+__global__ void moe_block_table_kernel(const int64_t* counts, int n_experts, int bm, int max_blocks, int* blk_expert,
+                                       int* blk_row0, int* blk_rows) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int b = 0;
+  int64_t row = 0;
+  for (int e = 0; e < n_experts; ++e) {
+    int64_t c = counts[e];
+    for (int64_t o = 0; o < c && b < max_blocks; o += bm, ++b) {
+      blk_expert[b] = e;
+      blk_row0[b] = (int)(row + o);
+      blk_rows[b] = (int)min((int64_t)bm, c - o);
+    }
+    row += c;
+  }
+  for (; b < max_blocks; ++b) { blk_expert[b] = -1; blk_row0[b] = 0; blk_rows[b] = 0; }
+}
+}  // namespace bigdl
+
+using namespace bigdl;
+
+static int dispatch(const GemmArgs& a, int qtype, int bm, int mblocks, hipStream_t st) {
+  switch (qtype) {
+    case Q_SYM_INT4: return gemm_launch_sym_int4(a, bm, mblocks, st);
+    case Q_ASYM_INT4: return gemm_launch_asym_int4(a, bm, mblocks, st);
+    case Q_WOQ_INT4: return gemm_launch_woq_int4(a, bm, mblocks, st);
+    case Q_FP4: return gemm_launch_fp4(a, bm, mblocks, st);
+    case Q_NF4: return gemm_launch_nf4(a, bm, mblocks, st);
+    case Q_SYM_INT5: return gemm_launch_sym_int5(a, bm, mblocks, st);
+    case Q_ASYM_INT5: return gemm_launch_asym_int5(a, bm, mblocks, st);
+    case Q_FP6: return gemm_launch_fp6(a, bm, mblocks, st);
+    case Q_SYM_INT8: return gemm_launch_sym_int8(a, bm, mblocks, st);
+    case Q_FP8_E4M3: return gemm_launch_fp8_e4m3(a, bm, mblocks, st);
+    case Q_FP8_E5M2: return gemm_launch_fp8_e5m2(a, bm, mblocks, st);
+    default: return -2;
+  }
+}
+
+static void plan(int mblocks, int N, int K, int* splitk, int* kt_per_split) {
+  const int KT = (K + 127) / 128;
+  const int blocks = ((N + 127) / 128) * mblocks;
+  int sk = 1;
+  static const int target = getenv("BIGDL_GEMM_TARGET") ? atoi(getenv("BIGDL_GEMM_TARGET")) : 256;
+  if (blocks < target * 3 / 4) sk = (target + blocks - 1) / blocks;
+  sk = sk < 1 ? 1 : sk;
+  if (sk > KT / 2) sk = KT / 2 > 0 ? KT / 2 : 1;   // at least two k tiles per split
+  const int per = (KT + sk - 1) / sk;
+  *kt_per_split = per;
+  *splitk = (KT + per - 1) / per;
+}
+
+// Number of K splits the launch below will use for this shape (the caller provides splitk * M * N floats of
+// workspace when it is > 1).  mblocks: number of row blocks (dense: ceil(M / bm)).
+extern "C" int bigdl_gemm_lowbit_splitk(int mblocks, int N, int K) {
+  int sk, per;
+  plan(mblocks, N, K, &sk, &per);
+  return sk;
+}
+
+extern "C" int bigdl_gemm_lowbit_bm(int M) {
+  static const int forced = getenv("BIGDL_GEMM_BM") ? atoi(getenv("BIGDL_GEMM_BM")) : 0;
+  if (forced == 64 || forced == 128) return forced;
+  // 64-row blocks keep two or more wavefronts per SIMD (170 VGPRs): measured 10-40 % faster than 128-row blocks at
+  // every M between 64 and 1024 on the Llama-2-7B projection shapes
+  return 64;
+}
+
+// Dense form.  x fp16 [M, ldx] (ldx % 8 == 0, 16-byte aligned), K % 32 == 0.  workspace: fp32, >= splitk*M*N.
+extern "C" int bigdl_gemm_lowbit(const void* x, const void* w, void* out, const void* bias, const void* residual,
+                                 float* workspace, int64_t workspace_floats, int M, int N, int K, int ldx, int ldo,
+                                 int qtype, int act, int out_type, hipStream_t stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || (K & 31) || (ldx & 7) || ((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return -1;
+  if (out_type < 0 || out_type > 2) return -3;
+  if ((int64_t)M * ldx >= (1ll << 31)) return -6;
+  GemmArgs a = {};
+  a.x = (const _Float16*)x; a.w = w; a.out = out; a.bias = bias; a.residual = residual; a.partial = workspace;
+  a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldo = ldo; a.act = act; a.out_type = out_type;
+  const int bm = bigdl_gemm_lowbit_bm(M);
+  const int mblocks = (M + bm - 1) / bm;
+  plan(mblocks, N, K, &a.splitk, &a.kt_per_split);
+  if (a.splitk > 1 && (workspace == nullptr || workspace_floats < (int64_t)a.splitk * M * N)) return -5;
+  const int rc = dispatch(a, qtype, bm, mblocks, stream);
+  if (rc != 0 || a.splitk == 1) return rc;
+  const int64_t total = (int64_t)M * N;
+  hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
+  return HIP_CHECK_LAUNCH();
+}
+
+// Grouped form: `rows` sorted rows in total; row i uses the weights of the expert that the block table assigns
+// to its block, reads x row x_rows[i] (null: i) and writes out row i (scaled by row_scale[i] if given).
+// The experts' [N, K] matrices are stacked by rows in w (N % 16 == 0).  bm is 64 or 128 and must be the value the
+// block table was built with; max_blocks >= ceil(rows / bm) + n_experts.
+extern "C" int bigdl_gemm_lowbit_grouped(const void* x, const void* w, void* out, const int* blk_expert,
+                                         const int* blk_row0, const int* blk_rows, const int* x_rows,
+                                         const float* row_scale, int rows, int max_blocks, int bm, int n_experts,
+                                         int N, int K, int ldx, int ldo, int qtype, int act, int out_type,
+                                         int x_row_count, hipStream_t stream) {
+  if (x_row_count <= 0 || (int64_t)x_row_count * ldx >= (1ll << 31)) return -6;
+  if (rows <= 0 || N <= 0 || K <= 0 || (K & 31) || (N & 15) || (ldx & 7) || ((uintptr_t)x & 15) || ((uintptr_t)w & 15) ||
+      blk_expert == nullptr || blk_row0 == nullptr || blk_rows == nullptr || (bm != 64 && bm != 128) || max_blocks <= 0 ||
+      max_blocks > 65535 || n_experts <= 0)
+    return -1;
+  if (out_type < 0 || out_type > 2) return -3;
+  GemmArgs a = {};
+  a.x = (const _Float16*)x; a.w = w; a.out = out; a.M = rows; a.N = N; a.K = K; a.ldx = ldx; a.ldo = ldo; a.act = act;
+  a.out_type = out_type; a.splitk = 1; a.kt_per_split = (K + 127) / 128;
+  a.blk_expert = blk_expert; a.blk_row0 = blk_row0; a.blk_rows = blk_rows; a.x_rows = x_rows; a.row_scale = row_scale;
+  a.n_total = n_experts * N;
+  return dispatch(a, qtype, bm, max_blocks, stream);
+}
+
+extern "C" int bigdl_moe_block_table(const int64_t* counts, int n_experts, int bm, int max_blocks, int* blk_expert,
+                                     int* blk_row0, int* blk_rows, hipStream_t stream) {
+  if (counts == nullptr || n_experts <= 0 || bm <= 0 || max_blocks <= 0) return -1;
+  hipLaunchKernelGGL(moe_block_table_kernel, dim3(1), dim3(64), 0, stream, counts, n_experts, bm, max_blocks, blk_expert,
+                     blk_row0, blk_rows);
+  return HIP_CHECK_LAUNCH();
+}

@@ -24,7 +24,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import qtypes as Q
-from ..transformers.low_bit_linear import FP4Params, dequant_weight
+from ..transformers.low_bit_linear import FP4Params, GEMM_MAX_ROWS, GEMV_MAX_ROWS, dequant_weight
 
 
 @dataclass
@@ -255,8 +255,10 @@ class NativeDecoder:
     # ------------------------------------------------------------------ prefill (eager)
     def _linear_dense(self, x, lin: Lin):
         from ..ops import hip
-        if lin.fused and x.shape[0] <= 64:
+        if lin.fused and x.shape[0] <= GEMV_MAX_ROWS:
             return hip.gemv_lowbit(x.contiguous(), lin.w, lin.qtype, lin.n, lin.k, bias=lin.bias)
+        if lin.fused and x.shape[0] <= GEMM_MAX_ROWS:
+            return hip.gemm_lowbit(x.contiguous(), lin.w, lin.qtype, lin.n, lin.k, bias=lin.bias)
         y = F.linear(x, lin.dense())
         if lin.bias is not None:
             y = y + lin.bias
@@ -437,6 +439,15 @@ class NativeDecoder:
         """out = epilogue(norm?(x) @ W^T): fused kernel for T16 weights, unfused torch ops otherwise."""
         from ..ops import hip
         cfg = self.cfg
+        m = x.shape[0]
+        if lin.fused and (w2 is None or w2.fused) and m > GEMV_MAX_ROWS and att_partials is None:
+            # batched decode (17 .. 64 rows): RMSNorm kernel + MFMA GEMM with the epilogue fused
+            xin = x if gamma is None else hip.rms_norm(x, gamma, cfg.rms_eps, offset=cfg.norm_offset)
+            if w2 is None:
+                return hip.gemm_lowbit(xin, lin.w, lin.qtype, lin.n, lin.k, bias=lin.bias, residual=residual, act=act, out=out)
+            g = hip.gemm_lowbit(xin, lin.w, lin.qtype, lin.n, lin.k, bias=lin.bias, out=out)
+            u = hip.gemm_lowbit(xin, w2.w, w2.qtype, w2.n, w2.k, bias=w2.bias)
+            return hip.act_mul(g, u, act)
         if lin.fused and (w2 is None or w2.fused):
             return hip.gemv_lowbit(x, lin.w, lin.qtype, lin.n, lin.k, w2=None if w2 is None else w2.w, bias=lin.bias,
                                    bias2=None if w2 is None else w2.bias, residual=residual, gamma=gamma,

@@ -5,7 +5,8 @@ device) -> routed gate/up GEMV with fused activation -> routed down GEMV scaled 
 combine kernel (sum over the k slots + gated shared expert + residual).  Only the selected experts' weights are
 streamed: for Mixtral-8x7B that is 2/8 of the expert bytes per token.
 
-Prefill: tokens are bucketed by expert and each non-empty expert runs dequant + dense GEMM on its bucket.
+Prefill: tokens are sorted by expert on the device and the three expert products run as grouped dequant-fused MFMA
+GEMMs over 64-row blocks (``gemm_lowbit_grouped``); dense (unquantized) experts run one GEMM per non-empty bucket.
 
 Expert parallelism: ``expert_range=(lo, hi)`` keeps a contiguous slice of the experts on this rank; slots routed
 elsewhere produce zero rows and the partial outputs are summed with one all-reduce (every rank holds all tokens
@@ -22,6 +23,36 @@ import torch
 import torch.nn.functional as F
 
 from .. import qtypes as Q
+
+
+def grouped_moe_ffn(x, ids, weights, gate, up, down, qtype, n_experts, inter, hidden, act, zero_fill=False):
+    """Routed expert FFN for many tokens on the grouped dequant-fused MFMA GEMM.
+
+    x [T, H] fp16; ids int [T, k] (negative = expert not on this rank); weights [T, k]; gate / up / down: T16 buffers of
+    the experts' matrices stacked by rows.  Rows are sorted by expert on the device and cut into 64-row blocks by a
+    table kernel, so there is no host round trip (the reference buckets on the host:
+    python/llm/src/ipex_llm/transformers/models/qwen2_moe.py:400-416).  Returns sum_k w * expert(x) as [T, H]."""
+    from ..ops import hip
+    t, k = ids.shape
+    flat = ids.reshape(-1).long()
+    key = torch.where(flat >= 0, flat, torch.full_like(flat, n_experts))      # non-local slots sort last
+    order = torch.argsort(key, stable=True)
+    tok = torch.div(order, k, rounding_mode="floor")
+    rows, bm = t * k, 64
+    counts = torch.bincount(key, minlength=n_experts + 1)[:n_experts].contiguous()
+    table = hip.moe_block_table(counts, bm, (rows + bm - 1) // bm + n_experts)
+    tok32 = tok.int()
+    alloc = torch.zeros if zero_fill else torch.empty                            # non-local rows must stay zero
+    g = alloc((rows, inter), dtype=torch.float16, device=x.device)
+    hip.gemm_lowbit_grouped(x, gate, qtype, n_experts, inter, hidden, table, rows, bm, x_rows=tok32, out=g)
+    u = hip.gemm_lowbit_grouped(x, up, qtype, n_experts, inter, hidden, table, rows, bm, x_rows=tok32)
+    hip.act_mul(g, u, act)
+    y = alloc((rows, hidden), dtype=torch.float16, device=x.device)
+    hip.gemm_lowbit_grouped(g, down, qtype, n_experts, hidden, inter, table, rows, bm,
+                            row_scale=weights.reshape(-1)[order].float().contiguous(), out=y)
+    out = torch.zeros_like(x)
+    out.index_add_(0, tok, y)
+    return out
 
 
 class MoEWeights:
@@ -109,9 +140,13 @@ class MoEWeights:
         from ..ops import hip
         sg, su, sd = self.shared
         t = x.shape[0]
-        if t <= 32 and sg.fused and su.fused and sd.fused:
+        if t <= 16 and sg.fused and su.fused and sd.fused:
             a = hip.gemv_lowbit(x, sg.w, sg.qtype, sg.n, sg.k, w2=su.w, act=self.act)
             y = hip.gemv_lowbit(a, sd.w, sd.qtype, sd.n, sd.k)
+        elif t <= 256 and sg.fused and su.fused and sd.fused:
+            a = hip.act_mul(hip.gemm_lowbit(x, sg.w, sg.qtype, sg.n, sg.k), hip.gemm_lowbit(x, su.w, su.qtype, su.n, su.k),
+                            self.act)
+            y = hip.gemm_lowbit(a, sd.w, sd.qtype, sd.n, sd.k)
         else:
             a = hip.act_mul(F.linear(x, sg.dense()), F.linear(x, su.dense()), self.act)
             y = F.linear(a, sd.dense())
@@ -173,25 +208,28 @@ class MoEWeights:
                                     slot_scale=w.view(-1))
             out = y.view(t, k, -1).sum(1)
         else:
-            flat = ids.view(-1).long()
-            local = flat >= 0
-            key = torch.where(local, flat, torch.full_like(flat, self.n_local))      # non-local slots sort last
-            order = torch.argsort(key, stable=True)
-            counts = torch.bincount(key, minlength=self.n_local + 1).tolist()
-            tok = torch.div(order, k, rounding_mode="floor")
-            xs = x[tok]
-            ws = w.view(-1)[order].to(x.dtype)
-            out = torch.zeros_like(x)
-            off = 0
-            for e in range(self.n_local):
-                c = counts[e]
-                if c == 0:
-                    continue
-                xe = xs[off:off + c]
-                a = hip.act_mul(F.linear(xe, self._expert_w("gate", e)), F.linear(xe, self._expert_w("up", e)), self.act)
-                ye = F.linear(a, self._expert_w("down", e))
-                out.index_add_(0, tok[off:off + c], ye * ws[off:off + c, None])
-                off += c
+            if self.fused:
+                out = grouped_moe_ffn(x, ids, w, self.gate, self.up, self.down, self.qtype, self.n_local, self.inter,
+                                      self.hidden, self.act, zero_fill=self.expert_range is not None)
+            else:
+                flat = ids.view(-1).long()
+                key = torch.where(flat >= 0, flat, torch.full_like(flat, self.n_local))
+                order = torch.argsort(key, stable=True)
+                tok = torch.div(order, k, rounding_mode="floor")
+                counts = torch.bincount(key, minlength=self.n_local + 1).tolist()
+                xs = x[tok]
+                ws = w.view(-1)[order].to(x.dtype)
+                out = torch.zeros_like(x)
+                off = 0
+                for e in range(self.n_local):
+                    c = counts[e]
+                    if c == 0:
+                        continue
+                    xe = xs[off:off + c]
+                    a = hip.act_mul(F.linear(xe, self._expert_w("gate", e)), F.linear(xe, self._expert_w("up", e)), self.act)
+                    ye = F.linear(a, self._expert_w("down", e))
+                    out.index_add_(0, tok[off:off + c], ye * ws[off:off + c, None])
+                    off += c
         if self.expert_range is not None:
             self._reduce(out)
         sy, gl = self._shared_out(engine, x)

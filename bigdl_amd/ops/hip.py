@@ -53,6 +53,11 @@ def lib():
         L.bigdl_dequant_t16.argtypes = [vp, vp, ci, ci, i64, ci, ci, ci, ci, vp]
         L.bigdl_dequant_rows.argtypes = [vp, vp, vp, i64, i64, ci, ci, i64, ci, vp]
         L.bigdl_gemv_lowbit_moe.argtypes = [vp, vp, vp, vp, vp, vp, vp, cf, cf, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp]
+        L.bigdl_gemm_lowbit.argtypes = [vp, vp, vp, vp, vp, vp, i64, ci, ci, ci, ci, ci, ci, ci, ci, vp]
+        L.bigdl_gemm_lowbit_splitk.argtypes = [ci, ci, ci]
+        L.bigdl_gemm_lowbit_bm.argtypes = [ci]
+        L.bigdl_gemm_lowbit_grouped.argtypes = [vp] * 8 + [ci] * 12 + [vp]
+        L.bigdl_moe_block_table.argtypes = [vp, ci, ci, ci, vp, vp, vp, vp]
         L.bigdl_moe_route.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, i64, ci, ci, vp]
         L.bigdl_moe_combine.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, i64, vp]
         L.bigdl_rwkv_time_shift.argtypes = [vp, vp, vp, vp, i64, ci, ci, ci, vp]
@@ -176,6 +181,105 @@ def gemv_lowbit_moe(x, w, qtype, n_experts, out_features, in_features, slot_expe
                                      in_features, x.stride(0), out.stride(0), qtype, ACT[act], _out_type(out.dtype),
                                      _stream())
     _check(rc, "gemv_lowbit_moe")
+    return out
+
+
+_GEMM_WS = {}
+
+
+def _gemm_workspace(device, floats):
+    """fp32 scratch for split-K partials, grown on demand and kept per device (stream-ordered reuse: every GEMM
+    call consumes its partials before returning control to the stream's next kernel)."""
+    ws = _GEMM_WS.get(device)
+    if ws is None or ws.numel() < floats:
+        ws = _GEMM_WS[device] = torch.empty(max(floats, 1 << 22), dtype=torch.float32, device=device)
+    return ws
+
+
+def gemm_lowbit(x, w, qtype, out_features, in_features, *, bias=None, residual=None, act=None, out=None,
+                out_dtype=None):
+    """``y = act(x @ dequant(w)^T + bias) [+ residual]`` on the MFMA GEMM kernel: x [M, K] fp16 with any M (meant
+    for 16 < M <= 512; larger M is better served by dequantize + hipBLASLt).  w: T16 device buffer."""
+    _need_cuda(x, w, bias, residual, out)
+    if x.dim() != 2 or x.dtype != torch.float16 or x.stride(1) != 1:
+        raise ValueError("x must be a 2-D fp16 tensor with contiguous rows")
+    m, k = x.shape
+    if k != in_features:
+        raise ValueError(f"x has {k} features, weight expects {in_features}")
+    if qtype not in Q.T16_QTYPES:
+        raise ValueError(f"qtype {qtype} has no fused GEMM kernel")
+    from .host import device_nbytes
+    if w.numel() * w.element_size() != device_nbytes(qtype, out_features, in_features):
+        raise ValueError("weight buffer size does not match the tiled layout")
+    out_dtype = out_dtype or (out.dtype if out is not None else torch.float16)
+    if out is None:
+        out = torch.empty((m, out_features), dtype=out_dtype, device=x.device)
+    if out.shape != (m, out_features) or out.stride(1) != 1 or out.dtype != out_dtype:
+        raise ValueError("bad out tensor")
+    if bias is not None and (bias.dtype != torch.float16 or bias.numel() != out_features or not bias.is_contiguous()):
+        raise ValueError("bias must be contiguous fp16 [out_features]")
+    if residual is not None and (residual.shape != out.shape or residual.dtype != out.dtype
+                                 or residual.stride() != out.stride()):
+        raise ValueError("residual must match out")
+    L = lib()
+    bm = L.bigdl_gemm_lowbit_bm(m)
+    sk = L.bigdl_gemm_lowbit_splitk((m + bm - 1) // bm, out_features, k)
+    ws, ws_n = None, 0
+    if sk > 1:
+        ws_n = sk * m * out_features
+        ws = _gemm_workspace(x.device, ws_n)
+        ws_n = ws.numel()
+    rc = L.bigdl_gemm_lowbit(_ptr(x), _ptr(w), _ptr(out), _ptr(bias), _ptr(residual), _ptr(ws), ws_n, m, out_features, k,
+                             x.stride(0), out.stride(0), qtype, ACT[act], _out_type(out_dtype), _stream())
+    _check(rc, "gemm_lowbit")
+    return out
+
+
+def moe_block_table(counts, bm, max_blocks):
+    """counts int64 [E] (rows per expert, rows sorted by expert) -> (blk_expert, blk_row0, blk_rows) int32
+    [max_blocks] on the device, built without a host round trip."""
+    _need_cuda(counts)
+    if counts.dtype != torch.int64 or not counts.is_contiguous():
+        raise ValueError("counts must be contiguous int64")
+    tbl = torch.empty((3, max_blocks), dtype=torch.int32, device=counts.device)
+    rc = lib().bigdl_moe_block_table(_ptr(counts), counts.numel(), bm, max_blocks, _ptr(tbl[0]), _ptr(tbl[1]), _ptr(tbl[2]),
+                                     _stream())
+    _check(rc, "moe_block_table")
+    return tbl[0], tbl[1], tbl[2]
+
+
+def gemm_lowbit_grouped(x, w, qtype, n_experts, out_features, in_features, table, rows, bm, *, x_rows=None,
+                        row_scale=None, act=None, out=None):
+    """Grouped GEMM over experts: sorted row i (rows in total, grouped by expert as described by ``table`` =
+    ``moe_block_table(...)`` built with the same ``bm``) reads ``x[x_rows[i]]`` (``x[i]`` without x_rows) and
+    produces ``out[i] = row_scale[i] * act(x_row @ dequant(W[expert of i])^T)``."""
+    blk_expert, blk_row0, blk_rows = table
+    _need_cuda(x, w, blk_expert, x_rows, row_scale, out)
+    if x.dim() != 2 or x.dtype != torch.float16 or x.stride(1) != 1 or x.shape[1] != in_features:
+        raise ValueError("x must be a 2-D fp16 tensor [*, in_features] with contiguous rows")
+    if qtype not in Q.T16_QTYPES or out_features % 16:
+        raise ValueError("grouped GEMM needs a device-tiled format and out_features % 16 == 0")
+    from .host import device_nbytes
+    if w.numel() * w.element_size() != device_nbytes(qtype, out_features * n_experts, in_features):
+        raise ValueError("expert weight buffer size does not match n_experts x [out_features, in_features]")
+    max_blocks = blk_expert.numel()
+    if max_blocks < (rows + bm - 1) // bm + n_experts - 1 and max_blocks < rows:
+        raise ValueError("block table too small for the row count")
+    if x_rows is not None and (x_rows.dtype != torch.int32 or x_rows.numel() < rows or not x_rows.is_contiguous()):
+        raise ValueError("x_rows must be contiguous int32 [rows]")
+    if x_rows is None and x.shape[0] < rows:
+        raise ValueError("x has too few rows")
+    if row_scale is not None and (row_scale.dtype != torch.float32 or row_scale.numel() < rows or not row_scale.is_contiguous()):
+        raise ValueError("row_scale must be contiguous fp32 [rows]")
+    if out is None:
+        out = torch.empty((rows, out_features), dtype=torch.float16, device=x.device)
+    if out.shape != (rows, out_features) or out.stride(1) != 1:
+        raise ValueError("bad out tensor")
+    rc = lib().bigdl_gemm_lowbit_grouped(_ptr(x), _ptr(w), _ptr(out), _ptr(blk_expert), _ptr(blk_row0), _ptr(blk_rows),
+                                         _ptr(x_rows), _ptr(row_scale), rows, max_blocks, bm, n_experts, out_features,
+                                         in_features, x.stride(0), out.stride(0), qtype, ACT[act], _out_type(out.dtype),
+                                         x.shape[0], _stream())
+    _check(rc, "gemm_lowbit_grouped")
     return out
 
 

@@ -11,6 +11,8 @@ python/llm/src/ipex_llm/transformers/models/mixtral.py:60-130 and models/common.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch import nn
 
@@ -18,6 +20,9 @@ from .. import qtypes as Q
 from .low_bit_linear import FP4Params, LowBitLinear, dequant_weight_rows
 
 ROUTED_GEMV_MAX_SLOTS = 64
+# inference with many routed rows: grouped dequant-fused MFMA GEMM; BIGDL_MOE_GROUPED_GEMM=0 falls back to one dense
+# GEMM pair per expert (kept as an independent reference path)
+GROUPED_GEMM = os.environ.get("BIGDL_MOE_GROUPED_GEMM", "1") != "0"
 
 
 def is_fused_experts(module) -> bool:
@@ -81,6 +86,12 @@ class LowBitExperts(nn.Module):
             y = hip.gemv_lowbit_moe(a, down.data, self.qtype, e, h, i, ids,
                                     slot_scale=top_k_weights.reshape(-1).float().contiguous())
             return y.view(t, k, h).sum(1).to(hidden_states.dtype)
+        if hidden_states.device.type == "cuda" and gate.qlayout == "t16" and act is not None and i % 16 == 0 \
+                and h % 16 == 0 and not torch.is_grad_enabled() and GROUPED_GEMM:
+            from ..models.moe import grouped_moe_ffn
+            x = hidden_states if hidden_states.dtype == torch.float16 else hidden_states.to(torch.float16)
+            return grouped_moe_ffn(x.contiguous(), top_k_index, top_k_weights, gate.data, up.data, down.data, self.qtype,
+                                   e, i, h, act).to(hidden_states.dtype)
         # bucket the (token, slot) pairs by expert; one dense GEMM pair per expert that received tokens
         flat = top_k_index.reshape(-1)
         order = torch.argsort(flat, stable=True)

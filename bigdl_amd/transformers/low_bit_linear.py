@@ -27,7 +27,10 @@ from ..utils.common import invalidInputError
 
 TORCH_LINEAR_THRESHOLD = int(os.getenv("BIGDL_LLM_LINEAR_THRESHOLD", "512"))
 # rows above which the device path dequantizes + calls the dense GEMM instead of the fused GEMV
-GEMV_MAX_ROWS = 64
+# row-count policy of the fused kernels on the GPU (measured on the Llama-2-7B projection shapes, sym_int4): the skinny
+# GEMV wins up to 16 rows, the fused MFMA GEMM from 17 to 256 rows, dequantize + hipBLASLt above
+GEMV_MAX_ROWS = 16
+GEMM_MAX_ROWS = 256
 
 
 def get_block_size(qtype) -> int:
@@ -234,11 +237,13 @@ def lowbit_matmul(x_2d: torch.Tensor, weight: FP4Params, out_features: int) -> t
     if weight.data.device.type == "cuda":
         from ..ops import hip
         m = x_2d.shape[0]
-        if weight.qlayout == "t16" and m <= GEMV_MAX_ROWS:
+        if weight.qlayout == "t16" and m <= GEMM_MAX_ROWS:
             xh = x_2d if x_2d.dtype == torch.float16 else x_2d.to(torch.float16)
             if xh.stride(1) != 1 or xh.stride(0) % 8 or xh.data_ptr() % 16:
                 xh = xh.contiguous()
-            return hip.gemv_lowbit(xh, weight.data, weight.qtype, n, k, out_dtype=x_2d.dtype)
+            if m <= GEMV_MAX_ROWS:
+                return hip.gemv_lowbit(xh, weight.data, weight.qtype, n, k, out_dtype=x_2d.dtype)
+            return hip.gemm_lowbit(xh, weight.data, weight.qtype, n, k, out_dtype=x_2d.dtype)
         cdt = x_2d.dtype if x_2d.dtype in (torch.float16, torch.bfloat16) else torch.float16
         w = dequant_weight(weight, cdt)
         return F.linear(x_2d.to(cdt), w).to(x_2d.dtype)

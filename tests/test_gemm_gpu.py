@@ -1,0 +1,97 @@
+"""Dequant-fused MFMA GEMM (dense and grouped) against a plain PyTorch fp32 reference over the dequantized weights."""
+import pytest
+import torch
+
+from bigdl_amd import qtypes as Q
+from bigdl_amd.ops import host
+
+pytestmark = pytest.mark.gpu
+
+T16 = ["sym_int4", "asym_int4", "woq_int4", "fp4", "nf4", "sym_int5", "asym_int5", "fp6", "sym_int8", "fp8_e4m3",
+       "fp8_e5m2"]
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from bigdl_amd.ops import hip as h
+    h.lib()
+    return h
+
+
+def _quant_dev(w, qt):
+    n, k = w.shape
+    buf = host.quantize(w, qt)
+    raw = buf.view(torch.uint8) if buf.dtype != torch.uint8 else buf
+    ref = host.dequantize(raw, qt, w.shape)
+    return host.relayout_to_device(raw, qt, n, k).cuda(), ref
+
+
+@pytest.mark.parametrize("name", T16)
+@pytest.mark.parametrize("m", [17, 64, 100, 128, 300])
+def test_gemm_matches_dequant_reference(hip, name, m):
+    torch.manual_seed(2)
+    qt = Q.ggml_tensor_qtype[name]
+    n, k = 272, 640          # N not a multiple of 128 (tail tiles), K = 5 k-tiles (odd: both pipeline exits)
+    w = torch.randn(n, k) * 0.05
+    x = torch.randn(m, k).half()
+    dev, ref_w = _quant_dev(w, qt)
+    ref = x.float() @ ref_w.t()
+    out = hip.gemm_lowbit(x.cuda(), dev, qt, n, k, out_dtype=torch.float32).cpu()
+    # weights are rounded to fp16 after scaling (as in dequantize + dense GEMM), accumulation is fp32
+    torch.testing.assert_close(out, ref, rtol=3e-3, atol=3e-3)
+
+
+@pytest.mark.parametrize("shape", [(96, 4096, 1024), (130, 256, 4096), (64, 1024, 128)])
+def test_gemm_split_k_epilogue(hip, shape):
+    """Shapes that take the split-K path (few output tiles, long K) with bias, activation and residual."""
+    torch.manual_seed(3)
+    m, k, n = shape
+    qt = Q.SYM_INT4
+    w = torch.randn(n, k) * 0.03
+    x = torch.randn(m, k).half()
+    bias = (torch.randn(n) * 0.1).half()
+    res = torch.randn(m, n).half()
+    dev, ref_w = _quant_dev(w, qt)
+    ref = torch.nn.functional.silu(x.float() @ ref_w.t() + bias.float()) + res.float()
+    out = hip.gemm_lowbit(x.cuda(), dev, qt, n, k, bias=bias.cuda(), residual=res.cuda(), act="silu").cpu().float()
+    torch.testing.assert_close(out, ref, rtol=5e-3, atol=5e-3)
+
+
+def test_gemm_strided_rows_and_k_tail(hip):
+    torch.manual_seed(4)
+    qt = Q.ASYM_INT4
+    m, k, n = 70, 160, 48        # K = 1.25 k-tiles: zero-scale padding blocks, x beyond K must not be read
+    w = torch.randn(n, k) * 0.05
+    big = torch.randn(m, k + 24).half().cuda()
+    x = big[:, :k]
+    dev, ref_w = _quant_dev(w, qt)
+    out = hip.gemm_lowbit(x, dev, qt, n, k, out_dtype=torch.float32).cpu()
+    torch.testing.assert_close(out, x.cpu().float() @ ref_w.t(), rtol=3e-3, atol=3e-3)
+
+
+@pytest.mark.parametrize("bm", [64, 128])
+def test_grouped_gemm_matches_per_expert_reference(hip, bm):
+    torch.manual_seed(5)
+    qt = Q.SYM_INT4
+    e, n, k, t, top_k = 6, 96, 256, 150, 2
+    ws = [torch.randn(n, k) * 0.05 for _ in range(e)]
+    refs, raws = [], []
+    for w in ws:
+        buf = host.quantize(w, qt)
+        raws.append(buf.view(torch.uint8))
+        refs.append(host.dequantize(raws[-1], qt, w.shape))
+    stacked = host.relayout_to_device(torch.cat(raws), qt, e * n, k).cuda()
+    x = torch.randn(t, k).half().cuda()
+    ids = torch.stack([torch.randperm(e)[:top_k] for _ in range(t)]).int().cuda()
+    ids[ids == 4] = 1                         # expert 4 gets no rows at all
+    flat = ids.view(-1).long()
+    order = torch.argsort(flat, stable=True)
+    counts = torch.bincount(flat, minlength=e)
+    tok = torch.div(order, top_k, rounding_mode="floor").int()
+    scale = torch.rand(t * top_k).cuda()
+    rows = t * top_k
+    table = hip.moe_block_table(counts, bm, (rows + bm - 1) // bm + e)
+    out = hip.gemm_lowbit_grouped(x, stacked, qt, e, n, k, table, rows, bm, x_rows=tok, row_scale=scale[order].contiguous())
+    exp_sorted = flat[order].cpu()
+    ref = torch.stack([x[tok[i]].cpu().float() @ refs[int(exp_sorted[i])].t() * float(scale[order][i]) for i in range(rows)])
+    torch.testing.assert_close(out.cpu().float(), ref, rtol=5e-3, atol=5e-3)
