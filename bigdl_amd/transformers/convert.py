@@ -69,8 +69,15 @@ def is_linear_module(module):
         return True, (module.infeatures if hasattr(module, "infeatures") else module.in_features,
                       module.outfeatures if hasattr(module, "outfeatures") else module.out_features, None)
     if isinstance(module, nn.Linear):
+        name = type(module).__name__.lower()
+        if type(module).forward is not nn.Linear.forward and ("router" in name or "gate" in name):
+            # MoE routers implemented as nn.Linear subclasses return (logits, weights, ids) tuples: keep their class
+            return False, (module.in_features, module.out_features, None)
         return True, (module.in_features, module.out_features, None)
     cls = type(module).__name__
+    if cls == "Conv1D" and hasattr(module, "nf") and getattr(module, "weight", None) is not None and module.weight.dim() == 2:
+        # GPT-2 style transposed linear: weight [in, out]
+        return True, (module.weight.shape[0], module.weight.shape[1], None)
     if cls in ("ColumnParallelLinear", "RowParallelLinear", "QKVParallelLinear", "MergedColumnParallelLinear",
                "ParallelLMHead"):
         # vLLM tensor-parallel linears: per-partition sizes, TP group only for row-parallel outputs
@@ -224,8 +231,12 @@ def _replace_with_low_bit_linear(model, qtype, modules_to_not_convert=None, conv
                 new_linear = LowBitLinear(in_features, out_features, cur_qtype, module.bias is not None,
                                           mp_group=mp_group, optimize_lm_head=optimize_lm_head,
                                           enable_scale_search=enable_scale_search)
+                src_weight = module.weight.data
+                if type(module).__name__ == "Conv1D":
+                    src_weight = src_weight.t().contiguous() if src_weight.device.type != "meta" else \
+                        torch.empty(out_features, in_features, dtype=src_weight.dtype, device="meta")
                 new_linear._parameters["weight"] = FP4Params(
-                    data=module.weight.data, requires_grad=False, quantized=False, _shape=None,
+                    data=src_weight, requires_grad=False, quantized=False, _shape=None,
                     convert_shape_only=convert_shape_only, qtype=cur_qtype, imatrix=cur_imatrix,
                     in_features=in_features, enable_scale_search=enable_scale_search).to(device)
                 if module.bias is not None:
@@ -235,7 +246,8 @@ def _replace_with_low_bit_linear(model, qtype, modules_to_not_convert=None, conv
                 module.to(dt)
                 new_linear = cls(in_features, out_features, module.bias is not None, mp_group=mp_group,
                                  optimize_lm_head=optimize_lm_head)
-                new_linear._parameters["weight"] = nn.Parameter(module.weight.data, requires_grad=False)
+                dense_w = module.weight.data.t().contiguous() if type(module).__name__ == "Conv1D" else module.weight.data
+                new_linear._parameters["weight"] = nn.Parameter(dense_w, requires_grad=False)
                 if module.bias is not None:
                     new_linear._parameters["bias"] = nn.Parameter(module.bias.data, requires_grad=False)
             if new_linear is not None:

@@ -1,0 +1,89 @@
+"""Breadth check of the module path: tiny random-init models of the HF families the reference lists
+(python/llm/src/ipex_llm/transformers/convert.py:1301-2025) go through ``optimize_model`` and keep their logits.
+
+Criterion is the reference's own (python/llm/test/inference/test_transformers_api.py:151-169): mean relative
+difference between optimized and original logits below 5 %.  sym_int8 keeps quantization noise out of the way so
+that a wrong rewrite (merged qkv order, transposed Conv1D, replaced router) shows up clearly."""
+import copy
+
+import pytest
+import torch
+from transformers import AutoConfig, AutoModelForCausalLM
+
+from bigdl_amd.optimize import optimize_model
+
+COMMON = dict(vocab_size=320, hidden_size=128, num_hidden_layers=2, num_attention_heads=4, max_position_embeddings=256)
+FAMILIES = {
+    "llama": dict(intermediate_size=256, num_key_value_heads=2),
+    "mistral": dict(intermediate_size=256, num_key_value_heads=2),
+    "qwen2": dict(intermediate_size=256, num_key_value_heads=2),
+    "qwen3": dict(intermediate_size=256, num_key_value_heads=2, head_dim=32),
+    "gemma": dict(intermediate_size=256, num_key_value_heads=2, head_dim=32),
+    "gemma2": dict(intermediate_size=256, num_key_value_heads=2, head_dim=32),
+    "phi": dict(intermediate_size=256),
+    "phi3": dict(intermediate_size=256, num_key_value_heads=2, pad_token_id=0),
+    "stablelm": dict(intermediate_size=256, num_key_value_heads=2),
+    "starcoder2": dict(intermediate_size=256, num_key_value_heads=2),
+    "gpt2": dict(n_embd=128, n_layer=2, n_head=4, n_positions=256),
+    "gpt_neox": dict(intermediate_size=256),
+    "gpt_bigcode": dict(n_embd=128, n_layer=2, n_head=4, n_positions=256),
+    "gptj": dict(n_embd=128, n_layer=2, n_head=4, n_positions=256, rotary_dim=16),
+    "bloom": dict(n_head=4, n_layer=2),
+    "mpt": dict(d_model=128, n_heads=4, n_layers=2, max_seq_len=256),
+    "falcon": dict(),
+    "glm": dict(intermediate_size=256, num_key_value_heads=2, head_dim=32, pad_token_id=0),
+    "glm4": dict(intermediate_size=256, num_key_value_heads=2, head_dim=32, pad_token_id=0),
+    "minicpm3": dict(intermediate_size=256, num_key_value_heads=4, q_lora_rank=32, kv_lora_rank=16, qk_nope_head_dim=16,
+                     qk_rope_head_dim=16, v_head_dim=16),
+    "cohere": dict(intermediate_size=256),
+    "granite": dict(intermediate_size=256, num_key_value_heads=2),
+    "phimoe": dict(intermediate_size=128, num_key_value_heads=2, num_local_experts=4),
+    "deepseek_v2": dict(intermediate_size=256, moe_intermediate_size=64, num_key_value_heads=4, n_routed_experts=4,
+                        n_shared_experts=1, q_lora_rank=32, kv_lora_rank=16, qk_nope_head_dim=16, qk_rope_head_dim=16,
+                        v_head_dim=16, first_k_dense_replace=1, num_experts_per_tok=2),
+}
+
+
+def _rel(a, b):
+    return ((a - b).abs().mean() / b.abs().mean()).item()
+
+
+@pytest.mark.parametrize("family", sorted(FAMILIES))
+def test_causal_lm_family_keeps_logits(family):
+    torch.manual_seed(0)
+    cfg = AutoConfig.for_model(family, **{**COMMON, **FAMILIES[family]})
+    model = AutoModelForCausalLM.from_config(cfg).eval().float()
+    ids = torch.randint(0, 320, (2, 9))        # <= 10 positions: the lm_head keeps every position
+    with torch.no_grad():
+        ref = model(ids).logits.float()
+        q = optimize_model(copy.deepcopy(model), low_bit="sym_int8")
+        out = q(ids).logits.float()
+        gen = q.generate(ids[:1], max_new_tokens=3, do_sample=False)
+    n_low = sum(1 for m in q.modules() if type(m).__name__ in ("LowBitLinear", "LowBitExperts"))
+    assert n_low >= 2 * cfg.num_hidden_layers, "projections were not converted"
+    assert _rel(out, ref) < 0.05
+    assert gen.shape == (1, 12)
+
+
+def test_bert_encoder_and_whisper_seq2seq():
+    from transformers import BertConfig, BertModel, WhisperConfig, WhisperForConditionalGeneration
+    torch.manual_seed(0)
+    bert = BertModel(BertConfig(vocab_size=320, hidden_size=128, num_hidden_layers=2, num_attention_heads=4,
+                                intermediate_size=256, max_position_embeddings=64)).eval()
+    ids = torch.randint(0, 320, (2, 16))
+    with torch.no_grad():
+        ref = bert(ids).last_hidden_state
+        out = optimize_model(copy.deepcopy(bert), low_bit="sym_int8")(ids).last_hidden_state
+    assert _rel(out, ref) < 0.05
+    wcfg = WhisperConfig(vocab_size=320, d_model=128, encoder_layers=2, decoder_layers=2, encoder_attention_heads=4,
+                         decoder_attention_heads=4, encoder_ffn_dim=256, decoder_ffn_dim=256, num_mel_bins=16,
+                         max_source_positions=32, max_target_positions=32, pad_token_id=0, bos_token_id=1, eos_token_id=2,
+                         decoder_start_token_id=1)
+    wh = WhisperForConditionalGeneration(wcfg).eval()
+    feats = torch.randn(1, 16, 64)
+    dec = torch.randint(3, 320, (1, 6))
+    with torch.no_grad():
+        ref = wh(input_features=feats, decoder_input_ids=dec).logits
+        q = optimize_model(copy.deepcopy(wh), low_bit="sym_int8")
+        out = q(input_features=feats, decoder_input_ids=dec).logits
+    assert _rel(out, ref) < 0.05
