@@ -1,0 +1,493 @@
+"""Decoder families that HuggingFace only ships as remote code, served by the native engine.
+
+The reference optimizes these by rebinding the forwards of the checkpoints' own ``modeling_*.py``
+(python/llm/src/ipex_llm/transformers/models/{chatglm2,chatglm4,baichuan,qwen,internlm,minicpm,aquila}.py, bound in
+convert.py:1301-2025), which needs ``trust_remote_code`` and the files next to the weights.  Here a family is a
+*weight-name map*: its checkpoint tensors are renamed / re-split into one canonical llama-like state dict plus a
+``DecoderConfig`` that switches on what the family needs (qkv bias, partial or interleaved rotary, multi-query groups,
+embedding / residual / logit scales).  The canonical form is then either quantized into the native engine (GPU) or
+run by the plain PyTorch forward in this file (CPU; also the numerics reference of the tests).  No remote code runs.
+
+Canonical tensor names (all ``[out, in]`` like nn.Linear):
+``embed``, ``final_norm``, ``lm_head``, and per layer ``L{i}.input_norm``, ``L{i}.qkv`` (+ ``.bias``; rows q | k | v),
+``L{i}.o`` (+ ``.bias``), ``L{i}.post_norm``, ``L{i}.gate``, ``L{i}.up``, ``L{i}.down``.
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+from typing import Callable, Dict, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from .. import qtypes as Q
+from .decoder import DecoderConfig, compute_inv_freq
+
+StateDict = Dict[str, torch.Tensor]
+
+
+def _get(cfg: dict, *names, default=None):
+    for n in names:
+        if n in cfg and cfg[n] is not None:
+            return cfg[n]
+    return default
+
+
+# ------------------------------------------------------------------------------------------------
+# family converters: (config dict, checkpoint state dict) -> (DecoderConfig, canonical state dict)
+# ------------------------------------------------------------------------------------------------
+def _llama_keys(cfg: dict, sd: StateDict, dc: DecoderConfig, *, qkv: Optional[str] = None, o_scale=1.0, down_scale=1.0):
+    """Checkpoints that already use llama's module names (baichuan-7B with a packed W_pack, internlm, minicpm,
+    aquila, yi)."""
+    out = {"embed": sd["model.embed_tokens.weight"], "final_norm": sd["model.norm.weight"]}
+    out["lm_head"] = sd.get("lm_head.weight", out["embed"])
+    for i in range(dc.num_layers):
+        p = f"model.layers.{i}."
+        if qkv is not None:
+            out[f"L{i}.qkv"] = sd[p + f"self_attn.{qkv}.weight"]
+            if p + f"self_attn.{qkv}.bias" in sd:
+                out[f"L{i}.qkv.bias"] = sd[p + f"self_attn.{qkv}.bias"]
+        else:
+            out[f"L{i}.qkv"] = torch.cat([sd[p + f"self_attn.{n}_proj.weight"] for n in "qkv"], 0)
+            if p + "self_attn.q_proj.bias" in sd:
+                out[f"L{i}.qkv.bias"] = torch.cat([sd[p + f"self_attn.{n}_proj.bias"] for n in "qkv"], 0)
+        out[f"L{i}.o"] = sd[p + "self_attn.o_proj.weight"] * o_scale
+        if p + "self_attn.o_proj.bias" in sd:
+            out[f"L{i}.o.bias"] = sd[p + "self_attn.o_proj.bias"] * o_scale
+        out[f"L{i}.input_norm"] = sd[p + "input_layernorm.weight"]
+        out[f"L{i}.post_norm"] = sd[p + "post_attention_layernorm.weight"]
+        out[f"L{i}.gate"] = sd[p + "mlp.gate_proj.weight"]
+        out[f"L{i}.up"] = sd[p + "mlp.up_proj.weight"]
+        out[f"L{i}.down"] = sd[p + "mlp.down_proj.weight"] * down_scale
+    return out
+
+
+def _base_config(cfg: dict, model_type: str, **over) -> DecoderConfig:
+    heads = _get(cfg, "num_attention_heads", "n_head")
+    hidden = _get(cfg, "hidden_size", "n_embd")
+    kw = dict(vocab_size=_get(cfg, "vocab_size", "padded_vocab_size"), hidden_size=hidden,
+              intermediate_size=_get(cfg, "intermediate_size", "ffn_hidden_size", default=0),
+              num_layers=_get(cfg, "num_hidden_layers", "num_layers", "n_layer"), num_heads=heads,
+              num_kv_heads=_get(cfg, "num_key_value_heads", default=heads),
+              head_dim=_get(cfg, "head_dim", "kv_channels", default=hidden // heads),
+              rms_eps=_get(cfg, "rms_norm_eps", "layernorm_epsilon", "layer_norm_epsilon", default=1e-6),
+              rope_theta=float(_get(cfg, "rope_theta", "rotary_emb_base", default=10000.0)),
+              rope_scaling=_get(cfg, "rope_scaling"),
+              max_position=_get(cfg, "max_position_embeddings", "seq_length", "model_max_length", default=4096),
+              tie_word_embeddings=bool(_get(cfg, "tie_word_embeddings", default=False)), model_type=model_type)
+    kw.update(over)
+    return DecoderConfig(**kw)
+
+
+def convert_chatglm(cfg: dict, sd: StateDict):
+    """ChatGLM2 / ChatGLM3 / GLM-4 (``model_type: chatglm`` with RMSNorm; reference models/chatglm2.py, chatglm4.py).
+    Rotary embedding on the first half of each head, interleaved pairs; multi-query groups; qkv bias; the MLP's
+    ``dense_h_to_4h`` holds gate and up stacked."""
+    if not _get(cfg, "rmsnorm", default=True) or _get(cfg, "position_encoding_2d", default=False):
+        raise NotImplementedError("ChatGLM-6B (v1: LayerNorm, 2-D rotary, GELU) is not covered by the native engine")
+    heads = cfg["num_attention_heads"]
+    d = _get(cfg, "kv_channels", default=cfg["hidden_size"] // heads)
+    mqa = bool(_get(cfg, "multi_query_attention", default=False))
+    nkv = _get(cfg, "multi_query_group_num", default=heads) if mqa else heads
+    dc = _base_config(cfg, "chatglm", num_kv_heads=nkv, head_dim=d, rot_dim=d // 2, rope_interleaved=True,
+                      rope_theta=10000.0 * float(_get(cfg, "rope_ratio", default=1.0)),
+                      intermediate_size=cfg["ffn_hidden_size"], vocab_size=_get(cfg, "padded_vocab_size", "vocab_size"))
+    ffn = dc.intermediate_size
+    out = {"embed": sd["transformer.embedding.word_embeddings.weight"],
+           "final_norm": sd["transformer.encoder.final_layernorm.weight"],
+           "lm_head": sd["transformer.output_layer.weight"]}
+    for i in range(dc.num_layers):
+        p = f"transformer.encoder.layers.{i}."
+        w = sd[p + "self_attention.query_key_value.weight"]
+        b = sd.get(p + "self_attention.query_key_value.bias")
+        if not mqa:
+            # [heads, (q, k, v), d] per head -> q | k | v
+            w = w.view(heads, 3, d, -1).transpose(0, 1).reshape(3 * heads * d, -1)
+            b = None if b is None else b.view(heads, 3, d).transpose(0, 1).reshape(-1)
+        out[f"L{i}.qkv"] = w
+        if b is not None:
+            out[f"L{i}.qkv.bias"] = b
+        out[f"L{i}.o"] = sd[p + "self_attention.dense.weight"]
+        out[f"L{i}.input_norm"] = sd[p + "input_layernorm.weight"]
+        out[f"L{i}.post_norm"] = sd[p + "post_attention_layernorm.weight"]
+        h4 = sd[p + "mlp.dense_h_to_4h.weight"]
+        out[f"L{i}.gate"], out[f"L{i}.up"] = h4[:ffn], h4[ffn:]
+        out[f"L{i}.down"] = sd[p + "mlp.dense_4h_to_h.weight"]
+    return dc, out
+
+
+def convert_baichuan(cfg: dict, sd: StateDict):
+    """Baichuan-7B / Baichuan2-7B (reference models/baichuan.py:206-286): llama with a packed ``W_pack``; Baichuan2's
+    ``NormHead`` normalizes the lm_head rows at inference, folded into the weight here (reference
+    convert.py:909-923).  The 13B models use ALiBi instead of rotary embeddings."""
+    if _get(cfg, "hidden_size") == 5120 or "max_position_embeddings" not in cfg:
+        raise NotImplementedError("Baichuan-13B (ALiBi attention) is not covered by the native engine")
+    dc = _base_config(cfg, "baichuan")
+    out = _llama_keys(cfg, sd, dc, qkv="W_pack")
+    if cfg.get("vocab_size", 0) >= 125696:           # Baichuan2 vocabulary: NormHead
+        out["lm_head"] = F.normalize(out["lm_head"].float(), dim=-1).to(out["lm_head"].dtype)
+    return dc, out
+
+
+def convert_qwen(cfg: dict, sd: StateDict):
+    """Qwen (v1) 1.8B-72B (reference models/qwen.py): packed ``c_attn`` with bias, RMSNorm, ``c_proj(w1(x) * silu(w2(x)))``."""
+    dc = _base_config(cfg, "qwen", intermediate_size=cfg["intermediate_size"] // 2,
+                      head_dim=_get(cfg, "kv_channels", default=cfg["hidden_size"] // cfg["num_attention_heads"]))
+    out = {"embed": sd["transformer.wte.weight"], "final_norm": sd["transformer.ln_f.weight"], "lm_head": sd["lm_head.weight"]}
+    for i in range(dc.num_layers):
+        p = f"transformer.h.{i}."
+        out[f"L{i}.qkv"] = sd[p + "attn.c_attn.weight"]
+        out[f"L{i}.qkv.bias"] = sd[p + "attn.c_attn.bias"]
+        out[f"L{i}.o"] = sd[p + "attn.c_proj.weight"]
+        out[f"L{i}.input_norm"] = sd[p + "ln_1.weight"]
+        out[f"L{i}.post_norm"] = sd[p + "ln_2.weight"]
+        out[f"L{i}.gate"] = sd[p + "mlp.w2.weight"]
+        out[f"L{i}.up"] = sd[p + "mlp.w1.weight"]
+        out[f"L{i}.down"] = sd[p + "mlp.c_proj.weight"]
+    return dc, out
+
+
+def convert_internlm(cfg: dict, sd: StateDict):
+    """InternLM (v1; reference models/internlm.py:56-113): llama with biases on q/k/v/o."""
+    dc = _base_config(cfg, "internlm")
+    return dc, _llama_keys(cfg, sd, dc)
+
+
+def convert_internlm2(cfg: dict, sd: StateDict):
+    """InternLM2 (reference models/internlm.py:116-183): ``wqkv`` stores, per key/value head, its group of query
+    heads followed by the key and the value head."""
+    dc = _base_config(cfg, "internlm2")
+    hq, hkv, d = dc.num_heads, dc.num_kv_heads, dc.head_dim
+    g = hq // hkv
+    out = {"embed": sd["model.tok_embeddings.weight"], "final_norm": sd["model.norm.weight"], "lm_head": sd["output.weight"]}
+    for i in range(dc.num_layers):
+        p = f"model.layers.{i}."
+        w = sd[p + "attention.wqkv.weight"].view(hkv, g + 2, d, -1)
+        out[f"L{i}.qkv"] = torch.cat([w[:, :g].reshape(hq * d, -1), w[:, g].reshape(hkv * d, -1), w[:, g + 1].reshape(hkv * d, -1)], 0)
+        if p + "attention.wqkv.bias" in sd:
+            b = sd[p + "attention.wqkv.bias"].view(hkv, g + 2, d)
+            out[f"L{i}.qkv.bias"] = torch.cat([b[:, :g].reshape(-1), b[:, g].reshape(-1), b[:, g + 1].reshape(-1)], 0)
+        out[f"L{i}.o"] = sd[p + "attention.wo.weight"]
+        out[f"L{i}.input_norm"] = sd[p + "attention_norm.weight"]
+        out[f"L{i}.post_norm"] = sd[p + "ffn_norm.weight"]
+        out[f"L{i}.gate"] = sd[p + "feed_forward.w1.weight"]
+        out[f"L{i}.up"] = sd[p + "feed_forward.w3.weight"]
+        out[f"L{i}.down"] = sd[p + "feed_forward.w2.weight"]
+    return dc, out
+
+
+def convert_minicpm(cfg: dict, sd: StateDict):
+    """MiniCPM 1B/2B (reference models/minicpm.py:58-66 ``apply_residual_scale``): llama with an embedding scale, a
+    residual scale ``scale_depth / sqrt(layers)`` (folded into o_proj / down_proj) and logits divided by
+    ``hidden / dim_model_base``."""
+    dc = _base_config(cfg, "minicpm", tie_word_embeddings=True)
+    dc.embed_scale = float(_get(cfg, "scale_emb", default=1.0))
+    dc.logit_scale = float(_get(cfg, "dim_model_base", default=dc.hidden_size)) / dc.hidden_size
+    rs = float(_get(cfg, "scale_depth", default=1.0)) / math.sqrt(dc.num_layers)
+    return dc, _llama_keys(cfg, sd, dc, o_scale=rs, down_scale=rs)
+
+
+def convert_llama_like(cfg: dict, sd: StateDict):
+    """Aquila / Aquila2, Yi and other checkpoints that use llama's tensor names under another ``model_type``
+    (reference models/aquila.py)."""
+    dc = _base_config(cfg, cfg.get("model_type", "llama"))
+    return dc, _llama_keys(cfg, sd, dc)
+
+
+ARCH_CONVERTERS: Dict[str, Callable[[dict, StateDict], Tuple[DecoderConfig, StateDict]]] = {
+    "chatglm": convert_chatglm, "baichuan": convert_baichuan, "qwen": convert_qwen, "internlm": convert_internlm,
+    "internlm2": convert_internlm2, "minicpm": convert_minicpm, "aquila": convert_llama_like, "yi": convert_llama_like,
+}
+
+
+# ------------------------------------------------------------------------------------------------
+# plain PyTorch forward over the canonical form (CPU path and test oracle)
+# ------------------------------------------------------------------------------------------------
+def _rope(x, pos, inv_freq, rot, interleaved, scaling):
+    """x [B, H, S, D]; rotary on the first ``rot`` features (half-split or interleaved pairs)."""
+    ang = pos[:, None].float() * inv_freq[None].float()                 # [S, rot/2]
+    cos, sin = ang.cos() * scaling, ang.sin() * scaling
+    xr, xp = x[..., :rot], x[..., rot:]
+    if interleaved:
+        x0, x1 = xr[..., 0::2], xr[..., 1::2]
+        r = torch.stack([x0 * cos - x1 * sin, x1 * cos + x0 * sin], -1).flatten(-2)
+    else:
+        x0, x1 = xr[..., : rot // 2], xr[..., rot // 2:]
+        r = torch.cat([x0 * cos - x1 * sin, x1 * cos + x0 * sin], -1)
+    return torch.cat([r, xp], -1)
+
+
+_ACTS = {"silu": F.silu, "swish": F.silu, "gelu": F.gelu, "relu": F.relu,
+         "gelu_pytorch_tanh": lambda x: F.gelu(x, approximate="tanh"), "gelu_tanh": lambda x: F.gelu(x, approximate="tanh"),
+         "gelu_new": lambda x: F.gelu(x, approximate="tanh")}
+
+
+@torch.no_grad()
+def reference_forward(dc: DecoderConfig, sd: StateDict, ids: torch.Tensor, past=None, linear=None):
+    """Logits [B, S, V] (fp32) and the updated KV list.  ``linear(name, x)`` may replace the dense products (the CPU
+    low-bit path plugs its quantized matmul in here); ``past`` is a list of (k, v) per layer."""
+    def lin(name, x):
+        if linear is not None:
+            return linear(name, x)
+        y = x @ sd[name].float().t()
+        b = sd.get(name + ".bias")
+        return y if b is None else y + b.float()
+
+    def norm(x, w):
+        return x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + dc.rms_eps) * (w.float() + dc.norm_offset)
+
+    b, s = ids.shape
+    hq, hkv, d = dc.num_heads, dc.num_kv_heads, dc.head_dim
+    rot = dc.rot_dim or d
+    inv, scaling = compute_inv_freq(dc)
+    p0 = 0 if not past else past[0][0].shape[2]
+    pos = torch.arange(p0, p0 + s)
+    h = sd["embed"][ids].float() * dc.embed_scale
+    act = _ACTS[dc.act]
+    scale = dc.attn_scale if dc.attn_scale is not None else 1.0 / math.sqrt(d)
+    new_past = []
+    for i in range(dc.num_layers):
+        x = norm(h, sd[f"L{i}.input_norm"])
+        qkv = lin(f"L{i}.qkv", x)
+        q = qkv[..., : hq * d].view(b, s, hq, d).transpose(1, 2)
+        k = qkv[..., hq * d:(hq + hkv) * d].view(b, s, hkv, d).transpose(1, 2)
+        v = qkv[..., (hq + hkv) * d:].view(b, s, hkv, d).transpose(1, 2)
+        q, k = _rope(q, pos, inv, rot, dc.rope_interleaved, scaling), _rope(k, pos, inv, rot, dc.rope_interleaved, scaling)
+        if past:
+            k, v = torch.cat([past[i][0], k], 2), torch.cat([past[i][1], v], 2)
+        new_past.append((k, v))
+        kk, vv = k.repeat_interleave(hq // hkv, 1), v.repeat_interleave(hq // hkv, 1)
+        sc = q @ kk.transpose(-1, -2) * scale
+        L = k.shape[2]
+        mask = torch.arange(L)[None] > (p0 + torch.arange(s))[:, None]
+        sc = sc.masked_fill(mask, float("-inf"))
+        a = (torch.softmax(sc, -1) @ vv).transpose(1, 2).reshape(b, s, hq * d)
+        h = h + lin(f"L{i}.o", a)
+        x = norm(h, sd[f"L{i}.post_norm"])
+        h = h + lin(f"L{i}.down", act(lin(f"L{i}.gate", x)) * lin(f"L{i}.up", x))
+    logits = lin("lm_head", norm(h, sd["final_norm"])) * dc.logit_scale
+    return logits, new_past
+
+
+# ------------------------------------------------------------------------------------------------
+# canonical form -> engine / CPU model
+# ------------------------------------------------------------------------------------------------
+LINEAR_SUFFIXES = (".qkv", ".o", ".gate", ".up", ".down")
+
+
+def quantize_canonical(sd: StateDict, qtype: int, lm_head_qtype: Optional[int] = None):
+    """Quantize the linears of a canonical state dict into ``FP4Params`` (host layout); norms / embedding / biases
+    stay dense.  Rows whose in_features do not fit the block size stay dense fp16."""
+    from ..transformers.low_bit_linear import FP4Params
+    out = {}
+    for name, t in sd.items():
+        is_lin = name.endswith(LINEAR_SUFFIXES) or name == "lm_head"
+        qt = (lm_head_qtype or qtype) if name == "lm_head" else qtype
+        if is_lin and qt not in (Q.FP16, Q.BF16) and t.shape[1] % 64 == 0:
+            out[name] = FP4Params(t.detach().float().contiguous(), requires_grad=False, quantized=False, _shape=None,
+                                  qtype=qt, in_features=t.shape[1]).to("cpu")
+        else:
+            out[name] = t.detach().to(torch.float16)
+    return out
+
+
+def build_engine(dc: DecoderConfig, qsd: dict, device="cuda"):
+    """Canonical (quantized) tensors -> ``NativeDecoder`` on ``device``."""
+    from ..transformers.low_bit_linear import FP4Params
+    from .decoder import LayerWeights, Lin, NativeDecoder
+    dev = torch.device(device)
+
+    def lin(name):
+        w = qsd[name]
+        w = w.to(dev) if isinstance(w, FP4Params) else w.to(dev, torch.float16)
+        b = qsd.get(name + ".bias")
+        return Lin(w, None if b is None else b.to(dev))
+
+    def vec(name):
+        return qsd[name].to(dev, torch.float16).contiguous()
+
+    layers = [LayerWeights(input_norm=vec(f"L{i}.input_norm"), qkv=lin(f"L{i}.qkv"), o=lin(f"L{i}.o"),
+                           post_norm=vec(f"L{i}.post_norm"), gate=lin(f"L{i}.gate"), up=lin(f"L{i}.up"),
+                           down=lin(f"L{i}.down")) for i in range(dc.num_layers)]
+    return NativeDecoder(dc, vec("embed"), layers, vec("final_norm"), lin("lm_head"), device=dev)
+
+
+class NativeCausalLM:
+    """A remote-code family loaded without its remote code: canonical low-bit tensors + ``DecoderConfig``.
+    ``.to("cuda")`` builds the hipGraph engine; on the CPU ``generate`` runs the plain forward over the quantized
+    matmul.  ``save_low_bit`` / ``load_low_bit`` keep the canonical tensors (host block layout) and the config."""
+
+    def __init__(self, dc: DecoderConfig, qsd: dict, low_bit: str, source_config: Optional[dict] = None):
+        self.dc, self.qsd, self.low_bit = dc, qsd, low_bit
+        self.source_config = source_config or {}
+        self.engine = None
+        self.device = torch.device("cpu")
+        self.first_cost = self.rest_cost_mean = self.peak_memory = 0.0
+
+    # -- construction
+    @classmethod
+    def from_state_dict(cls, cfg: dict, sd: StateDict, low_bit="sym_int4"):
+        mt = cfg.get("model_type")
+        if mt not in ARCH_CONVERTERS:
+            raise ValueError(f"no native weight map for model_type {mt!r}")
+        dc, canon = ARCH_CONVERTERS[mt](cfg, sd)
+        return cls(dc, quantize_canonical(canon, Q.ggml_tensor_qtype[low_bit]), low_bit, cfg)
+
+    @classmethod
+    def from_pretrained(cls, path: str, low_bit="sym_int4"):
+        cfg = json.load(open(os.path.join(path, "config.json")))
+        return cls.from_state_dict(cfg, load_checkpoint_tensors(path), low_bit)
+
+    # -- device
+    def to(self, device):
+        device = torch.device(device)
+        if device.type == "cuda":
+            self.engine = build_engine(self.dc, self.qsd, device)
+        else:
+            self.engine = None
+        self.device = device
+        return self
+
+    def half(self):
+        return self
+
+    def eval(self):
+        return self
+
+    # -- inference
+    def _cpu_linear(self, name, x):
+        from ..transformers.low_bit_linear import FP4Params, lowbit_matmul
+        w = self.qsd[name]
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        y = lowbit_matmul(x2, w, w._shape[0]) if isinstance(w, FP4Params) else x2 @ w.float().t()
+        b = self.qsd.get(name + ".bias")
+        if b is not None:
+            y = y + b.float()
+        return y.view(*shp[:-1], -1)
+
+    @torch.no_grad()
+    def __call__(self, input_ids, past_key_values=None):
+        if self.engine is not None:
+            eng = self.engine
+            eng.ensure_cache(input_ids.shape[0], input_ids.shape[1] + 1)
+            eng.cache.reset()
+            return eng.prefill(input_ids.to(self.device), last_only=False), None
+        return reference_forward(self.dc, self.qsd, input_ids, past_key_values, linear=self._cpu_linear)
+
+    @torch.no_grad()
+    def generate(self, input_ids, max_new_tokens=32, do_sample=False, eos_token_id=None, **kw):
+        if self.engine is not None:
+            from ..transformers.utils import use_quantize_kv_cache
+            out = self.engine.generate(input_ids, max_new_tokens=max_new_tokens, do_sample=do_sample,
+                                       eos_token_id=eos_token_id, kv_fp8=use_quantize_kv_cache(), **kw)
+            self.first_cost, self.rest_cost_mean = self.engine.first_cost, self.engine.rest_cost_mean
+            self.peak_memory = self.engine.peak_memory
+            return out
+        eos = set([eos_token_id] if isinstance(eos_token_id, int) else (eos_token_id or []))
+        ids, past, cur = input_ids, None, input_ids
+        for _ in range(max_new_tokens):
+            logits, past = self(cur, past)
+            nxt = logits[:, -1].argmax(-1, keepdim=True)
+            ids = torch.cat([ids, nxt], 1)
+            cur = nxt
+            if eos and all(int(t) in eos for t in nxt.view(-1)):
+                break
+        return ids
+
+    # -- checkpoint
+    def save_low_bit(self, path: str):
+        from ..transformers.low_bit_linear import FP4Params
+        os.makedirs(path, exist_ok=True)
+        tensors, meta = {}, {}
+        for name, t in self.qsd.items():
+            if isinstance(t, FP4Params):
+                data = t.data if t.data.device.type == "cpu" else t.to("cpu").data
+                tensors[name] = data.view(torch.uint8) if data.dtype != torch.uint8 else data
+                meta[name] = {"qtype": Q.qtype_name(t.qtype), "shape": list(t._shape)}
+            else:
+                tensors[name] = t.cpu()
+        torch.save(tensors, os.path.join(path, "pytorch_model.bin"))
+        cfg = dict(self.source_config)
+        cfg["bigdl_transformers_low_bit"] = self.low_bit
+        cfg["bigdl_native_arch"] = {"quantized": meta}
+        json.dump(cfg, open(os.path.join(path, "config.json"), "w"), indent=1)
+        json.dump({"all_checkpoint_keys": sorted(tensors)}, open(os.path.join(path, "load_keys.json"), "w"))
+
+    @classmethod
+    def load_low_bit(cls, path: str):
+        from ..transformers.low_bit_linear import FP4Params
+        cfg = json.load(open(os.path.join(path, "config.json")))
+        if "bigdl_native_arch" not in cfg:
+            raise ValueError(f"{path} is not a native-architecture low-bit checkpoint")
+        meta = cfg.pop("bigdl_native_arch")["quantized"]
+        low_bit = cfg.pop("bigdl_transformers_low_bit")
+        tensors = torch.load(os.path.join(path, "pytorch_model.bin"), weights_only=True)
+        dc = arch_config_only(cfg)
+        qsd = {}
+        for name, t in tensors.items():
+            if name in meta:
+                qsd[name] = FP4Params(t, requires_grad=False, quantized=True, _shape=tuple(meta[name]["shape"]),
+                                      qtype=Q.ggml_tensor_qtype[meta[name]["qtype"]])
+            else:
+                qsd[name] = t
+        return cls(dc, qsd, low_bit, cfg)
+
+
+def arch_config_only(cfg: dict) -> DecoderConfig:
+    """DecoderConfig of a family from its config dict alone (the converters only read shapes from the tensors)."""
+    mt = cfg.get("model_type")
+    probe = {"chatglm": _probe_chatglm, "minicpm": _probe_minicpm}.get(mt)
+    if probe is not None:
+        return probe(cfg)
+    if mt == "qwen":
+        return _base_config(cfg, "qwen", intermediate_size=cfg["intermediate_size"] // 2,
+                            head_dim=_get(cfg, "kv_channels", default=cfg["hidden_size"] // cfg["num_attention_heads"]))
+    return _base_config(cfg, mt)
+
+
+def _probe_chatglm(cfg):
+    heads = cfg["num_attention_heads"]
+    d = _get(cfg, "kv_channels", default=cfg["hidden_size"] // heads)
+    mqa = bool(_get(cfg, "multi_query_attention", default=False))
+    return _base_config(cfg, "chatglm", num_kv_heads=_get(cfg, "multi_query_group_num", default=heads) if mqa else heads,
+                        head_dim=d, rot_dim=d // 2, rope_interleaved=True,
+                        rope_theta=10000.0 * float(_get(cfg, "rope_ratio", default=1.0)),
+                        intermediate_size=cfg["ffn_hidden_size"], vocab_size=_get(cfg, "padded_vocab_size", "vocab_size"))
+
+
+def _probe_minicpm(cfg):
+    dc = _base_config(cfg, "minicpm", tie_word_embeddings=True)
+    dc.embed_scale = float(_get(cfg, "scale_emb", default=1.0))
+    dc.logit_scale = float(_get(cfg, "dim_model_base", default=dc.hidden_size)) / dc.hidden_size
+    return dc
+
+
+def load_checkpoint_tensors(path: str) -> StateDict:
+    """All tensors of a HF checkpoint directory (safetensors preferred; ``.bin`` shards through the weights-only
+    unpickler)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(path, "*.safetensors")))
+    sd: StateDict = {}
+    if files:
+        from safetensors.torch import load_file
+        for f in files:
+            sd.update(load_file(f))
+        return sd
+    files = sorted(glob.glob(os.path.join(path, "pytorch_model*.bin")))
+    if not files:
+        raise FileNotFoundError(f"no weight files under {path}")
+    for f in files:
+        sd.update(torch.load(f, map_location="cpu", weights_only=True))
+    return sd
+
+
+def is_native_arch(config_dict: dict) -> bool:
+    """True when the checkpoint's model_type has a weight map here and HuggingFace has no built-in class for it."""
+    mt = config_dict.get("model_type")
+    if mt not in ARCH_CONVERTERS:
+        return False
+    from transformers.models.auto.configuration_auto import CONFIG_MAPPING_NAMES
+    return mt not in CONFIG_MAPPING_NAMES

@@ -190,6 +190,14 @@ class _BaseAutoModelClass:
                 invalidInputError(False, "model_hub='modelscope' needs the `modelscope` package")
         config_dict, _ = PretrainedConfig.get_config_dict(pretrained_model_name_or_path)
         bigdl_transformers_low_bit = config_dict.pop("bigdl_transformers_low_bit", False)
+        if not bigdl_transformers_low_bit and isinstance(pretrained_model_name_or_path, str) \
+                and os.path.isdir(pretrained_model_name_or_path):
+            from ..models.arch import NativeCausalLM, is_native_arch
+            if is_native_arch(config_dict):
+                # families HuggingFace only has as remote code (chatglm, baichuan, qwen v1, internlm, minicpm, ...):
+                # loaded through their weight-name map into the native engine, no remote code is executed
+                low_bit = kwargs.get("load_in_low_bit") or "sym_int4"
+                return NativeCausalLM.from_pretrained(pretrained_model_name_or_path, low_bit=low_bit)
         invalidInputError(not bigdl_transformers_low_bit,
                           f"Detected model is a low-bit({bigdl_transformers_low_bit}) model, "
                           f"Please use load_low_bit to load this model.")
@@ -422,6 +430,13 @@ class _BaseAutoModelClass:
         variant = kwargs.pop("variant", None)
         mixed_precision = kwargs.pop("mixed_precision", False)
         config = kwargs.pop("config", None)
+        if config is None and isinstance(pretrained_model_name_or_path, str) and os.path.isfile(
+                os.path.join(pretrained_model_name_or_path, "config.json")):
+            import json
+            with open(os.path.join(pretrained_model_name_or_path, "config.json")) as f:
+                if "bigdl_native_arch" in json.load(f):
+                    from ..models.arch import NativeCausalLM
+                    return NativeCausalLM.load_low_bit(pretrained_model_name_or_path)
         if config is None:
             config = transformers.AutoConfig.from_pretrained(pretrained_model_name_or_path,
                                                             trust_remote_code=trust_remote_code)
