@@ -8,9 +8,15 @@ streamed: for Mixtral-8x7B that is 2/8 of the expert bytes per token.
 Prefill: tokens are sorted by expert on the device and the three expert products run as grouped dequant-fused MFMA
 GEMMs over 64-row blocks (``gemm_lowbit_grouped``); dense (unquantized) experts run one GEMM per non-empty bucket.
 
-Expert parallelism: ``expert_range=(lo, hi)`` keeps a contiguous slice of the experts on this rank; slots routed
-elsewhere produce zero rows and the partial outputs are summed with one all-reduce (every rank holds all tokens
-during decode, so this replaces the dispatch/return all-to-all pair by a single collective of [tokens, hidden]).
+Expert parallelism: ``expert_range=(lo, hi)`` keeps a contiguous slice of the experts on this rank.  Two layouts:
+
+* tokens replicated (tensor-parallel attention next to it, ``ep_mode="allreduce"``): slots routed elsewhere produce zero
+  rows and the partial outputs are summed with one all-reduce of [tokens, hidden];
+* tokens sharded (every rank serves its own sequences with replicated attention, ``ep_mode="a2a"``): prefill
+  dispatches each routed row to the rank that owns its expert with ``all_to_all_single`` (variable splits), runs
+  the grouped GEMM on what arrived and returns the rows the same way; the graph-captured decode step uses the
+  fixed-shape form of the same exchange (all-gather of the step's [batch, hidden] rows, local experts over all of them,
+  reduce-scatter back), because a hipGraph cannot hold data-dependent split sizes.
 
 Reference behaviour: python/llm/src/ipex_llm/transformers/models/mixtral.py:60-130 (``mixtral_moeblock_forward``),
 models/qwen2_moe.py:104-149, models/common.py:339-354 (``moe_group_topk`` / ``moe_softmax_topk``).
@@ -71,6 +77,8 @@ class MoEWeights:
         self.expert_range = expert_range        # (lo, hi) of the experts held locally, None = all
         self.group = group                      # process group for the expert-parallel all-reduce
         self.n_local = num_experts if expert_range is None else expert_range[1] - expert_range[0]
+        self.ep_mode = "allreduce"              # "a2a": tokens are sharded over the expert-parallel ranks
+        self.ep_rank, self.ep_world = 0, 1
 
     # ------------------------------------------------------------------ builders
     @classmethod
@@ -103,7 +111,7 @@ class MoEWeights:
         return cls(router, gate, up, down, qt, dc.num_experts, dc.top_k, dc.hidden_size, dc.moe_intermediate_size,
                    act=act, normalize=normalize, shared=shared, shared_router=shared_router)
 
-    def shard_experts(self, rank: int, world: int, group=None):
+    def shard_experts(self, rank: int, world: int, group=None, mode: str = "allreduce"):
         """Keep experts [rank*E/world, (rank+1)*E/world) (expert parallelism).  T16 buffers are re-sliced plane by
         plane through the dense form once at load time."""
         assert self.num_experts % world == 0, "expert count must divide the expert-parallel degree"
@@ -117,13 +125,28 @@ class MoEWeights:
         else:
             self.gate, self.up, self.down = (t[lo:hi].contiguous() for t in (self.gate, self.up, self.down))
         self.expert_range, self.group, self.n_local = (lo, hi), group, per
+        assert mode in ("allreduce", "a2a")
+        self.ep_mode, self.ep_rank, self.ep_world = mode, rank, world
         return self
 
     # ------------------------------------------------------------------ pieces
-    def route(self, x):
-        from ..ops import hip
-        logits = F.linear(x, self.router)
-        return hip.moe_route(logits, self.top_k, self.normalize, expert_range=self.expert_range)
+    def route(self, x, local_only=True):
+        """-> (expert ids int32 [T, k], weights fp32 [T, k]).  local_only: ids of experts on other ranks become -1
+        and local ones are rebased to this rank's slice."""
+        logits = F.linear(x, self.router.to(x.dtype))
+        rng = self.expert_range if local_only else None
+        if x.device.type == "cuda":
+            from ..ops import hip
+            return hip.moe_route(logits, self.top_k, self.normalize, expert_range=rng)
+        p = torch.softmax(logits.float(), -1)
+        w, ids = torch.topk(p, self.top_k, dim=-1)
+        if self.normalize:
+            w = w / w.sum(-1, keepdim=True)
+        ids = ids.int()
+        if rng is not None:
+            keep = (ids >= rng[0]) & (ids < rng[1])
+            ids = torch.where(keep, ids - rng[0], torch.full_like(ids, -1))
+        return ids, w
 
     def _expert_w(self, which, e, dtype=torch.float16):
         from ..ops import hip
@@ -164,6 +187,11 @@ class MoEWeights:
         from ..ops import hip
         cfg = engine.cfg
         x = hip.rms_norm(h, gamma, cfg.rms_eps, offset=cfg.norm_offset)
+        if self.ep_mode == "a2a" and self.ep_world > 1:
+            y = self.forward_gather_scatter(x)
+            sy, gl = self._shared_out(engine, x)
+            hip.moe_combine(y, 1, h, shared=sy, shared_gate=gl, residual=h)
+            return h
         ids, w = self.route(x)
         m, k = x.shape[0], self.top_k
         if self.fused:
@@ -195,11 +223,82 @@ class MoEWeights:
         scale = (w.view(-1) * (ids.view(-1) >= 0)).to(y.dtype)
         return (y * scale[:, None]).contiguous()
 
+    # ------------------------------------------------------------------ expert FFN over rows with local expert ids
+    def local_ffn(self, x, ids, w):
+        """sum_k w[t, k] * expert_{ids[t, k]}(x[t]) over this rank's experts (ids < 0 contribute nothing) -> [T, H]"""
+        t, k = ids.shape
+        if self.fused and x.device.type == "cuda":
+            return grouped_moe_ffn(x, ids, w, self.gate, self.up, self.down, self.qtype, self.n_local, self.inter,
+                                   self.hidden, self.act, zero_fill=True)
+        from ..models.arch import _ACTS
+        act = _ACTS[self.act]
+        out = torch.zeros_like(x)
+        flat = ids.reshape(-1)
+        wf = w.reshape(-1).to(x.dtype)
+        tok = torch.arange(t, device=x.device).repeat_interleave(k)
+        for e in range(self.n_local):
+            sel = (flat == e).nonzero().squeeze(-1)
+            if sel.numel() == 0:
+                continue
+            xe = x[tok[sel]]
+            g, u, d = (self._expert_w(n, e, x.dtype) for n in ("gate", "up", "down"))
+            out.index_add_(0, tok[sel], F.linear(act(F.linear(xe, g)) * F.linear(xe, u), d) * wf[sel, None])
+        return out
+
+    def forward_a2a(self, x):
+        """Tokens sharded over the expert-parallel group: dispatch routed rows to the owners of their experts,
+        compute there, return them (two ``all_to_all_single`` exchanges of [rows, hidden] with variable splits)."""
+        import torch.distributed as dist
+        t, k = x.shape[0], self.top_k
+        per = self.n_local
+        ids, w = self.route(x, local_only=False)                     # global expert ids
+        flat = ids.reshape(-1).long()
+        dest = torch.div(flat, per, rounding_mode="floor")
+        order = torch.argsort(dest, stable=True)
+        tok = torch.div(order, k, rounding_mode="floor")
+        send_counts = torch.bincount(dest, minlength=self.ep_world)
+        recv_counts = torch.empty_like(send_counts)
+        dist.all_to_all_single(recv_counts, send_counts, group=self.group)
+        send_n, recv_n = send_counts.tolist(), recv_counts.tolist()  # the one host round trip: split sizes
+        send_x = x[tok].contiguous()
+        send_e = (flat[order] % per).int().contiguous()
+        recv_x = x.new_empty((sum(recv_n), x.shape[1]))
+        recv_e = send_e.new_empty((sum(recv_n),))
+        dist.all_to_all_single(recv_x, send_x, recv_n, send_n, group=self.group)
+        dist.all_to_all_single(recv_e, send_e, recv_n, send_n, group=self.group)
+        if recv_x.shape[0]:
+            y = self.local_ffn(recv_x, recv_e.view(-1, 1), torch.ones(recv_e.numel(), 1, device=x.device))
+        else:
+            y = recv_x
+        back = x.new_empty(send_x.shape)
+        dist.all_to_all_single(back, y.contiguous(), send_n, recv_n, group=self.group)
+        out = torch.zeros_like(x)
+        out.index_add_(0, tok, back * w.reshape(-1)[order].to(x.dtype)[:, None])
+        return out
+
+    def forward_gather_scatter(self, x):
+        """Fixed-shape form of the exchange for the graph-captured decode step: every rank contributes the same number
+        of rows; all-gather them, run the local experts over all rows, reduce-scatter the partial sums back."""
+        import torch.distributed as dist
+        allx = x.new_empty((x.shape[0] * self.ep_world, x.shape[1]))
+        dist.all_gather_into_tensor(allx, x.contiguous(), group=self.group)
+        ids, w = self.route(allx, local_only=True)
+        part = self.local_ffn(allx, ids, w)
+        out = torch.empty_like(x)
+        dist.reduce_scatter_tensor(out, part.contiguous(), group=self.group)
+        return out
+
     # ------------------------------------------------------------------ prefill
     def forward_dense(self, x, engine=None):
         """x [T, H] fp16 (already normalized) -> moe(x) [T, H]"""
         from ..ops import hip
         t, k = x.shape[0], self.top_k
+        if self.ep_mode == "a2a" and self.ep_world > 1:
+            out = self.forward_a2a(x)
+            sy, gl = self._shared_out(engine, x)
+            if sy is not None:
+                out = out + (torch.sigmoid(gl.float()).to(sy.dtype) * sy if gl is not None else sy)
+            return out
         ids, w = self.route(x)
         if self.fused and t * k <= 64:
             a = hip.gemv_lowbit_moe(x, self.gate, self.qtype, self.n_local, self.inter, self.hidden, ids.view(-1),

@@ -7,3 +7,5 @@
 * ``data_parallel``    gradient synchronisation for LoRA / QLoRA fine-tuning
 """
 from .comm import all_reduce_, all_reduce_coalesced_, barrier, init_distributed, new_groups, rank, world_size  # noqa: F401
+
+from .expert_parallel import shard_engine_experts  # noqa: E402,F401

@@ -138,3 +138,42 @@ def _comm_worker(rank, port):
 
 def test_groups_and_bucketed_all_reduce():
     _run(_comm_worker)
+
+
+# ------------------------------------------------------------------------------------------------
+def _ep_worker(rank, port):
+    _boot(rank, port)
+    from bigdl_amd import qtypes as Q
+    from bigdl_amd.models.moe import MoEWeights
+    torch.manual_seed(0)                                     # same experts on every rank, then sharded
+    e, k, h, inter = 4, 2, 64, 96
+    router = torch.randn(e, h) * 0.3
+    gate, up, down = torch.randn(e, inter, h) * 0.1, torch.randn(e, inter, h) * 0.1, torch.randn(e, h, inter) * 0.1
+
+    def make():
+        m = MoEWeights(router, gate.clone(), up.clone(), down.clone(), Q.FP16, e, k, h, inter)
+        m.router = router.clone()                            # fp32 on the CPU
+        return m
+    full = make()
+    torch.manual_seed(100)
+    x_all = torch.randn(WORLD * 5, h)                        # 5 tokens per rank
+    ids, w = full.route(x_all, local_only=False)
+    want = full.local_ffn(x_all, ids, w)                     # single-process result for every token
+    mine = x_all[rank * 5:(rank + 1) * 5].contiguous()
+    # tokens sharded: dispatch / return with all_to_all (prefill form), gather / reduce-scatter (decode form)
+    ep = make().shard_experts(rank, WORLD, None, mode="a2a")
+    assert ep.n_local == e // WORLD and ep.gate.shape[0] == e // WORLD
+    torch.testing.assert_close(ep.forward_a2a(mine), want[rank * 5:(rank + 1) * 5], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(ep.forward_gather_scatter(mine), want[rank * 5:(rank + 1) * 5], rtol=1e-4, atol=1e-5)
+    # tokens replicated: partial sums + all-reduce
+    rep = make().shard_experts(rank, WORLD, None, mode="allreduce")
+    ids_l, w_l = rep.route(x_all, local_only=True)
+    part = rep.local_ffn(x_all, ids_l, w_l)
+    dist.all_reduce(part)
+    torch.testing.assert_close(part, want, rtol=1e-4, atol=1e-5)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_expert_parallel_all_to_all_matches_single_process():
+    _run(_ep_worker)
