@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--kv", default="fp8", choices=["fp8", "fp16"])
     ap.add_argument("--model", default="llama2-7b", choices=["llama2-7b", "tinyllama"])
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--prefill-dense-cache", action="store_true",
+                    help="keep fp16 copies of the weights for prefill GEMMs (off in the headline number)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -48,6 +50,9 @@ def main():
     qt = Q.ggml_tensor_qtype[args.low_bit]
     model = build_random_decoder(cfg, qt, device=f"cuda:{local_rank}", seed=1234)
     model.use_graph = not args.no_graph
+    if args.prefill_dense_cache:
+        from bigdl_amd.models.decoder import Lin
+        Lin.cache_dense = True
     g = torch.Generator().manual_seed(rank)
     prompt = torch.randint(3, cfg.vocab_size, (1, args.in_len), generator=g).cuda()
 
@@ -89,7 +94,7 @@ def main():
             "config": {"model": "Llama-2-7B (random-init)" if args.model == "llama2-7b" else "TinyLlama-1.1B (random-init)",
                        "low_bit": args.low_bit, "global_batch": world, "seq_len": args.in_len,
                        "new_tokens": args.out_len, "parallelism": f"dp{world}" if world > 1 else "single",
-                       "hip_graph": not args.no_graph}}))
+                       "hip_graph": not args.no_graph, "prefill_dense_cache": bool(args.prefill_dense_cache)}}))
     if dist_on:
         dist.destroy_process_group()
 

@@ -333,11 +333,15 @@ __global__ __launch_bounds__(256) void prefill_rope_append_kernel(PrefillRopeArg
   // ---- V: [tokens, D] -> V^T rows ----
   const int hv = head - a.Hq - a.Hkv;
   const int TS = D + 8;
+  // the transposed read below walks 8 token rows per thread with the token group (tc) varying fastest across lanes:
+  // rows 8 apart are a multiple of 32 banks apart, so the 16-byte chunk index is XOR-ed with the token group to
+  // spread the 8 groups over all banks (needs the chunk count to be a multiple of 8)
+  const int swz = (CH & 7) == 0 ? 7 : 0;
   for (int it = threadIdx.x; it < PR_TOK * CH; it += 256) {
     const int tl = it / CH, c = it % CH, t = t0 + tl;
     half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
     if (t < a.S) v = *(const half8*)(base + (int64_t)t * a.ld + 8 * c);
-    *(half8*)(tile + tl * TS + 8 * c) = v;
+    *(half8*)(tile + tl * TS + 8 * (c ^ ((tl >> 3) & swz))) = v;
   }
   __syncthreads();
   const int ntok = min(PR_TOK, a.S - t0);
@@ -347,7 +351,7 @@ __global__ __launch_bounds__(256) void prefill_rope_append_kernel(PrefillRopeArg
     if (8 * tc >= ntok) continue;
     half8 v;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = tile[(8 * tc + e) * TS + d];
+    for (int e = 0; e < 8; ++e) v[e] = tile[(8 * tc + e) * TS + (((d >> 3) ^ (tc & swz)) << 3) + (d & 7)];
     const int64_t row = ((int64_t)b * a.Hkv + hv) * D + d;
     const int key = a.past + t0 + 8 * tc;
     const bool full = 8 * tc + 8 <= ntok;
