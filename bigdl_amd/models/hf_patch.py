@@ -17,6 +17,7 @@ here are generic:
 from __future__ import annotations
 
 import logging
+import os
 import sys
 import types
 
@@ -231,6 +232,92 @@ def _native_attention(module, q, k, v, attention_mask, kwargs):
     from ..ops import hip
     softcap = getattr(module, "attn_logit_softcapping", None) or 0.0
     return hip.attn_prefill(q, k, v, scale=module.scaling, causal=mask is None, mask=mask, softcap=softcap)
+
+
+HIP_ATTENTION = "bigdl_hip"
+
+
+def hip_attention_interface(module, query, key, value, attention_mask, dropout=0.0, scaling=None, is_causal=None, **kwargs):
+    """Entry in HuggingFace's attention-function registry (``config._attn_implementation = "bigdl_hip"``): every
+    architecture that dispatches through that registry (gpt2, gpt_neox, falcon, phi, starcoder2, opt, whisper, bert,
+    ... next to the llama-layout ones) reaches the MFMA flash-attention kernel without a per-family forward -- the
+    reference rebinds one attention forward per family instead (python/llm/src/ipex_llm/transformers/models/
+    {gpt2,gptneox,phi,starcoder2,whisper,bert}.py).  Cases the kernel does not cover fall through to PyTorch SDPA."""
+    from transformers.integrations.sdpa_attention import sdpa_attention_forward
+    d = query.shape[-1]
+    ok = (_is_cuda(query) and query.dtype == torch.float16 and not torch.is_grad_enabled() and d in (64, 128)
+          and not module.training and not dropout and kwargs.get("position_bias") is None
+          and query.dim() == 4 and key.shape[1] > 0 and query.shape[1] % key.shape[1] == 0)
+    if ok:
+        sq, lk = query.shape[2], key.shape[2]
+        causal = attention_mask is None and sq > 1 and (is_causal if is_causal is not None else getattr(module, "is_causal", True))
+        if attention_mask is None and sq > 1 and not causal and sq != lk and getattr(module, "is_causal", False):
+            ok = False
+    if ok:
+        class _Shim:                      # what _native_attention reads from the attention module
+            pass
+        shim = _Shim()
+        shim.scaling = scaling if scaling is not None else d ** -0.5
+        shim.attn_logit_softcapping = kwargs.get("softcap", getattr(module, "attn_logit_softcapping", None))
+        shim.training = False
+        q, k, v = query, key, value
+        fix = lambda t: t if (t.stride(-1) == 1 and all(t.stride(i) % 8 == 0 for i in (0, 1, 2))) else t.contiguous()  # noqa: E731
+        mask = attention_mask
+        if mask is None and not causal:
+            out = _native_attention_call(fix(q), fix(k), fix(v), shim, None, causal=False)
+        else:
+            out = _native_attention(shim, fix(q), fix(k), fix(v), mask, {})
+        if out is not None:
+            return out.view(query.shape[0], query.shape[2], query.shape[1], d), None
+    return sdpa_attention_forward(module, query, key, value, attention_mask, dropout=dropout, scaling=scaling,
+                                  is_causal=is_causal, **kwargs)
+
+
+def _native_attention_call(q, k, v, shim, mask, causal):
+    from ..ops import hip
+    return hip.attn_prefill(q, k, v, scale=shim.scaling, causal=causal, mask=mask, softcap=shim.attn_logit_softcapping or 0.0)
+
+
+def register_hip_attention(model):
+    """Register the kernel in HF's attention registry and select it for ``model`` (and nested configs)."""
+    try:
+        from transformers.modeling_utils import ALL_ATTENTION_FUNCTIONS
+        from transformers.masking_utils import ALL_MASK_ATTENTION_FUNCTIONS
+    except ImportError:
+        return False
+    if HIP_ATTENTION not in ALL_ATTENTION_FUNCTIONS:
+        ALL_ATTENTION_FUNCTIONS.register(HIP_ATTENTION, hip_attention_interface)
+        # masks are built as for SDPA: None for pure causal, additive / boolean [B, 1, Sq, Lk] otherwise
+        ALL_MASK_ATTENTION_FUNCTIONS.register(HIP_ATTENTION, ALL_MASK_ATTENTION_FUNCTIONS["sdpa"])
+    done = False
+    for m in model.modules():
+        cfg = getattr(m, "config", None)
+        if cfg is not None and getattr(cfg, "_attn_implementation", None) in ("sdpa", "eager", None) \
+                and _dispatches_through_registry(type(m)):
+            try:
+                cfg._attn_implementation = HIP_ATTENTION
+                done = True
+            except Exception:
+                pass
+    return done
+
+
+_REGISTRY_DISPATCH = {}
+
+
+def _dispatches_through_registry(cls) -> bool:
+    """True when the modeling file of ``cls`` picks its attention through ALL_ATTENTION_FUNCTIONS only; files that
+    compare ``_attn_implementation`` with fixed names (falcon, bloom-style manual attention) keep their own choice."""
+    mod = sys.modules.get(cls.__module__)
+    if mod not in _REGISTRY_DISPATCH:
+        try:
+            import inspect
+            src = inspect.getsource(mod)
+            _REGISTRY_DISPATCH[mod] = "ALL_ATTENTION_FUNCTIONS" in src and "_attn_implementation ==" not in src \
+                and "_attn_implementation !=" not in src
+        except Exception:
+            _REGISTRY_DISPATCH[mod] = False
+    return _REGISTRY_DISPATCH[mod]
 
 
 # ------------------------------------------------------------------------------------------------
@@ -475,6 +562,8 @@ def optimize_post(model):
             and any(hasattr(getattr(l, "self_attn", None), "_merged_sizes") for l in base.layers):
         base.register_forward_pre_hook(kv_cache_pre_hook, with_kwargs=True)
         object.__setattr__(base, "_kv_hook_installed", True)
+    if os.environ.get("BIGDL_HIP_ATTENTION", "1") != "0":
+        register_hip_attention(model)
     install_generate_front_door(model)
     return model
 
