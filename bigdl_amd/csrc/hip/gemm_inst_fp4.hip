@@ -2,5 +2,5 @@
 // formats compile in parallel).
 #include "gemm_kernel.h"
 namespace bigdl {
-int gemm_launch_fp4(const GemmArgs& a, int bm, int mblocks, hipStream_t st) { return gemm_launch_qt<Q_FP4>(a, bm, mblocks, st); }
+int gemm_launch_fp4(const GemmArgs& a, int bm, int bn, int mblocks, hipStream_t st) { return gemm_launch_qt<Q_FP4>(a, bm, bn, mblocks, st); }
 }  // namespace bigdl

@@ -40,9 +40,9 @@ struct GemmArgs {
   int n_total;             // rows of the stacked weight buffer
 };
 
-template <int QT, int MT>
+// MT = 16-row tiles of x per workgroup, NT = 16-column weight tiles per wavefront (4 wavefronts side by side)
+template <int QT, int MT, int NT>
 __global__ __launch_bounds__(256, 2) void gemm_t16_kernel(GemmArgs a) {
-  constexpr int NT = 2;            // 16-column weight tiles per wavefront
   constexpr int BM = MT * 16;
   constexpr int BN = 4 * NT * 16;  // 4 wavefronts side by side along N
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -102,20 +102,22 @@ __global__ __launch_bounds__(256, 2) void gemm_t16_kernel(GemmArgs a) {
     }
   }
   const int swz = ((sslot ^ srow) & 15) << 4;   // (16 p + srow) & 15 == srow
-  uint4v areg[MT];
-  auto gload_a = [&](int kt) {
+  // x tiles travel global -> registers -> LDS two k-tiles ahead of their use: tile t sits in register set t & 1
+  // from iteration t - 2 and is written to LDS stage t & 1 at the end of iteration t - 1
+  uint4v areg[2][MT];
+  auto gload_a = [&](uint4v (&dst)[MT], int kt) {
     const int k = kt * 128 + sslot * 8;
 #pragma unroll
     for (int p = 0; p < MT; ++p) {
       uint4v v = {0, 0, 0, 0};
       if (xsrc[p] != ~0u && k < a.K) v = *(const uint4v*)(a.x + xsrc[p] + kt * 128);
-      areg[p] = v;
+      dst[p] = v;
     }
   };
-  auto store_a = [&](int stage) {
+  auto store_a = [&](uint4v (&src)[MT], int stage) {
     char* base = As + stage * BM * 256 + srow * 256 + swz;
 #pragma unroll
-    for (int p = 0; p < MT; ++p) *(uint4v*)(base + p * 16 * 256) = areg[p];
+    for (int p = 0; p < MT; ++p) *(uint4v*)(base + p * 16 * 256) = src[p];
   };
 
   float4v acc[MT][NT];
@@ -124,22 +126,25 @@ __global__ __launch_bounds__(256, 2) void gemm_t16_kernel(GemmArgs a) {
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[j][n] = float4v{0, 0, 0, 0};
 
-  Tile<QT> ta[NT], tb[NT];
-  auto fetch_b = [&](Tile<QT> (&tt)[NT], int kt) {
+  // weight tiles: a ring of DEPTH k-tiles per wavefront in flight (HBM latency under load is several k-tiles of
+  // MFMA work at small M; one tile of look-ahead left the MFMA pipe waiting on vmcnt)
+  constexpr int DEPTH = 4;
+  Tile<QT> tt[DEPTH][NT];
+  auto fetch_b = [&](Tile<QT> (&t)[NT], int kt) {
 #pragma unroll
-    for (int n = 0; n < NT; ++n) load_tile<QT>(tt[n], pl, tbase[n] + kt, lane);
+    for (int n = 0; n < NT; ++n) load_tile<QT>(t[n], pl, tbase[n] + kt, lane);
   };
-  auto compute = [&](Tile<QT> (&tt)[NT], int stage) {
+  auto compute = [&](Tile<QT> (&t)[NT], int stage) {
     const char* abase = As + stage * BM * 256 + r * 256;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       half8 bf[NT];
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
-        const half8 code = decode_step<QT>(tt[n], s, lut);
-        _Float16 d = tt[n].d[s];
+        const half8 code = decode_step<QT>(t[n], s, lut);
+        _Float16 d = t[n].d[s];
         if constexpr (post_scale<QT>() != 1.0f) d = (_Float16)fminf((float)d * post_scale<QT>(), 65504.0f);
-        if constexpr (has_min<QT>()) bf[n] = code * d + tt[n].m[s];
+        if constexpr (has_min<QT>()) bf[n] = code * d + t[n].m[s];
         else bf[n] = code * d;
       }
       const int aoff = (((4 * s + g) ^ r) & 15) << 4;
@@ -153,23 +158,24 @@ __global__ __launch_bounds__(256, 2) void gemm_t16_kernel(GemmArgs a) {
   };
 
   // prologue
-  gload_a(kt0);
-  fetch_b(ta, kt0);
-  store_a(0);
+  gload_a(areg[0], kt0);
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d)
+    if (kt0 + d < kt1) fetch_b(tt[d], kt0 + d);
+  store_a(areg[0], 0);
+  if (kt0 + 1 < kt1) gload_a(areg[1], kt0 + 1);
   __syncthreads();
-  for (int kt = kt0; kt < kt1; kt += 2) {
-    // even step: compute stage 0 with ta, prefetch kt + 1 into stage 1 / tb
-    const bool more1 = kt + 1 < kt1;
-    if (more1) { gload_a(kt + 1); fetch_b(tb, kt + 1); }
-    compute(ta, 0);
-    if (more1) store_a(1);
-    __syncthreads();
-    if (!more1) break;
-    const bool more2 = kt + 2 < kt1;
-    if (more2) { gload_a(kt + 2); fetch_b(ta, kt + 2); }
-    compute(tb, 1);
-    if (more2) store_a(0);
-    __syncthreads();
+  for (int kt = kt0; kt < kt1; kt += DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      const int k = kt + d;                 // block-uniform
+      if (k >= kt1) break;
+      if (k + 2 < kt1) gload_a(areg[d & 1], k + 2);      // (k - kt0) & 1 == d & 1: DEPTH is even
+      compute(tt[d], d & 1);
+      if (k + DEPTH < kt1) fetch_b(tt[d], k + DEPTH);
+      if (k + 1 < kt1) store_a(areg[(d + 1) & 1], (d + 1) & 1);
+      __syncthreads();
+    }
   }
 
   // epilogue
@@ -210,26 +216,31 @@ __global__ __launch_bounds__(256, 2) void gemm_t16_kernel(GemmArgs a) {
   }
 }
 
-template <int QT, int MT>
+template <int QT, int MT, int NT>
 static int gemm_launch_mt(const GemmArgs& a, int mblocks, hipStream_t st) {
   constexpr int BM = MT * 16;
   const size_t lds = 2 * BM * 256 + (QT == Q_NF4 ? 64 * 16 * 2 : 0);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm_t16_kernel<QT, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)gemm_t16_kernel<QT, MT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return -101;
     attr_set = true;
   }
-  const int nblocks = (a.N + 127) / 128;
+  const int bn = 64 * NT;
+  const int nblocks = (a.N + bn - 1) / bn;
   const dim3 grid(nblocks * a.splitk, mblocks);
-  hipLaunchKernelGGL((gemm_t16_kernel<QT, MT>), grid, dim3(256), lds, st, a);
+  hipLaunchKernelGGL((gemm_t16_kernel<QT, MT, NT>), grid, dim3(256), lds, st, a);
   return HIP_CHECK_LAUNCH();
 }
 
+// bm: rows per block (64 / 128); bn: columns per block (128).  64-column blocks and 32-row blocks were measured too
+// (more workgroups streaming weights at few rows): slower or equal on every Llama-2-7B projection shape.
 template <int QT>
-static int gemm_launch_qt(const GemmArgs& a, int bm, int mblocks, hipStream_t st) {
-  if (bm == 64) return gemm_launch_mt<QT, 4>(a, mblocks, st);
-  return gemm_launch_mt<QT, 8>(a, mblocks, st);
+static int gemm_launch_qt(const GemmArgs& a, int bm, int bn, int mblocks, hipStream_t st) {
+  if (bn != 128) return -4;
+  if (bm == 64) return gemm_launch_mt<QT, 4, 2>(a, mblocks, st);
+  if (bm == 128) return gemm_launch_mt<QT, 8, 2>(a, mblocks, st);
+  return -4;
 }
 
 }  // namespace bigdl

@@ -5,17 +5,17 @@
 #include <stdlib.h>
 
 namespace bigdl {
-int gemm_launch_sym_int4(const GemmArgs& a, int bm, int mblocks, hipStream_t st);
-int gemm_launch_asym_int4(const GemmArgs& a, int bm, int mblocks, hipStream_t st);
-int gemm_launch_woq_int4(const GemmArgs& a, int bm, int mblocks, hipStream_t st);
-int gemm_launch_fp4(const GemmArgs& a, int bm, int mblocks, hipStream_t st);
-int gemm_launch_nf4(const GemmArgs& a, int bm, int mblocks, hipStream_t st);
-int gemm_launch_sym_int5(const GemmArgs& a, int bm, int mblocks, hipStream_t st);
-int gemm_launch_asym_int5(const GemmArgs& a, int bm, int mblocks, hipStream_t st);
-int gemm_launch_fp6(const GemmArgs& a, int bm, int mblocks, hipStream_t st);
-int gemm_launch_sym_int8(const GemmArgs& a, int bm, int mblocks, hipStream_t st);
-int gemm_launch_fp8_e4m3(const GemmArgs& a, int bm, int mblocks, hipStream_t st);
-int gemm_launch_fp8_e5m2(const GemmArgs& a, int bm, int mblocks, hipStream_t st);
+int gemm_launch_sym_int4(const GemmArgs& a, int bm, int bn, int mblocks, hipStream_t st);
+int gemm_launch_asym_int4(const GemmArgs& a, int bm, int bn, int mblocks, hipStream_t st);
+int gemm_launch_woq_int4(const GemmArgs& a, int bm, int bn, int mblocks, hipStream_t st);
+int gemm_launch_fp4(const GemmArgs& a, int bm, int bn, int mblocks, hipStream_t st);
+int gemm_launch_nf4(const GemmArgs& a, int bm, int bn, int mblocks, hipStream_t st);
+int gemm_launch_sym_int5(const GemmArgs& a, int bm, int bn, int mblocks, hipStream_t st);
+int gemm_launch_asym_int5(const GemmArgs& a, int bm, int bn, int mblocks, hipStream_t st);
+int gemm_launch_fp6(const GemmArgs& a, int bm, int bn, int mblocks, hipStream_t st);
+int gemm_launch_sym_int8(const GemmArgs& a, int bm, int bn, int mblocks, hipStream_t st);
+int gemm_launch_fp8_e4m3(const GemmArgs& a, int bm, int bn, int mblocks, hipStream_t st);
+int gemm_launch_fp8_e5m2(const GemmArgs& a, int bm, int bn, int mblocks, hipStream_t st);
 
 // out[m][n] = epilogue(sum_s partial[s][m][n])
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs a) {
@@ -64,26 +64,26 @@ __global__ void moe_block_table_kernel(const int64_t* counts, int n_experts, int
 
 using namespace bigdl;
 
-static int dispatch(const GemmArgs& a, int qtype, int bm, int mblocks, hipStream_t st) {
+static int dispatch(const GemmArgs& a, int qtype, int bm, int bn, int mblocks, hipStream_t st) {
   switch (qtype) {
-    case Q_SYM_INT4: return gemm_launch_sym_int4(a, bm, mblocks, st);
-    case Q_ASYM_INT4: return gemm_launch_asym_int4(a, bm, mblocks, st);
-    case Q_WOQ_INT4: return gemm_launch_woq_int4(a, bm, mblocks, st);
-    case Q_FP4: return gemm_launch_fp4(a, bm, mblocks, st);
-    case Q_NF4: return gemm_launch_nf4(a, bm, mblocks, st);
-    case Q_SYM_INT5: return gemm_launch_sym_int5(a, bm, mblocks, st);
-    case Q_ASYM_INT5: return gemm_launch_asym_int5(a, bm, mblocks, st);
-    case Q_FP6: return gemm_launch_fp6(a, bm, mblocks, st);
-    case Q_SYM_INT8: return gemm_launch_sym_int8(a, bm, mblocks, st);
-    case Q_FP8_E4M3: return gemm_launch_fp8_e4m3(a, bm, mblocks, st);
-    case Q_FP8_E5M2: return gemm_launch_fp8_e5m2(a, bm, mblocks, st);
+    case Q_SYM_INT4: return gemm_launch_sym_int4(a, bm, bn, mblocks, st);
+    case Q_ASYM_INT4: return gemm_launch_asym_int4(a, bm, bn, mblocks, st);
+    case Q_WOQ_INT4: return gemm_launch_woq_int4(a, bm, bn, mblocks, st);
+    case Q_FP4: return gemm_launch_fp4(a, bm, bn, mblocks, st);
+    case Q_NF4: return gemm_launch_nf4(a, bm, bn, mblocks, st);
+    case Q_SYM_INT5: return gemm_launch_sym_int5(a, bm, bn, mblocks, st);
+    case Q_ASYM_INT5: return gemm_launch_asym_int5(a, bm, bn, mblocks, st);
+    case Q_FP6: return gemm_launch_fp6(a, bm, bn, mblocks, st);
+    case Q_SYM_INT8: return gemm_launch_sym_int8(a, bm, bn, mblocks, st);
+    case Q_FP8_E4M3: return gemm_launch_fp8_e4m3(a, bm, bn, mblocks, st);
+    case Q_FP8_E5M2: return gemm_launch_fp8_e5m2(a, bm, bn, mblocks, st);
     default: return -2;
   }
 }
 
-static void plan(int mblocks, int N, int K, int* splitk, int* kt_per_split) {
+static void plan(int mblocks, int bn, int N, int K, int* splitk, int* kt_per_split) {
   const int KT = (K + 127) / 128;
-  const int blocks = ((N + 127) / 128) * mblocks;
+  const int blocks = ((N + bn - 1) / bn) * mblocks;
   int sk = 1;
   static const int target = getenv("BIGDL_GEMM_TARGET") ? atoi(getenv("BIGDL_GEMM_TARGET")) : 256;
   if (blocks < target * 3 / 4) sk = (target + blocks - 1) / blocks;
@@ -96,9 +96,16 @@ static void plan(int mblocks, int N, int K, int* splitk, int* kt_per_split) {
 
 // Number of K splits the launch below will use for this shape (the caller provides splitk * M * N floats of
 // workspace when it is > 1).  mblocks: number of row blocks (dense: ceil(M / bm)).
-extern "C" int bigdl_gemm_lowbit_splitk(int mblocks, int N, int K) {
+extern "C" int bigdl_gemm_lowbit_bm(int M);
+static int pick_bn(int M) {
+  (void)M;
+  return 128;
+}
+
+extern "C" int bigdl_gemm_lowbit_splitk(int M, int N, int K) {
   int sk, per;
-  plan(mblocks, N, K, &sk, &per);
+  const int bm = bigdl_gemm_lowbit_bm(M);
+  plan((M + bm - 1) / bm, pick_bn(M), N, K, &sk, &per);
   return sk;
 }
 
@@ -121,10 +128,11 @@ extern "C" int bigdl_gemm_lowbit(const void* x, const void* w, void* out, const 
   a.x = (const _Float16*)x; a.w = w; a.out = out; a.bias = bias; a.residual = residual; a.partial = workspace;
   a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldo = ldo; a.act = act; a.out_type = out_type;
   const int bm = bigdl_gemm_lowbit_bm(M);
+  const int bn = pick_bn(M);
   const int mblocks = (M + bm - 1) / bm;
-  plan(mblocks, N, K, &a.splitk, &a.kt_per_split);
+  plan(mblocks, bn, N, K, &a.splitk, &a.kt_per_split);
   if (a.splitk > 1 && (workspace == nullptr || workspace_floats < (int64_t)a.splitk * M * N)) return -5;
-  const int rc = dispatch(a, qtype, bm, mblocks, stream);
+  const int rc = dispatch(a, qtype, bm, bn, mblocks, stream);
   if (rc != 0 || a.splitk == 1) return rc;
   const int64_t total = (int64_t)M * N;
   hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
@@ -151,7 +159,7 @@ extern "C" int bigdl_gemm_lowbit_grouped(const void* x, const void* w, void* out
   a.out_type = out_type; a.splitk = 1; a.kt_per_split = (K + 127) / 128;
   a.blk_expert = blk_expert; a.blk_row0 = blk_row0; a.blk_rows = blk_rows; a.x_rows = x_rows; a.row_scale = row_scale;
   a.n_total = n_experts * N;
-  return dispatch(a, qtype, bm, max_blocks, stream);
+  return dispatch(a, qtype, bm, 128, max_blocks, stream);
 }
 
 extern "C" int bigdl_moe_block_table(const int64_t* counts, int n_experts, int bm, int max_blocks, int* blk_expert,

@@ -222,8 +222,7 @@ def gemm_lowbit(x, w, qtype, out_features, in_features, *, bias=None, residual=N
                                  or residual.stride() != out.stride()):
         raise ValueError("residual must match out")
     L = lib()
-    bm = L.bigdl_gemm_lowbit_bm(m)
-    sk = L.bigdl_gemm_lowbit_splitk((m + bm - 1) // bm, out_features, k)
+    sk = L.bigdl_gemm_lowbit_splitk(m, out_features, k)
     ws, ws_n = None, 0
     if sk > 1:
         ws_n = sk * m * out_features
