@@ -241,6 +241,7 @@ class NativeDecoder:
         # row-parallel projections are all-reduced over this group
         self.tp_group = None
         self.tp_world = 1
+        self.tp_fast_allreduce = None   # parallel/xgmi_allreduce.py ``OneShotAllReduce`` (opt-in)
         # timing attributes with the reference's names (utils/benchmark_util_4_47.py:3372-3393)
         self.first_cost = self.rest_cost_mean = self.encoder_time = self.peak_memory = 0.0
         self.first_token_time = 0.0
@@ -280,7 +281,10 @@ class NativeDecoder:
 
     def _tp_reduce(self, t):
         if self.tp_group is not None:
-            torch.distributed.all_reduce(t, group=self.tp_group)
+            if self.tp_fast_allreduce is not None and self.tp_fast_allreduce.usable(t):
+                self.tp_fast_allreduce(t)          # one kernel launch over IPC-mapped peer buffers (graph-capturable)
+            else:
+                torch.distributed.all_reduce(t, group=self.tp_group)
         return t
 
     def _norm(self, x, w, residual=None, res_out=None):

@@ -229,9 +229,11 @@ def _concat_t16(bufs, qtype, rows, k):
     return torch.cat([x for pl in planes for x in pl]).contiguous()
 
 
-def shard_engine(engine, rank: int, world: int, group=None):
+def shard_engine(engine, rank: int, world: int, group=None, fast_allreduce=None):
     """Tensor-parallel view of a ``NativeDecoder``: attention heads and MLP columns are split over ``world`` ranks,
-    the engine all-reduces after o_proj and down_proj (see ``NativeDecoder.tp_group``)."""
+    the engine all-reduces after o_proj and down_proj (see ``NativeDecoder.tp_group``).  ``fast_allreduce=True`` (or
+    ``BIGDL_XGMI_ALLREDUCE=1``) routes the decode-sized all-reduces through the one-shot IPC kernel
+    (``parallel/xgmi_allreduce.py``) instead of RCCL."""
     import dataclasses
     if world == 1:
         return engine
@@ -252,6 +254,12 @@ def shard_engine(engine, rank: int, world: int, group=None):
                                      intermediate_size=cfg.intermediate_size // world)
     engine.tp_group = group if group is not None else dist.group.WORLD
     engine.tp_world = world
+    if fast_allreduce is None:
+        import os
+        fast_allreduce = os.environ.get("BIGDL_XGMI_ALLREDUCE") == "1"
+    if fast_allreduce and engine.device.type == "cuda":
+        from .xgmi_allreduce import OneShotAllReduce
+        engine.tp_fast_allreduce = OneShotAllReduce(engine.tp_group, device=engine.device)
     engine.cache = None
     engine._graphs.clear()
     engine._static.clear()

@@ -1,0 +1,104 @@
+"""One-shot all-reduce over IPC-mapped peer buffers (kernel: ``csrc/hip/allreduce_xgmi.hip``) for the small,
+latency-bound all-reduces of a tensor-parallel decode step.
+
+Every rank allocates one fine-grained device buffer, the ranks exchange ``hipIpcMemHandle``s through the (RCCL or
+gloo) process group, and each call is a single kernel launch on the current stream -- capturable into the decode
+hipGraph, because the call counter lives in device memory.  Ranks must sit in one node (xGMI / same host); anything
+else, other dtypes or larger messages fall back to ``torch.distributed.all_reduce``.
+
+Opt-in (``BIGDL_XGMI_ALLREDUCE=1`` or ``shard_engine(..., fast_allreduce=True)``): the kernel is verified with two
+processes sharing one GPU (``tests/test_allreduce_gpu.py``); the default for multi-GPU runs stays RCCL.
+"""
+from __future__ import annotations
+
+import ctypes
+import socket
+
+import torch
+import torch.distributed as dist
+
+from ..ops import hip
+
+DEFAULT_MAX_BYTES = 256 * 1024
+
+
+class OneShotAllReduce:
+    def __init__(self, group=None, max_bytes: int = DEFAULT_MAX_BYTES, device=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.max_bytes = (max_bytes + 63) // 64 * 64
+        hosts = [None] * self.world
+        dist.all_gather_object(hosts, socket.gethostname(), group=group)
+        if len(set(hosts)) != 1:
+            raise RuntimeError("one-shot all-reduce needs all ranks in one node")
+        if self.world > 16:
+            raise RuntimeError("one-shot all-reduce supports at most 16 ranks")
+        L = self.lib = hip.lib()
+        L.bigdl_ar_buffer_bytes.restype = ctypes.c_int64
+        L.bigdl_ar_buffer_bytes.argtypes = [ctypes.c_int, ctypes.c_int64]
+        L.bigdl_ar_alloc.argtypes = [ctypes.c_int64, ctypes.POINTER(ctypes.c_void_p)]
+        L.bigdl_ar_free.argtypes = [ctypes.c_void_p]
+        L.bigdl_ar_ipc_handle.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
+        L.bigdl_ar_ipc_open.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p)]
+        L.bigdl_ar_ipc_close.argtypes = [ctypes.c_void_p]
+        L.bigdl_allreduce_oneshot.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                              ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        with torch.cuda.device(self.device):
+            nbytes = L.bigdl_ar_buffer_bytes(self.world, self.max_bytes)
+            own = ctypes.c_void_p()
+            if L.bigdl_ar_alloc(nbytes, ctypes.byref(own)) != 0:
+                raise RuntimeError("fine-grained buffer allocation failed")
+            self._own = own
+            handle = ctypes.create_string_buffer(64)
+            if L.bigdl_ar_ipc_handle(own, handle) != 0:
+                raise RuntimeError("hipIpcGetMemHandle failed")
+            handles = [None] * self.world
+            dist.all_gather_object(handles, handle.raw, group=group)
+            self._opened = []
+            ptrs = []
+            for r, h in enumerate(handles):
+                if r == self.rank:
+                    ptrs.append(own.value)
+                    continue
+                p = ctypes.c_void_p()
+                if L.bigdl_ar_ipc_open(h, ctypes.byref(p)) != 0:
+                    raise RuntimeError(f"hipIpcOpenMemHandle failed for rank {r}")
+                self._opened.append(p)
+                ptrs.append(p.value)
+            self._peers = (ctypes.c_int64 * self.world)(*ptrs)
+            self.epoch = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self.error = torch.zeros(1, dtype=torch.int32, device=self.device)
+        dist.barrier(group=group)          # every buffer is mapped everywhere before the first call
+
+    def usable(self, t: torch.Tensor) -> bool:
+        return (t.device.type == "cuda" and t.dtype == torch.float16 and t.is_contiguous() and t.numel() % 8 == 0
+                and t.numel() * 2 <= self.max_bytes and t.data_ptr() % 16 == 0)
+
+    def all_reduce(self, t: torch.Tensor) -> torch.Tensor:
+        """In-place sum over the group."""
+        if not self.usable(t):
+            dist.all_reduce(t, group=self.group)
+            return t
+        rc = self.lib.bigdl_allreduce_oneshot(self._peers, self.rank, self.world, t.data_ptr(), t.data_ptr(), t.numel(),
+                                              self.max_bytes, self.epoch.data_ptr(), self.error.data_ptr(),
+                                              torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            raise RuntimeError(f"allreduce_oneshot: native launcher rejected the call (code {rc})")
+        return t
+
+    __call__ = all_reduce
+
+    def check(self):
+        """Raise if a call gave up waiting for a peer (synchronises the device)."""
+        if int(self.error.item()) != 0:
+            raise RuntimeError("one-shot all-reduce: a peer did not publish its data in time")
+
+    def close(self):
+        for p in getattr(self, "_opened", []):
+            self.lib.bigdl_ar_ipc_close(p)
+        self._opened = []
+        if getattr(self, "_own", None) is not None:
+            self.lib.bigdl_ar_free(self._own)
+            self._own = None
