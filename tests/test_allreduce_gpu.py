@@ -70,3 +70,43 @@ def test_one_shot_all_reduce_two_processes_one_gpu(tmp_path):
     mp.spawn(_worker, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
     for r in range(WORLD):
         assert int(torch.load(tmp_path / f"ok{r}.pt")) == WORLD
+
+
+def _tp_engine_worker(rank, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    from bigdl_amd import qtypes as Q
+    from bigdl_amd.models.decoder import DecoderConfig, build_random_decoder
+    from bigdl_amd.parallel.tensor_parallel import shard_engine
+    cfg = DecoderConfig(vocab_size=320, hidden_size=256, intermediate_size=512, num_layers=2, num_heads=4, num_kv_heads=2,
+                        head_dim=64, max_position=512)
+    ids = torch.randint(3, 320, (1, 20), generator=torch.Generator().manual_seed(0)).cuda()
+    full = build_random_decoder(cfg, Q.SYM_INT4, device="cuda", seed=3)        # same seed: same weights on both ranks
+    want = full.generate(ids, max_new_tokens=10)
+    full.ensure_cache(1, 64)
+    full.cache.reset()
+    want_logits = full.prefill(ids, last_only=False).float().cpu()
+    tp = shard_engine(build_random_decoder(cfg, Q.SYM_INT4, device="cuda", seed=3), rank, WORLD, fast_allreduce=True)
+    assert tp.tp_fast_allreduce is not None and tp.cfg.num_heads == 2
+    got = tp.generate(ids, max_new_tokens=10)                                  # graph decode with the one-shot all-reduce
+    tp.tp_fast_allreduce.check()
+    tp.cache.reset()
+    got_logits = tp.prefill(ids, last_only=False).float().cpu()
+    rel = ((got_logits - want_logits).abs().mean() / want_logits.abs().mean()).item()
+    ok = rel < 2e-2 and (got == want).float().mean().item() >= 0.8
+    torch.save(torch.tensor([int(ok), int(rel * 1e6)]), os.path.join(out_dir, f"tp{rank}.pt"))
+    dist.barrier()
+    tp.tp_fast_allreduce.close()
+    dist.destroy_process_group()
+
+
+def test_tensor_parallel_engine_two_processes_one_gpu(tmp_path):
+    """TP = 2 native engine (column / row sharded T16 weights, hipGraph decode with the one-shot all-reduce inside)
+    against the unsharded engine."""
+    port = _free_port()
+    mp.spawn(_tp_engine_worker, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
+    for r in range(WORLD):
+        ok, rel = torch.load(tmp_path / f"tp{r}.pt").tolist()
+        assert ok == 1, f"rank {r}: rel diff {rel / 1e6}"
