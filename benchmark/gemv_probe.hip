@@ -16,6 +16,8 @@ static size_t t16_bytes(int n, int k) {   // sym_int4: 4-bit codes + fp16 scale 
 }
 
 int main() {
+  const int M = getenv("PROBE_M") ? atoi(getenv("PROBE_M")) : 1;          // rows of x (1..16)
+  const bool with_norm = getenv("PROBE_NORM") != nullptr;                  // fused RMSNorm prologue as in the decode step
   struct Shape { const char* name; int n, k; bool gate_up; } shapes[] = {
       {"o", 4096, 4096, false}, {"qkv", 12288, 4096, false}, {"down", 4096, 11008, false}, {"gate_up", 11008, 4096, true}};
   hipStream_t st;
@@ -26,10 +28,13 @@ int main() {
     std::vector<void*> ws(copies);
     for (auto& w : ws) { CK(hipMalloc(&w, nb)); CK(hipMemset(w, 0x11, nb)); }
     _Float16 *x, *out;
-    CK(hipMalloc(&x, sh.k * 2)); CK(hipMemset(x, 0, sh.k * 2));
-    CK(hipMalloc(&out, sh.n * 2));
+    CK(hipMalloc(&x, (size_t)M * sh.k * 2)); CK(hipMemset(x, 0, (size_t)M * sh.k * 2));
+    CK(hipMalloc(&out, (size_t)M * sh.n * 2));
+    _Float16* gamma;
+    CK(hipMalloc(&gamma, sh.k * 2)); CK(hipMemset(gamma, 0x3c, sh.k * 2));
     GemvArgs a{};
-    a.x = x; a.out = out; a.M = 1; a.N = sh.n; a.K = sh.k; a.ldx = sh.k; a.ldo = sh.n; a.out_type = OUT_F16; a.att_qlen = 1;
+    a.gamma = with_norm ? gamma : nullptr;
+    a.x = x; a.out = out; a.M = M; a.N = sh.n; a.K = sh.k; a.ldx = sh.k; a.ldo = sh.n; a.out_type = OUT_F16; a.att_qlen = 1;
     a.slot_xdiv = 1; a.eps = 1e-5f;
     auto launch = [&](int i) {
       a.w = ws[i % copies];
@@ -52,8 +57,8 @@ int main() {
       CK(hipEventElapsedTime(&ms, e0, e1));
       if (ms < best) best = ms;
     }
-    printf("{\"probe\": %d, \"shape\": \"%s\", \"us\": %.2f, \"MB\": %.1f}\n", GEMV_PROBE, sh.name, best * 1e3 / iters,
-           nb * (sh.gate_up ? 2 : 1) / 1e6);
+    printf("{\"probe\": %d, \"M\": %d, \"norm\": %d, \"shape\": \"%s\", \"us\": %.2f, \"MB\": %.1f}\n", GEMV_PROBE, M,
+           (int)with_norm, sh.name, best * 1e3 / iters, nb * (sh.gate_up ? 2 : 1) / 1e6);
     for (auto& w : ws) CK(hipFree(w));
     CK(hipFree(x)); CK(hipFree(out));
   }

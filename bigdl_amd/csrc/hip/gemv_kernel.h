@@ -19,6 +19,7 @@
 //    1/rms factor applied to the result), gate/up pair with act(g)*u epilogue, bias, residual add.
 #pragma once
 #include "common.h"
+#include <type_traits>
 
 // Compile-time probe used only by benchmark/gemv_probe.hip to attribute kernel time (0 = production kernel):
 // 1 = return after the workgroup set-up, 2 = first round of loads + x staging + reduce/epilogue (no main loop),
@@ -247,12 +248,60 @@ __global__ __launch_bounds__(NW * 64) void gemv_t16_kernel(GemvArgs a) {
   if constexpr (XLDS) {
     __syncthreads();   // ssq_sh zeroed before the atomics below
     const int vec_per_row = (Kp + XTAIL) >> 3;
+    if (a.att_ws == nullptr) {
+      // Each wavefront stages whole 64-vector segments (one row, 64 x 16 bytes), up to 4 per round, with
+      // UNCONDITIONAL loads from clamped addresses (a load under a per-item condition makes the compiler wait for
+      // each one separately) and no dead slots (a redundant clamped load still costs L2 bandwidth): the loads of
+      // several rows are in flight together instead of one dependent L2 round trip per row (probe: +1.3 us per
+      // extra row of x with the row loop).
+      // rows are cut into segments of 64 vectors (one wavefront load); only [0, K) is loaded, the rest of the LDS
+      // row (padding up to Kp plus the zero tail) is filled without touching memory
+      const int kvec = a.K >> 3;
+      const int chunks = (kvec + 63) >> 6;
+      const int kmax = a.K - 8;
+      const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int i = threadIdx.x; i < a.M * (vec_per_row - kvec); i += GEMV_NW * 64) {
+        const int m = i / (vec_per_row - kvec), v = kvec + i % (vec_per_row - kvec);
+        *(half8*)(xs + m * XS + (v << 3)) = zero8;
+      }
+      // a wavefront owns a column chunk (64 vectors) for all rows: gamma is fetched once per chunk, and the rows of
+      // the chunk are loaded SU at a time
+      auto stage = [&](auto su_tag, int col, half8 g8, int m0) {
+        constexpr int SU = decltype(su_tag)::value;     // rows in flight together, all valid
+        const int cl = min(col, kmax);
+        const bool inside = col < a.K;
+        half8 xv[SU];
+#pragma unroll
+        for (int u = 0; u < SU; ++u) xv[u] = *(const half8*)(a.x + (int64_t)(m0 + u) * a.ldx + cl);
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+          half8 v = inside ? xv[u] : zero8;
+          if (norm) {
+            const float ssq = wave_sum(frag_sumsq(v));
+            if (lane == 0) atomicAdd(&ssq_sh[m0 + u], ssq);
+            v = v * g8;
+          }
+          if (inside) *(half8*)(xs + (m0 + u) * XS + col) = v;
+        }
+      };
+      for (int c = wave; c < chunks; c += GEMV_NW) {
+        const int col = (c * 64 + lane) << 3;
+        half8 g8 = zero8;
+        if (norm) {
+          g8 = *(const half8*)(a.gamma + min(col, kmax));
+          if (a.gamma_offset != 0.0f) g8 = g8 + (_Float16)a.gamma_offset;
+        }
+        int m0 = 0;
+        for (; m0 + 3 < a.M; m0 += 4) stage(std::integral_constant<int, 4>{}, col, g8, m0);
+        for (; m0 + 1 < a.M; m0 += 2) stage(std::integral_constant<int, 2>{}, col, g8, m0);
+        for (; m0 < a.M; ++m0) stage(std::integral_constant<int, 1>{}, col, g8, m0);
+      }
+    } else {
     for (int m = 0; m < a.M; ++m) {
-      float ssq = 0.0f;
       for (int v = threadIdx.x; v < vec_per_row; v += GEMV_NW * 64) {
         const int c = v << 3;
         half8 xv = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (c < a.K && a.att_ws != nullptr) {
+        if (c < a.K) {
           const int hq = c / a.att_D, d = c % a.att_D;
           const int bb = m / a.att_qlen, tok = m % a.att_qlen;
           const int64_t bh = (int64_t)bb * a.att_Hkv + hq / a.att_G;
@@ -273,21 +322,10 @@ __global__ __launch_bounds__(NW * 64) void gemv_t16_kernel(GemvArgs a) {
           const float inv = lt > 0.0f ? 1.0f / lt : 0.0f;
 #pragma unroll
           for (int q = 0; q < 8; ++q) xv[q] = (_Float16)(o8[q] * inv);
-        } else if (c < a.K) {
-          xv = *(const half8*)(a.x + (int64_t)m * a.ldx + c);
-          if (norm) {
-            ssq += frag_sumsq(xv);
-            half8 gm = *(const half8*)(a.gamma + c);
-            if (a.gamma_offset != 0.0f) gm = gm + (_Float16)a.gamma_offset;
-            xv = xv * gm;
-          }
         }
         *(half8*)(xs + m * XS + c) = xv;
       }
-      if (norm) {
-        ssq = wave_sum(ssq);
-        if (lane == 0) atomicAdd(&ssq_sh[m], ssq);
-      }
+    }
     }
   }
   __syncthreads();
@@ -456,6 +494,21 @@ __global__ __launch_bounds__(NW * 64) void gemv_t16_kernel(GemvArgs a) {
 }
 
 constexpr size_t GEMV_XLDS_LIMIT = 48 * 1024;   // stage x in LDS when it fits this budget
+// ... or, for at most 8 rows, this one (K = 11008 down projections at 3-4 rows: 21.5 -> about 12 us per launch; K = 4096
+// at 6-8 rows; decode step 2.22 -> 1.92 ms at batch 4 and 2.98 -> 2.69 ms at batch 8).  With more rows the single
+// workgroup per CU that such a footprint allows loses more than the LDS staging wins (measured at 16 rows).
+constexpr size_t GEMV_XLDS_LIMIT_FEW_ROWS = 100 * 1024;
+
+template <typename KernelT>
+static inline bool gemv_allow_lds(KernelT kernel, size_t bytes) {
+  if (bytes <= 64 * 1024) return true;          // more dynamic LDS has to be requested once per kernel
+  static bool done = false;
+  if (!done) {
+    if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) return false;
+    done = true;
+  }
+  return bytes <= 128 * 1024;
+}
 
 template <int QT, int MT, bool GATE_UP>
 static int launch_x(const GemvArgs& a, hipStream_t st) {
@@ -469,7 +522,8 @@ static int launch_x(const GemvArgs& a, hipStream_t st) {
   if (wide) {
     if constexpr (MT == 1 && !GATE_UP)
       hipLaunchKernelGGL((gemv_t16_kernel<QT, MT, GATE_UP, true, 16>), grid, dim3(1024), fixed(16) + xbytes, st, a);
-  } else if (xbytes <= GEMV_XLDS_LIMIT) {
+  } else if (xbytes <= GEMV_XLDS_LIMIT ||
+             (a.M <= 8 && xbytes <= GEMV_XLDS_LIMIT_FEW_ROWS && gemv_allow_lds(gemv_t16_kernel<QT, MT, GATE_UP, true, 8>, fixed(8) + xbytes))) {
     hipLaunchKernelGGL((gemv_t16_kernel<QT, MT, GATE_UP, true, 8>), grid, dim3(512), fixed(8) + xbytes, st, a);
   } else {
     hipLaunchKernelGGL((gemv_t16_kernel<QT, MT, GATE_UP, false, 8>), grid, dim3(512), fixed(8), st, a);
