@@ -186,11 +186,16 @@ __global__ __launch_bounds__(NW * 64) void gemv_t16_kernel(GemvArgs a) {
   // weight tiles fetched per wavefront per round trip (per stream): 16 B x 64 lanes x 4 = 4 KiB in flight
   constexpr int U = (GATE_UP || NW > 8) ? 2 : 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // carve: red | ssq | lut | x
+  // carve: red | ssq | lut | xsum | x
   float* red = (float*)smem;                                  // [NW][NACC*MT][64][4]
   float* ssq_sh = red + GEMV_NW * NACC * MT * 256;            // [MT*16] sum of squares per row
   _Float16* nf4_lut = (_Float16*)(ssq_sh + MT * 16);          // [64*16] (nf4 only)
-  _Float16* xs = nf4_lut + (QT == Q_NF4 ? 64 * 16 : 0);       // [M][Kp + XTAIL + XPAD]
+  // formats with a block minimum: sum of (scaled) x over every 32-block, [Kp/32 + XTAIL/32][MT*16 rows], so that the
+  // "+ min * sum(x)" term is one 16-byte LDS read per MFMA step instead of a cross-lane reduction of the fragment
+  float* xsum = (float*)(nf4_lut + (QT == Q_NF4 ? 64 * 16 : 0));
+  constexpr bool XSUM = XLDS && has_min<QT>();
+  const int xsum_floats = XSUM ? (((a.K + 127) >> 7) * 4 + XTAIL / 32) * MT * 16 : 0;
+  _Float16* xs = (_Float16*)(xsum + xsum_floats);             // [M][Kp + XTAIL + XPAD]
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -245,8 +250,12 @@ __global__ __launch_bounds__(NW * 64) void gemv_t16_kernel(GemvArgs a) {
     lut = nf4_lut + lane * 16;
   }
   if (threadIdx.x < MT * 16) ssq_sh[threadIdx.x] = 0.0f;
+  if constexpr (XSUM) {
+    const float4v z4 = {0, 0, 0, 0};
+    for (int i = threadIdx.x; i < (xsum_floats >> 2); i += GEMV_NW * 64) *(float4v*)(xsum + 4 * i) = z4;
+  }
   if constexpr (XLDS) {
-    __syncthreads();   // ssq_sh zeroed before the atomics below
+    __syncthreads();   // ssq_sh / xsum zeroed before the atomics and block sums below
     const int vec_per_row = (Kp + XTAIL) >> 3;
     if (a.att_ws == nullptr) {
       // Each wavefront stages whole 64-vector segments (one row, 64 x 16 bytes), up to 4 per round, with
@@ -280,6 +289,12 @@ __global__ __launch_bounds__(NW * 64) void gemv_t16_kernel(GemvArgs a) {
             const float ssq = wave_sum(frag_sumsq(v));
             if (lane == 0) atomicAdd(&ssq_sh[m0 + u], ssq);
             v = v * g8;
+          }
+          if constexpr (XSUM) {
+            float bs = frag_sum(v);                       // 4 consecutive lanes = one 32-block of this row
+            bs += __shfl_xor(bs, 1);
+            bs += __shfl_xor(bs, 2);
+            if (inside && (lane & 3) == 0) xsum[(col >> 5) * (MT * 16) + m0 + u] = bs;
           }
           if (inside) *(half8*)(xs + (m0 + u) * XS + col) = v;
         }
@@ -322,6 +337,12 @@ __global__ __launch_bounds__(NW * 64) void gemv_t16_kernel(GemvArgs a) {
           const float inv = lt > 0.0f ? 1.0f / lt : 0.0f;
 #pragma unroll
           for (int q = 0; q < 8; ++q) xv[q] = (_Float16)(o8[q] * inv);
+        }
+        if constexpr (XSUM) {
+          float bs = frag_sum(xv);
+          bs += __shfl_xor(bs, 1);
+          bs += __shfl_xor(bs, 2);
+          if ((threadIdx.x & 3) == 0) xsum[(c >> 5) * (MT * 16) + m] = bs;
         }
         *(half8*)(xs + m * XS + c) = xv;
       }
@@ -395,7 +416,13 @@ __global__ __launch_bounds__(NW * 64) void gemv_t16_kernel(GemvArgs a) {
             const float4v c1 = mfma16(xa[j], bf, zero4);
             acc[st][j][0] = __builtin_elementwise_fma(float2v{c1[0], c1[1]}, d2, acc[st][j][0]);
             acc[st][j][1] = __builtin_elementwise_fma(float2v{c1[2], c1[3]}, d2, acc[st][j][1]);
-            if constexpr (has_min<QT>()) {
+            if constexpr (XSUM) {
+              // + min * sum_k x[m][k] over the block, block sums precomputed at staging: rows 4g .. 4g+3
+              const float4v x4 = *(const float4v*)(xsum + (ktx * 4 + s) * (MT * 16) + 16 * j + 4 * g);
+              const float mn = (float)t.m[s];
+              acc[st][j][0] = __builtin_elementwise_fma(float2v{x4[0], x4[1]}, float2v{mn, mn}, acc[st][j][0]);
+              acc[st][j][1] = __builtin_elementwise_fma(float2v{x4[2], x4[3]}, float2v{mn, mn}, acc[st][j][1]);
+            } else if constexpr (has_min<QT>()) {
               // + min * sum_k x[m][k] over the block: per-row sums live on lanes (row m = lane&15),
               // the result needs them on (col n = lane&15, rows 4g+q): exchange through the wave
               float sx = frag_sum(xa[j]);
@@ -515,7 +542,10 @@ static int launch_x(const GemvArgs& a, hipStream_t st) {
   const dim3 grid((a.N + 15) / 16, a.slot_expert ? a.n_slots : 1);
   const int Kp = (a.K + 127) / 128 * 128;
   const size_t xbytes = (size_t)a.M * (Kp + XTAIL + XPAD) * 2;
-  auto fixed = [&](int nw) { return (size_t)nw * (GATE_UP ? 2 : 1) * MT * 256 * 4 + MT * 16 * 4 + (QT == Q_NF4 ? 64 * 16 * 2 : 0); };
+  auto fixed = [&](int nw, bool xlds = true) {
+    return (size_t)nw * (GATE_UP ? 2 : 1) * MT * 256 * 4 + MT * 16 * 4 + (QT == Q_NF4 ? 64 * 16 * 2 : 0) +
+           (has_min_of(QT) && xlds ? (size_t)(Kp / 32 + XTAIL / 32) * MT * 16 * 4 : 0);
+  };
   // 16 wavefronts when the grid is small (about one workgroup per CU) and every wavefront still gets
   // at least two k-tiles: halves the per-wavefront instruction stream of the latency-bound small GEMVs
   const bool wide = MT == 1 && !GATE_UP && xbytes <= GEMV_XLDS_LIMIT && grid.x <= 256 && Kp / 128 >= 64;
@@ -526,7 +556,7 @@ static int launch_x(const GemvArgs& a, hipStream_t st) {
              (a.M <= 8 && xbytes <= GEMV_XLDS_LIMIT_FEW_ROWS && gemv_allow_lds(gemv_t16_kernel<QT, MT, GATE_UP, true, 8>, fixed(8) + xbytes))) {
     hipLaunchKernelGGL((gemv_t16_kernel<QT, MT, GATE_UP, true, 8>), grid, dim3(512), fixed(8) + xbytes, st, a);
   } else {
-    hipLaunchKernelGGL((gemv_t16_kernel<QT, MT, GATE_UP, false, 8>), grid, dim3(512), fixed(8), st, a);
+    hipLaunchKernelGGL((gemv_t16_kernel<QT, MT, GATE_UP, false, 8>), grid, dim3(512), fixed(8, false), st, a);
   }
   return HIP_CHECK_LAUNCH();
 }
