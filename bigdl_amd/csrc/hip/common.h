@@ -166,6 +166,12 @@ __device__ __forceinline__ half8 dec_fp6(uint32_t w, uint32_t hb) {
 }
 constexpr float FP6_POST = 4096.0f;
 
+__constant__ const float NF4_VALUES[16] = {
+    -1.0f, -0.6961928009986877f, -0.5250730514526367f, -0.39491748809814453f,
+    -0.28444138169288635f, -0.18477343022823334f, -0.09105003625154495f, 0.0f,
+    0.07958029955625534f, 0.16093020141124725f, 0.24611230194568634f, 0.33791524171829224f,
+    0.44070982933044434f, 0.5626170039176941f, 0.7229568362236023f, 1.0f};
+
 // nf4: 16-entry table lookup; the table lives in LDS as 16 fp16 values replicated per lane
 // group to keep bank conflicts low (see gemv kernel)
 __device__ __forceinline__ half8 dec_nf4(uint32_t w, const _Float16* lut) {
@@ -177,6 +183,28 @@ __device__ __forceinline__ half8 dec_nf4(uint32_t w, const _Float16* lut) {
     r.h2[i] = h;
   }
   return r.v;
+}
+
+// nf4 through a bank-private table: 16 entries x 32 dwords in LDS, entry i of lane l at dword i * 32 + (l & 31), the
+// fp16 value replicated in both halves of the dword.  Every lane only ever touches bank l & 31 (lanes l and l + 32
+// read the same dword: a broadcast), so the 8 lookups of a fragment are conflict free whatever the codes are; the
+// replicated halves let one v_bfi merge two lookups into a packed pair.  `lut` already points at the lane's column.
+__device__ __forceinline__ half8 dec_nf4_banked(uint32_t w, const uint32_t* lut) {
+  H8 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t t = w >> (4 * i);
+    const uint32_t a = lut[(t & 15u) << 5], b = lut[((t >> 16) & 15u) << 5];
+    r.u[i] = (a & 0x0000ffffu) | (b & 0xffff0000u);
+  }
+  return r.v;
+}
+__device__ __forceinline__ void fill_nf4_banked(uint32_t* table, int tid, int nthreads) {
+  for (int i = tid; i < 16 * 32; i += nthreads) {
+    union { _Float16 h; uint16_t u; } c;
+    c.h = (_Float16)NF4_VALUES[i >> 5];
+    table[i] = (uint32_t)c.u | ((uint32_t)c.u << 16);
+  }
 }
 
 // int8 codes, 8 bytes (two words): value = (int8)code.  fp16 0x6400|b' = 1024 + b', b' = b ^ 0x80
@@ -211,11 +239,6 @@ __device__ __forceinline__ half8 dec_e4m3(uint32_t w0, uint32_t w1) {
 }
 constexpr float E4M3_POST = 256.0f;
 
-__constant__ const float NF4_VALUES[16] = {
-    -1.0f, -0.6961928009986877f, -0.5250730514526367f, -0.39491748809814453f,
-    -0.28444138169288635f, -0.18477343022823334f, -0.09105003625154495f, 0.0f,
-    0.07958029955625534f, 0.16093020141124725f, 0.24611230194568634f, 0.33791524171829224f,
-    0.44070982933044434f, 0.5626170039176941f, 0.7229568362236023f, 1.0f};
 
 struct T16Planes {
   const uint8_t* lo;

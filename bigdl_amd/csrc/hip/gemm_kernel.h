@@ -73,8 +73,8 @@ __global__ __launch_bounds__(256, 2) void gemm_t16_kernel(GemmArgs a) {
 
   const _Float16* lut = nullptr;
   if constexpr (QT == Q_NF4) {
-    for (int i = threadIdx.x; i < 64 * 16; i += 256) nf4_lut[i] = (_Float16)NF4_VALUES[i & 15];
-    lut = nf4_lut + lane * 16;
+    fill_nf4_banked((uint32_t*)nf4_lut, threadIdx.x, 256);
+    lut = (const _Float16*)((const uint32_t*)nf4_lut + (lane & 31));
   }
 
   // this wavefront's weight tile rows (clamped: a tile past N is loaded from the last valid one and never stored)

@@ -126,7 +126,7 @@ __device__ __forceinline__ half8 decode_step(const Tile<QT>& t, int s, const _Fl
   if constexpr (QT == Q_SYM_INT4) return dec_int4_fast(t.lo0[s], 8.0f);
   else if constexpr (QT == Q_ASYM_INT4 || QT == Q_WOQ_INT4) return dec_int4_fast(t.lo0[s], 0.0f);
   else if constexpr (QT == Q_FP4) return dec_fp4(t.lo0[s]);
-  else if constexpr (QT == Q_NF4) return dec_nf4(t.lo0[s], lut);
+  else if constexpr (QT == Q_NF4) return dec_nf4_banked(t.lo0[s], (const uint32_t*)lut);
   else if constexpr (QT == Q_SYM_INT5) return dec_int5(t.lo0[s], (t.hi0 >> (8 * s)) & 0xffu, 16.0f);
   else if constexpr (QT == Q_ASYM_INT5) return dec_int5(t.lo0[s], (t.hi0 >> (8 * s)) & 0xffu, 0.0f);
   else if constexpr (QT == Q_FP6) return dec_fp6(t.lo0[s], ((s < 2 ? t.hi0 : t.hi1) >> (16 * (s & 1))) & 0xffffu);
@@ -246,8 +246,8 @@ __global__ __launch_bounds__(NW * 64) void gemv_t16_kernel(GemvArgs a) {
   const bool norm = a.gamma != nullptr;
   const _Float16* lut = nullptr;
   if constexpr (QT == Q_NF4) {
-    for (int i = threadIdx.x; i < 64 * 16; i += GEMV_NW * 64) nf4_lut[i] = (_Float16)NF4_VALUES[i & 15];
-    lut = nf4_lut + lane * 16;
+    fill_nf4_banked((uint32_t*)nf4_lut, threadIdx.x, GEMV_NW * 64);
+    lut = (const _Float16*)((const uint32_t*)nf4_lut + (lane & 31));
   }
   if (threadIdx.x < MT * 16) ssq_sh[threadIdx.x] = 0.0f;
   if constexpr (XSUM) {
