@@ -12,6 +12,7 @@ import uuid
 from typing import List, Optional
 
 from fastapi import FastAPI, HTTPException
+from fastapi import Request as HttpRequest
 from fastapi.responses import JSONResponse, PlainTextResponse, StreamingResponse
 
 from .model_worker import ModelWorker, Request
@@ -44,6 +45,42 @@ def get_prompt(messages, tokenizer=None) -> str:
         else:
             raise HTTPException(status_code=400, detail=f"Unknown role: {m['role']}")
     return out.strip()
+
+
+def parse_multipart(content_type: str, body: bytes) -> dict:
+    """multipart/form-data -> {field: bytes or str} with the standard library's MIME parser (the optional
+    ``python-multipart`` dependency of FastAPI's ``UploadFile`` is not required)."""
+    from email.parser import BytesParser
+    from email.policy import HTTP
+    msg = BytesParser(policy=HTTP).parsebytes(b"Content-Type: " + content_type.encode() + b"\r\n\r\n" + body)
+    out = {}
+    for part in msg.iter_parts():
+        name = part.get_param("name", header="content-disposition")
+        data = part.get_payload(decode=True)
+        if part.get_filename() is None:
+            data = data.decode("utf-8", "replace").strip()
+        out[name] = data
+    return out
+
+
+def decode_wav(data: bytes, target_rate: int = 16000):
+    """PCM WAV bytes -> mono float32 numpy array at ``target_rate`` (linear resampling)."""
+    import io
+    import wave
+
+    import numpy as np
+    with wave.open(io.BytesIO(data)) as w:
+        rate, width, ch = w.getframerate(), w.getsampwidth(), w.getnchannels()
+        raw = w.readframes(w.getnframes())
+    dt = {1: np.uint8, 2: np.int16, 4: np.int32}[width]
+    x = np.frombuffer(raw, dtype=dt).astype(np.float32)
+    x = (x - 128.0) / 128.0 if width == 1 else x / float(2 ** (8 * width - 1))
+    if ch > 1:
+        x = x.reshape(-1, ch).mean(1)
+    if rate != target_rate and x.size:
+        n = int(round(x.size * target_rate / rate))
+        x = np.interp(np.linspace(0, x.size - 1, n), np.arange(x.size), x).astype(np.float32)
+    return x
 
 
 def _stops(stop) -> List[str]:
@@ -206,6 +243,28 @@ class FastApp:
                 ChatCompletionResponseChoice(index=0, message=ChatMessage(role="assistant", content=text),
                                              finish_reason="stop")])
 
+        @app.post("/v1/audio/transcriptions")
+        async def transcriptions(request: HttpRequest):
+            """OpenAI audio API: multipart form with ``file`` (PCM WAV) and optional ``language`` / ``response_format``
+            (reference api_server.py:403-426)."""
+            ctype = request.headers.get("content-type", "")
+            body = await request.body()
+            if "multipart/form-data" in ctype:
+                form = parse_multipart(ctype, body)
+            else:
+                form = {"file": body}
+            if not isinstance(form.get("file"), (bytes, bytearray)) or not form["file"]:
+                raise HTTPException(status_code=400, detail="missing audio `file`")
+            try:
+                audio = decode_wav(bytes(form["file"]))
+            except Exception as e:
+                raise HTTPException(status_code=400, detail=f"unsupported audio (PCM WAV expected): {e}")
+            loop = asyncio.get_running_loop()
+            text = await loop.run_in_executor(None, self.transcribe, audio, form.get("language"))
+            if form.get("response_format") == "text":
+                return PlainTextResponse(text)
+            return JSONResponse({"text": text})
+
         @app.post("/v1/completions")
         async def completions(request: CompletionRequest):
             prompt = request.prompt
@@ -235,6 +294,26 @@ class FastApp:
             text = await self._collect(req)
             return CompletionResponse(model=request.model, usage=self._usage(prompt, text), choices=[
                 CompletionResponseChoice(index=0, text=(prompt + text) if request.echo else text, finish_reason="stop")])
+
+
+    def transcribe(self, audio, language: Optional[str] = None, max_new_tokens: int = 256) -> str:
+        """Speech -> text with a Whisper-style seq2seq model (``processor`` = feature extractor + tokenizer)."""
+        import torch
+        if self.processor is None:
+            raise HTTPException(status_code=400, detail="this server was started without an audio processor")
+        model = self.worker.model
+        feats = self.processor(audio, sampling_rate=16000, return_tensors="pt").input_features
+        p = next(p for p in model.parameters() if p.numel() > 0)
+        dtype = p.dtype if p.dtype in (torch.float16, torch.bfloat16, torch.float32) else torch.float16
+        kw = {}
+        if language and hasattr(self.processor, "get_decoder_prompt_ids"):
+            kw["forced_decoder_ids"] = self.processor.get_decoder_prompt_ids(language=language, task="transcribe")
+        limit = getattr(model.config, "max_target_positions", None)
+        if limit:
+            max_new_tokens = max(1, min(max_new_tokens, limit - 4))      # room for the start / language / task tokens
+        with torch.inference_mode():
+            ids = model.generate(feats.to(p.device, dtype), max_new_tokens=max_new_tokens, **kw)
+        return self.processor.batch_decode(ids, skip_special_tokens=True)[0]
 
 
 def serve(repo_id_or_model_path: str, low_bit: str = "sym_int4", port: int = 8000, host: str = "0.0.0.0",

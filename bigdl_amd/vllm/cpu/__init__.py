@@ -1,0 +1,1 @@
+"""Import path of the reference (ipex_llm.vllm.cpu); on MI355X there is one implementation: bigdl_amd.vllm."""

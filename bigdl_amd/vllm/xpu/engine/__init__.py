@@ -1,0 +1,7 @@
+"""from ipex_llm.vllm.xpu.engine import IPEXLLMClass as LLM (reference python/llm/src/ipex_llm/vllm/xpu/engine/__init__.py)."""
+from ...engine import run_mp_engine  # noqa: F401
+
+
+def __getattr__(name):
+    from ... import engine
+    return getattr(engine, name)

@@ -76,3 +76,63 @@ def test_stop_strings_health_and_metrics(client):
     assert client.get("/health").json()["status"] == "ok"
     m = client.get("/metrics").text
     assert "bigdl_requests_total" in m and "bigdl_generated_tokens_total" in m
+
+
+def test_audio_transcription_route():
+    """/v1/audio/transcriptions: multipart WAV upload -> Whisper-style generate -> text (tiny random model, stub
+    processor: the route, the stdlib multipart / WAV decoding and the dtype / device plumbing are what is tested)."""
+    import io
+    import wave
+
+    import numpy as np
+    import torch
+    from starlette.testclient import TestClient
+    from transformers import WhisperConfig, WhisperForConditionalGeneration
+
+    from bigdl_amd.optimize import optimize_model
+    from bigdl_amd.serving.fastapi.api_server import FastApp, decode_wav, parse_multipart
+
+    torch.manual_seed(0)
+    cfg = WhisperConfig(vocab_size=320, d_model=128, encoder_layers=1, decoder_layers=1, encoder_attention_heads=4,
+                        decoder_attention_heads=4, encoder_ffn_dim=256, decoder_ffn_dim=256, num_mel_bins=16,
+                        max_source_positions=32, max_target_positions=32, pad_token_id=0, bos_token_id=1, eos_token_id=2,
+                        decoder_start_token_id=1)
+    model = optimize_model(WhisperForConditionalGeneration(cfg).eval(), low_bit="sym_int8")
+    model.generation_config.forced_decoder_ids = None
+
+    class Proc:
+        seen = None
+
+        def __call__(self, audio, sampling_rate=16000, return_tensors="pt"):
+            Proc.seen = (len(audio), sampling_rate)
+            g = torch.Generator().manual_seed(len(audio))
+
+            class R:
+                input_features = torch.randn(1, 16, 64, generator=g)
+            return R
+
+        def batch_decode(self, ids, skip_special_tokens=True):
+            return ["tokens:" + ",".join(str(int(t)) for t in ids[0])]
+
+    class Tok:
+        eos_token_id = 2
+
+    buf = io.BytesIO()
+    with wave.open(buf, "wb") as w:
+        w.setnchannels(2); w.setsampwidth(2); w.setframerate(8000)
+        t = np.arange(8000) / 8000.0
+        pcm = (np.sin(2 * np.pi * 440 * t) * 12000).astype(np.int16)
+        w.writeframes(np.stack([pcm, pcm], 1).tobytes())
+    wav = buf.getvalue()
+    assert decode_wav(wav).shape == (16000,)                      # stereo 8 kHz -> mono 16 kHz
+    app = FastApp(model=model, mytokenizer=Tok(), myprocessor=Proc())
+    with TestClient(app.app) as c:
+        r = c.post("/v1/audio/transcriptions", files={"file": ("a.wav", wav, "audio/wav")},
+                   data={"language": "", "response_format": "json"})
+        assert r.status_code == 200, r.text
+        assert r.json()["text"].startswith("tokens:1") and Proc.seen == (16000, 16000)
+        bad = c.post("/v1/audio/transcriptions", files={"file": ("a.wav", b"not a wav", "audio/wav")})
+        assert bad.status_code == 400
+    form = parse_multipart('multipart/form-data; boundary=XX',
+                           b'--XX\r\nContent-Disposition: form-data; name="language"\r\n\r\nen\r\n--XX--\r\n')
+    assert form == {"language": "en"}
