@@ -26,8 +26,10 @@ def register():
     def forward_new(x: torch.Tensor, weight: torch.Tensor, qtype: int, out_features: int) -> torch.Tensor:
         x2 = x.reshape(-1, x.shape[-1])
         xh = x2 if x2.dtype == torch.float16 else x2.to(torch.float16)
-        if x2.shape[0] <= 64:
+        if x2.shape[0] <= 16:
             y = hip.gemv_lowbit(xh.contiguous(), weight, qtype, out_features, x.shape[-1], out_dtype=torch.float16)
+        elif x2.shape[0] <= 256:
+            y = hip.gemm_lowbit(xh.contiguous(), weight, qtype, out_features, x.shape[-1], out_dtype=torch.float16)
         else:
             y = torch.nn.functional.linear(xh, hip.dequant_t16(weight, qtype, out_features, x.shape[-1]))
         return y.to(x.dtype).view(*x.shape[:-1], out_features)

@@ -21,8 +21,9 @@ if __name__ == "__main__":
         eng.generate(ids, max_new_tokens=8)
         eng.generate(ids, max_new_tokens=a.n_predict)
         print(f"hipGraph={graph}: {eng.rest_cost_mean * 1e3:.3f} ms/token")
-    import bigdl_amd.ops.torch_ops  # noqa: F401  (registers bigdl_amd::* ops with fake kernels)
+    from bigdl_amd.ops import torch_ops
+    torch_ops.register()                     # bigdl_amd::* ops with fake kernels
     x = torch.randn(4, 2048, device="cuda", dtype=torch.float16)
     w = torch.ones(2048, device="cuda", dtype=torch.float16)
-    fn = torch.compile(lambda t: torch.ops.bigdl_amd.rms_norm(t, w, 1e-5) * 2, backend="aot_eager")
-    print("compiled op ok:", torch.allclose(fn(x), torch.ops.bigdl_amd.rms_norm(x, w, 1e-5) * 2))
+    fn = torch.compile(lambda t: torch.ops.bigdl_amd.rms_norm(w, t, 1e-5) * 2, backend="aot_eager")
+    print("compiled op ok:", torch.allclose(fn(x), torch.ops.bigdl_amd.rms_norm(w, x, 1e-5) * 2))
