@@ -307,14 +307,18 @@ _REGISTRY_DISPATCH = {}
 
 def _dispatches_through_registry(cls) -> bool:
     """True when the modeling file of ``cls`` picks its attention through ALL_ATTENTION_FUNCTIONS only; files that
-    compare ``_attn_implementation`` with fixed names (falcon, bloom-style manual attention) keep their own choice."""
+    compare ``_attn_implementation`` with the names of fused implementations (falcon) or never consult the registry
+    (bloom-style manual attention) keep their own choice."""
     mod = sys.modules.get(cls.__module__)
     if mod not in _REGISTRY_DISPATCH:
         try:
             import inspect
             src = inspect.getsource(mod)
-            _REGISTRY_DISPATCH[mod] = "ALL_ATTENTION_FUNCTIONS" in src and "_attn_implementation ==" not in src \
-                and "_attn_implementation !=" not in src
+            import re
+            # a comparison with "eager" is harmless (we are one of the non-eager choices); files that branch on the
+            # names of specific fused implementations would take their eager path with a mask built for SDPA
+            named = re.search(r"_attn_implementation\s*(==|!=|in)\s*[^\n]*(sdpa|flash|flex)", src)
+            _REGISTRY_DISPATCH[mod] = "ALL_ATTENTION_FUNCTIONS" in src and named is None
         except Exception:
             _REGISTRY_DISPATCH[mod] = False
     return _REGISTRY_DISPATCH[mod]

@@ -228,3 +228,49 @@ def test_left_padded_batch_on_module_path(tiny):
     out = q.generate(ids, attention_mask=mask, max_new_tokens=6, do_sample=False)
     solo = q.generate(b, max_new_tokens=6, do_sample=False)
     assert (out[1, 12:] == solo[0, 7:]).float().mean() > 0.8
+
+
+@pytest.mark.parametrize("family", ["gpt2", "gpt_neox", "phi", "starcoder2", "opt", "qwen3", "whisper"])
+def test_attention_registry_reaches_flash_kernel(family, monkeypatch):
+    """Families that dispatch through HF's attention registry (no per-family forward here) run the MFMA flash kernel
+    on the GPU and reproduce the CPU logits of the same quantized model."""
+    import copy
+    from transformers import AutoConfig, AutoModelForCausalLM, WhisperConfig, WhisperForConditionalGeneration
+    from bigdl_amd.ops import hip
+    from bigdl_amd.optimize import optimize_model
+    torch.manual_seed(0)
+    common = dict(vocab_size=320, hidden_size=256, num_hidden_layers=2, num_attention_heads=4, max_position_embeddings=256)
+    extra = {"gpt2": dict(n_embd=256, n_layer=2, n_head=4, n_positions=256), "gpt_neox": dict(intermediate_size=512),
+             "phi": dict(intermediate_size=512), "starcoder2": dict(intermediate_size=512, num_key_value_heads=2),
+             "opt": dict(ffn_dim=512, word_embed_proj_dim=256), "gptj": dict(n_embd=256, n_layer=2, n_head=4, n_positions=256, rotary_dim=32),
+             "qwen3": dict(intermediate_size=512, num_key_value_heads=2, head_dim=64)}
+    calls = {"n": 0}
+    real = hip.attn_prefill
+
+    def counted(*a, **k):
+        calls["n"] += 1
+        return real(*a, **k)
+    monkeypatch.setattr(hip, "attn_prefill", counted)
+    if family == "whisper":
+        cfg = WhisperConfig(vocab_size=320, d_model=256, encoder_layers=2, decoder_layers=2, encoder_attention_heads=4,
+                            decoder_attention_heads=4, encoder_ffn_dim=512, decoder_ffn_dim=512, num_mel_bins=16,
+                            max_source_positions=32, max_target_positions=32, pad_token_id=0, bos_token_id=1, eos_token_id=2,
+                            decoder_start_token_id=1)
+        q = optimize_model(WhisperForConditionalGeneration(cfg).eval(), low_bit="sym_int8")
+        feats, dec = torch.randn(1, 16, 64), torch.randint(3, 320, (1, 7))
+        with torch.no_grad():
+            ref = q(input_features=feats, decoder_input_ids=dec).logits.float()
+            q = q.half().to("cuda")
+            out = q(input_features=feats.half().cuda(), decoder_input_ids=dec.cuda()).logits.float().cpu()
+    else:
+        cfg = AutoConfig.for_model(family, **{**common, **extra[family]})
+        q = optimize_model(AutoModelForCausalLM.from_config(cfg).eval().float(), low_bit="sym_int8")
+        ids = torch.randint(0, 320, (2, 9))
+        with torch.no_grad():
+            ref = q(ids).logits.float()
+            q = q.half().to("cuda")
+            out = q(ids.cuda()).logits.float().cpu()
+            gen = q.generate(ids[:1].cuda(), max_new_tokens=4, do_sample=False)
+        assert gen.shape == (1, 13)
+    assert calls["n"] >= 2, "the flash kernel was not reached"
+    assert _rel(out, ref) < 0.03
