@@ -240,6 +240,12 @@ __device__ __forceinline__ half8 dec_e4m3(uint32_t w0, uint32_t w1) {
 constexpr float E4M3_POST = 256.0f;
 
 
+// k-quants with 32-wide sub-blocks are tiled as their asymmetric per-32 equivalents on the device
+// (bigdl_amd/csrc/host/relayout.cpp): the kernels only ever see the equivalent format
+__host__ __device__ inline int t16_kernel_qtype(int qtype) {
+  return qtype == Q_Q4_K ? Q_ASYM_INT4 : (qtype == Q_Q5_K ? Q_ASYM_INT5 : qtype);
+}
+
 struct T16Planes {
   const uint8_t* lo;
   const uint8_t* hi;

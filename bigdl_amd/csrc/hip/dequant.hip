@@ -235,6 +235,7 @@ static int launch_dq(const void* w, void* out, int N, int K, int64_t ldo, int ou
 // rows [row0, row0 + N) of the T16 buffer of an [n_total, K] matrix -> dense out [N, ldo]
 extern "C" int bigdl_dequant_t16(const void* w, void* out, int N, int K, int64_t ldo, int qtype, int out_type, int n_total,
                                  int row0, hipStream_t st) {
+  qtype = t16_kernel_qtype(qtype);
   if (n_total <= 0) { n_total = N; row0 = 0; }
   if ((row0 & 15) || row0 < 0 || row0 + N > (n_total + 15) / 16 * 16) return -1;
   const int n_planes = n_total;

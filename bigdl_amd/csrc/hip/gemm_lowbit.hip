@@ -121,6 +121,7 @@ extern "C" int bigdl_gemm_lowbit_bm(int M) {
 extern "C" int bigdl_gemm_lowbit(const void* x, const void* w, void* out, const void* bias, const void* residual,
                                  float* workspace, int64_t workspace_floats, int M, int N, int K, int ldx, int ldo,
                                  int qtype, int act, int out_type, hipStream_t stream) {
+  qtype = t16_kernel_qtype(qtype);
   if (M <= 0 || N <= 0 || K <= 0 || (K & 31) || (ldx & 7) || ((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return -1;
   if (out_type < 0 || out_type > 2) return -3;
   if ((int64_t)M * ldx >= (1ll << 31)) return -6;
@@ -148,6 +149,7 @@ extern "C" int bigdl_gemm_lowbit_grouped(const void* x, const void* w, void* out
                                          const float* row_scale, int rows, int max_blocks, int bm, int n_experts,
                                          int N, int K, int ldx, int ldo, int qtype, int act, int out_type,
                                          int x_row_count, hipStream_t stream) {
+  qtype = t16_kernel_qtype(qtype);
   if (x_row_count <= 0 || (int64_t)x_row_count * ldx >= (1ll << 31)) return -6;
   if (rows <= 0 || N <= 0 || K <= 0 || (K & 31) || (N & 15) || (ldx & 7) || ((uintptr_t)x & 15) || ((uintptr_t)w & 15) ||
       blk_expert == nullptr || blk_row0 == nullptr || blk_rows == nullptr || (bm != 64 && bm != 128) || max_blocks <= 0 ||

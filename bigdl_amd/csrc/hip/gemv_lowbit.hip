@@ -43,6 +43,7 @@ extern "C" int bigdl_gemv_lowbit(const void* x, const void* w, const void* w2, v
                                  float gamma_offset, int M, int N, int K, int ldx, int ldo, int qtype, int act,
                                  int out_type, const float* att_ws, int att_splits, int att_D, int att_G, int att_Hkv,
                                  int att_qlen, int att_rows_alloc, hipStream_t stream) {
+  qtype = t16_kernel_qtype(qtype);
   if (M <= 0 || N <= 0 || K <= 0 || (K & 31) || (ldx & 7) || ((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return -1;
   if (gamma && ((uintptr_t)gamma & 15)) return -1;
   if (w2 && ((uintptr_t)w2 & 15)) return -1;
@@ -75,6 +76,7 @@ extern "C" int bigdl_gemv_lowbit_moe(const void* x, const void* w, const void* w
                                      const float* slot_scale, const void* gamma, float eps, float gamma_offset,
                                      int n_slots, int slot_xdiv, int n_experts, int N, int K, int ldx, int ldo,
                                      int qtype, int act, int out_type, hipStream_t stream) {
+  qtype = t16_kernel_qtype(qtype);
   if (n_slots <= 0 || n_slots > 65535 || slot_xdiv <= 0 || N <= 0 || K <= 0 || (K & 31) || (ldx & 7) || ((uintptr_t)x & 15) ||
       ((uintptr_t)w & 15) || (N & 15) || n_experts <= 0 || slot_expert == nullptr)
     return -1;

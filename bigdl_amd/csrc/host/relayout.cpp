@@ -45,6 +45,10 @@ static bool dev_format(int qtype, DevFormat* f) {
     case Q_ASYM_INT5: *f = {4, 1, true, 32}; return true;
     case Q_FP6: *f = {4, 2, false, 32}; return true;
     case Q_SYM_INT8: case Q_FP8_E4M3: case Q_FP8_E5M2: *f = {8, 0, false, 32}; return true;
+    // k-quants whose sub-blocks are 32 wide map onto the asymmetric tiled layouts: per 32 elements
+    // scale = d * sc6 and min = -dmin * m6, rounded to fp16 (relative error 2^-11, far below the 4-/5-bit step)
+    case Q_Q4_K: *f = {4, 0, true, 256}; return true;
+    case Q_Q5_K: *f = {4, 1, true, 256}; return true;
     default: return false;
   }
 }
@@ -60,6 +64,16 @@ int64_t device_nbytes(int qtype, int64_t N, int64_t K) {
   b += Np * (Kp / 32) * 2;
   if (f.has_min) b += Np * (Kp / 32) * 2;
   return b;
+}
+
+static inline void k4_scale_min(int j, const uint8_t* q, uint8_t* d, uint8_t* m) {
+  if (j < 4) {
+    *d = q[j] & 63;
+    *m = q[j + 4] & 63;
+  } else {
+    *d = (q[j + 4] & 0xF) | ((q[j - 4] >> 6) << 4);
+    *m = (q[j + 4] >> 4) | ((q[j] >> 6) << 4);
+  }
 }
 
 // ---- host row <-> (codes, per-32 scale, per-32 min) ----
@@ -135,6 +149,34 @@ static void unpack_row(int qtype, const uint8_t* row, int64_t K, uint8_t* codes,
       for (int64_t i = 0; i < K / 32; ++i) {
         sc[i] = b[i].d;
         std::memcpy(codes + i * 32, b[i].qs, 32);
+      }
+      break;
+    }
+    case Q_Q4_K: case Q_Q5_K: {
+      // super-block of 256 = 8 sub-blocks of 32; byte l of 32-byte group p holds sub-block 2p (low nibble) and
+      // 2p + 1 (high nibble); q5_k adds bit (2p) / (2p + 1) of qh[l] as the fifth code bit
+      for (int64_t i = 0; i < K / 256; ++i) {
+        const uint8_t* scales; const uint8_t* qs; const uint8_t* qh = nullptr;
+        float d, dmin;
+        if (qtype == Q_Q4_K) {
+          const block_q4_K* b = (const block_q4_K*)row + i;
+          d = fp16_to_fp32(b->d); dmin = fp16_to_fp32(b->dmin); scales = b->scales; qs = b->qs;
+        } else {
+          const block_q5_K* b = (const block_q5_K*)row + i;
+          d = fp16_to_fp32(b->d); dmin = fp16_to_fp32(b->dmin); scales = b->scales; qs = b->qs; qh = b->qh;
+        }
+        for (int sb = 0; sb < 8; ++sb) {
+          uint8_t s6, m6;
+          k4_scale_min(sb, scales, &s6, &m6);
+          sc[i * 8 + sb] = fp32_to_fp16(d * s6);
+          mn[i * 8 + sb] = fp32_to_fp16(-dmin * m6);
+          const uint8_t* q = qs + (sb / 2) * 32;
+          for (int l = 0; l < 32; ++l) {
+            uint8_t c = (sb & 1) ? (q[l] >> 4) : (q[l] & 15);
+            if (qh) c |= ((qh[l] >> sb) & 1) << 4;
+            codes[i * 256 + sb * 32 + l] = c;
+          }
+        }
       }
       break;
     }
@@ -296,6 +338,7 @@ int relayout_to_device(int qtype, const uint8_t* src, uint8_t* dst, int64_t N, i
 int relayout_to_host(int qtype, const uint8_t* src, uint8_t* dst, int64_t N, int64_t K) {
   DevFormat f;
   if (!dev_format(qtype, &f)) return -1;
+  if (qtype == Q_Q4_K || qtype == Q_Q5_K) return -3;   // the 6-bit sub-scales are folded on the way in: not invertible
   if (K % f.host_qk != 0) return -2;
   const int64_t Np = round_up(N, 16), Kp = round_up(K, 128);
   const int64_t row_bytes = K / qk_size(qtype) * type_size(qtype);

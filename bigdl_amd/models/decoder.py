@@ -694,7 +694,7 @@ def _random_t16(n, k, qtype, device, gen, scale=0.02):
     nb = host.device_nbytes(qtype, n, k)
     np_, kp = (n + 15) // 16 * 16, (k + 127) // 128 * 128
     lo_bits = 8 if qtype in (Q.SYM_INT8, Q.FP8E4, Q.FP8E5) else 4
-    hi_bits = {Q.SYM_INT5: 1, Q.ASYM_INT5: 1, Q.FP6: 2}.get(qtype, 0)
+    hi_bits = {Q.SYM_INT5: 1, Q.ASYM_INT5: 1, Q.FP6: 2, Q.Q5_K: 1}.get(qtype, 0)
     code_bytes = np_ * kp * (lo_bits + hi_bits) // 8
     buf = torch.empty(nb, dtype=torch.uint8, device=device)
     codes = torch.randint(0, 256, (code_bytes,), dtype=torch.uint8, device=device, generator=gen)

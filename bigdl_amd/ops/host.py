@@ -201,8 +201,8 @@ def t16_plane_nbytes(qtype: int, n: int, k: int):
     """Byte sizes of the planes of a tiled device buffer, in storage order (codes, high bits, scales, mins)."""
     np_, kp = (n + 15) // 16 * 16, (k + 127) // 128 * 128
     lo_bits = 8 if qtype in (Q.SYM_INT8, Q.FP8E4, Q.FP8E5) else 4
-    hi_bits = {Q.SYM_INT5: 1, Q.ASYM_INT5: 1, Q.FP6: 2}.get(qtype, 0)
-    has_min = qtype in (Q.ASYM_INT4, Q.ASYM_INT5, Q.WOQ_INT4)
+    hi_bits = {Q.SYM_INT5: 1, Q.ASYM_INT5: 1, Q.FP6: 2, Q.Q5_K: 1}.get(qtype, 0)
+    has_min = qtype in (Q.ASYM_INT4, Q.ASYM_INT5, Q.WOQ_INT4, Q.Q4_K, Q.Q5_K)
     sizes = [np_ * kp * lo_bits // 8, np_ * kp * hi_bits // 8, np_ * (kp // 32) * 2, np_ * (kp // 32) * 2 if has_min else 0]
     assert sum(sizes) == device_nbytes(qtype, n, k)
     return sizes

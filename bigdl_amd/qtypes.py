@@ -79,7 +79,10 @@ RTN_QTYPES = (SYM_INT4_RTN, SYM_INT8_RTN, ASYM_INT4_RTN)
 # formats quantized with the importance-matrix-aware entry point
 K_QTYPES = (IQ2_XXS, IQ2_XS, Q2_K, IQ1_S, IQ1_M, Q4_K, Q6_K, Q5_K, FP6_K)
 # formats with a tiled device layout and a fused MFMA kernel on gfx950
-T16_QTYPES = (SYM_INT4, ASYM_INT4, FP4, NF4, WOQ_INT4, SYM_INT5, ASYM_INT5, FP6, SYM_INT8, FP8E4, FP8E5)
+# (q4_k / q5_k are tiled as asym_int4 / asym_int5 with per-32 scale = d * sc6 and min = -dmin * m6)
+T16_QTYPES = (SYM_INT4, ASYM_INT4, FP4, NF4, WOQ_INT4, SYM_INT5, ASYM_INT5, FP6, SYM_INT8, FP8E4, FP8E5, Q4_K, Q5_K)
+# tiled formats whose device form cannot be turned back into the host blocks (the host copy is kept instead)
+T16_ONE_WAY = (Q4_K, Q5_K)
 DENSE_QTYPES = (FP16, BF16)
 
 

@@ -117,6 +117,8 @@ class FP4Params(torch.nn.Parameter):
                         _shape=self._shape, convert_shape_only=self.convert_shape_only, qtype=self.qtype,
                         imatrix=self.imatrix, in_features=self.in_features,
                         enable_scale_search=self.enable_scale_search, host_only=self.host_only)
+        if getattr(self, "_host_blocks", None) is not None:
+            new._host_blocks = self._host_blocks
         memo[id(self)] = new
         return new
 
@@ -165,9 +167,20 @@ class FP4Params(torch.nn.Parameter):
             self.quantize("cpu")
             if self.qtype in Q.T16_QTYPES and not self.host_only:
                 tiled = ggml_q_format_convet_cpu2xpu(self.data, self._shape, self.qtype)
-                return self._clone_with(tiled.to(device, non_blocking=non_blocking), layout="t16")
+                new = self._clone_with(tiled.to(device, non_blocking=non_blocking), layout="t16")
+                if self.qtype in Q.T16_ONE_WAY:
+                    # k-quant sub-scales are folded into per-32 fp16 scales on the device: keep the host blocks for
+                    # save_low_bit / .to("cpu").  nn.Module._apply keeps this object and swaps its .data, a direct
+                    # caller keeps the returned one: both carry the copy.
+                    self._host_blocks = new._host_blocks = self.data
+                return new
             return self._clone_with(self.data.to(device, non_blocking=non_blocking), layout="host")
         if dst == "cpu" and src == "cuda":
+            if self.qlayout == "t16" and self.qtype in Q.T16_ONE_WAY:
+                blocks = getattr(self, "_host_blocks", None)
+                if blocks is None:
+                    raise RuntimeError("this k-quant weight was re-sliced on the device; its host blocks are gone")
+                return self._clone_with(blocks, layout="host")
             data = self.data.to("cpu")
             if self.qlayout == "t16":
                 data = ggml_q_format_convet_xpu2cpu(data, self._shape, self.qtype)

@@ -23,7 +23,7 @@ def _rel(a, b):
     return ((a - b).abs().mean() / b.abs().mean()).item()
 
 
-@pytest.mark.parametrize("low_bit", ["sym_int4", "asym_int4", "fp8_e5m2", "nf4", "sym_int8", "q4_k", "fp16"])
+@pytest.mark.parametrize("low_bit", ["sym_int4", "asym_int4", "fp8_e5m2", "nf4", "sym_int8", "q4_k", "q5_k", "q6_k", "fp16"])
 def test_gpu_logits_match_cpu_path(tiny, low_bit):
     from ipex_llm.transformers import AutoModelForCausalLM
     d, _ = tiny
@@ -32,6 +32,8 @@ def test_gpu_logits_match_cpu_path(tiny, low_bit):
     with torch.no_grad():
         cpu = q(ids).logits.float()
     q = q.half().to("cuda")
+    if low_bit in ("q4_k", "q5_k", "sym_int4"):
+        assert q.model.layers[0].mlp.down_proj.weight.qlayout == "t16"       # fused kernels, not dequantize + GEMM
     with torch.no_grad():
         gpu = q(ids.cuda()).logits.float().cpu()
     # reference test TEST/inference_gpu/test_transformers_api_final_logits.py:59-68 uses a mismatch fraction;

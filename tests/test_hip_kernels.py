@@ -44,6 +44,27 @@ def test_dequant_t16(hip, name, shape):
     torch.testing.assert_close(out16, ref, rtol=2e-3, atol=1e-4)
 
 
+@pytest.mark.parametrize("name", ["q4_k", "q5_k"])
+@pytest.mark.parametrize("m", [1, 5, 40, 130])
+def test_k_quants_run_on_the_asymmetric_tiled_kernels(hip, name, m):
+    """q4_k / q5_k are tiled as per-32 asymmetric formats (scale = d * sc6, min = -dmin * m6 in fp16): GEMV, GEMM and
+    dequantization on the device agree with the host dequantization of the original k-quant blocks."""
+    torch.manual_seed(3)
+    qt = Q.ggml_tensor_qtype[name]
+    n, k = 80, 768
+    w = torch.randn(n, k) * 0.05
+    x = torch.randn(m, k).half()
+    dev, ref_w = _quant_dev(w, qt)
+    ref = x.float() @ ref_w.t()
+    if m <= 16:
+        out = hip.gemv_lowbit(x.cuda(), dev, qt, n, k, out_dtype=torch.float32).cpu()
+    else:
+        out = hip.gemm_lowbit(x.cuda(), dev, qt, n, k, out_dtype=torch.float32).cpu()
+    torch.testing.assert_close(out, ref, rtol=4e-3, atol=4e-3)
+    deq = hip.dequant_t16(dev, qt, n, k, dtype=torch.float32).cpu()
+    torch.testing.assert_close(deq, ref_w, rtol=2e-3, atol=3e-4)
+
+
 @pytest.mark.parametrize("name", T16)
 @pytest.mark.parametrize("m", [1, 3, 16, 33])
 def test_gemv_matches_dequant_reference(hip, name, m):
