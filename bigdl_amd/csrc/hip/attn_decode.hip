@@ -33,6 +33,7 @@ struct AttnArgs {
   const _Float16* mask;  // optional additive mask [B, q_total, mask_ld] or null
   const float* rope;     // fused RoPE: table [max_pos][rot/2][2] (cos, sin) or null (q/k already rotated+appended)
   const int* position_ids;  // optional [B*q_total] rope positions (default: cache position)
+  const float* alibi;       // optional [Hq] ALiBi slopes: score += slope[head] * (key - query position)
   int mask_ld;
   float scale;           // softmax scale
   float softcap;         // gemma2 logit soft-capping (0 = off)
@@ -138,11 +139,13 @@ __global__ __launch_bounds__(ATT_NW * 64) void attn_decode_kernel(AttnArgs a) {
   half8 qf[RT][DC];
   int lim[RT];  // last visible key position per row (causal within the new tokens)
   int lo_lim[RT];
+  float slope[RT];   // ALiBi slope of the row's head, in log2 units (0 without ALiBi)
 #pragma unroll
   for (int t = 0; t < RT; ++t) {
     const int row = 16 * t + rr;
     const int tok = a.q_off + row / G, gq = row % G;
     const bool valid = row < rows;
+    slope[t] = a.alibi != nullptr ? a.alibi[hkv * G + gq] * 1.4426950408889634f : 0.0f;
     const int tokidx = b * a.q_total + tok;
     lim[t] = valid ? past + tok : -1;
     lo_lim[t] = (a.window > 0 && valid) ? max(0, past + tok - a.window + 1) : 0;
@@ -242,6 +245,10 @@ __global__ __launch_bounds__(ATT_NW * 64) void attn_decode_kernel(AttnArgs a) {
         for (int q = 0; q < 8; ++q) sv[q] = a.softcap * tanhf(sv[q] / a.softcap) * 1.4426950408889634f;
       }
       const int kfirst = kb + 8 * g;
+      if (a.alibi != nullptr) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sv[q] += slope[t] * (float)(kfirst + q - lim[t]);   // slope * (key - query)
+      }
       if (a.mask) {
         const int row = 16 * t + rr;
         if (row < rows) {
@@ -480,8 +487,8 @@ using namespace bigdl;
 // rope != null: q is rotated in registers, k is rotated and k/v appended to the caches by this launch
 // (requires q_off == 0 for the append; rot/2 % 32 == 0 unless interleaved).
 extern "C" int bigdl_attn_decode(void* qkv, void* kc, void* vc, void* out, float* ws, int* counters,
-                                 const int* past_len, const void* mask, int mask_ld, const float* rope,
-                                 const int* position_ids, int rope_max_pos, int rot, int interleaved, float scale,
+                                 const int* past_len, const void* mask, int mask_ld, const float* alibi,
+                                 const float* rope, const int* position_ids, int rope_max_pos, int rot, int interleaved, float scale,
                                  float softcap, int B, int Hq, int Hkv, int q_total, int q_off, int q_cnt, int ld,
                                  int Lmax, int D, int splits, int window, int fp8, int append, int defer_combine,
                                  hipStream_t stream) {
@@ -496,7 +503,7 @@ extern "C" int bigdl_attn_decode(void* qkv, void* kc, void* vc, void* out, float
   AttnArgs a;
   a.qkv = (_Float16*)qkv; a.kc = kc; a.vc = vc; a.out = (_Float16*)out; a.ws = ws; a.counters = counters;
   a.past_len = past_len; a.mask = (const _Float16*)mask; a.mask_ld = mask_ld; a.scale = scale; a.softcap = softcap;
-  a.rope = rope; a.position_ids = position_ids; a.rope_max_pos = rope_max_pos;
+  a.rope = rope; a.position_ids = position_ids; a.rope_max_pos = rope_max_pos; a.alibi = alibi;
   a.rot = rope ? rot : (append ? 0 : -1); a.interleaved = interleaved;
   a.B = B; a.Hq = Hq; a.Hkv = Hkv; a.ld = ld; a.Lmax = Lmax; a.splits = splits; a.window = window;
   a.q_total = q_total; a.q_off = q_off; a.q_cnt = q_cnt; a.defer_combine = defer_combine;

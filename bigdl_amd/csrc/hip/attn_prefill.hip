@@ -19,9 +19,10 @@ namespace bigdl {
 
 struct PrefillArgs {
   const _Float16* q; const _Float16* k; const _Float16* v; _Float16* out;
-  const _Float16* mask;              // additive [B, Sq, Lk] (strides m_sb, m_sq; last dim contiguous) or null
+  const _Float16* mask;              // additive [B, (Hq,) Sq, Lk] (strides m_sb, m_sh, m_sq; last dim contiguous) or null
+  const float* alibi;                // [Hq] ALiBi slopes (score += slope * (key - query position)) or null
   int B, Hq, Hkv, Sq, Lk;
-  int64_t q_sb, q_sh, q_ss, k_sb, k_sh, k_ss, v_sb, v_sh, v_ss, o_sb, o_ss, m_sb, m_sq;
+  int64_t q_sb, q_sh, q_ss, k_sb, k_sh, k_ss, v_sb, v_sh, v_ss, o_sb, o_ss, m_sb, m_sq, m_sh;
   float scale, softcap;
   int causal, window;
   int v_transposed;                  // v is [B, Hkv, D, Lk] (v_ss = stride of d, keys contiguous)
@@ -76,6 +77,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(PrefillArgs a) {
     for (int i = 0; i < DB; ++i) o[u][i] = float4v{0, 0, 0, 0};
   }
   const float LOG2E = 1.4426950408889634f;
+  const float slope = a.alibi != nullptr ? a.alibi[hq] : 0.0f;
 
   int kbeg = 0, kend = a.Lk;
   if (a.causal) kend = min(a.Lk, q0 + BM + offset);
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(PrefillArgs a) {
       float mloc = -INFINITY;
       const int wq0 = q0 + (wave * QB + u) * 16 + offset;
       // interior tile: every key of the tile is visible to every query of this block (uniform branch)
-      const bool interior = !HAS_MASK && a.softcap <= 0.0f && k0 + PF_BN <= a.Lk && (!a.causal || k0 + PF_BN - 1 <= wq0) &&
+      const bool interior = !HAS_MASK && a.alibi == nullptr && a.softcap <= 0.0f && k0 + PF_BN <= a.Lk && (!a.causal || k0 + PF_BN - 1 <= wq0) &&
                             (a.window <= 0 || k0 > wq0 + 15 - a.window);
       if (interior) {
         const float sc = a.scale * LOG2E;
@@ -180,8 +182,9 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(PrefillArgs a) {
             float v = s[u][kb][e] * a.scale;
             if (a.softcap > 0.0f) v = a.softcap * tanhf(v / a.softcap);
             if constexpr (HAS_MASK) {
-              if (qi[u] < a.Sq && key < a.Lk) v += (float)a.mask[b * a.m_sb + (int64_t)qi[u] * a.m_sq + key];
+              if (qi[u] < a.Sq && key < a.Lk) v += (float)a.mask[b * a.m_sb + hq * a.m_sh + (int64_t)qi[u] * a.m_sq + key];
             }
+            v += slope * (float)(key - pos[u]);   // ALiBi: slope * (key - query position)
             bool ok = key < a.Lk;
             if (a.causal) ok = ok && key <= pos[u];
             if (a.window > 0) ok = ok && key > pos[u] - a.window;
@@ -426,8 +429,8 @@ static int launch_pf(const PrefillArgs& a, hipStream_t st) {
 extern "C" int bigdl_attn_prefill(const void* q, const void* k, const void* v, void* out, const void* mask, int B, int Hq,
                                   int Hkv, int Sq, int Lk, int D, int64_t q_sb, int64_t q_sh, int64_t q_ss, int64_t k_sb,
                                   int64_t k_sh, int64_t k_ss, int64_t v_sb, int64_t v_sh, int64_t v_ss, int64_t o_sb,
-                                  int64_t o_ss, int64_t m_sb, int64_t m_sq, float scale, float softcap, int causal,
-                                  int window, int v_transposed, hipStream_t st) {
+                                  int64_t o_ss, int64_t m_sb, int64_t m_sq, int64_t m_sh, const float* alibi, float scale,
+                                  float softcap, int causal, int window, int v_transposed, hipStream_t st) {
   if (B <= 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv || Sq <= 0 || Lk <= 0 || B > 65535 || Hq > 65535) return -1;
   if (causal && Lk < Sq) return -1;
   if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15) || ((uintptr_t)out & 7)) return -1;
@@ -437,7 +440,7 @@ extern "C" int bigdl_attn_prefill(const void* q, const void* k, const void* v, v
   a.q = (const _Float16*)q; a.k = (const _Float16*)k; a.v = (const _Float16*)v; a.out = (_Float16*)out;
   a.mask = (const _Float16*)mask; a.B = B; a.Hq = Hq; a.Hkv = Hkv; a.Sq = Sq; a.Lk = Lk;
   a.q_sb = q_sb; a.q_sh = q_sh; a.q_ss = q_ss; a.k_sb = k_sb; a.k_sh = k_sh; a.k_ss = k_ss;
-  a.v_sb = v_sb; a.v_sh = v_sh; a.v_ss = v_ss; a.o_sb = o_sb; a.o_ss = o_ss; a.m_sb = m_sb; a.m_sq = m_sq;
+  a.v_sb = v_sb; a.v_sh = v_sh; a.v_ss = v_ss; a.o_sb = o_sb; a.o_ss = o_ss; a.m_sb = m_sb; a.m_sq = m_sq; a.m_sh = m_sh; a.alibi = alibi;
   a.scale = scale; a.softcap = softcap; a.causal = causal; a.window = window; a.v_transposed = v_transposed;
   switch (D) {
     case 64: return launch_pf<64>(a, st);

@@ -23,7 +23,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import qtypes as Q
-from .decoder import DecoderConfig, compute_inv_freq
+from .decoder import DecoderConfig, alibi_slopes, compute_inv_freq
 
 StateDict = Dict[str, torch.Tensor]
 
@@ -121,10 +121,9 @@ def convert_chatglm(cfg: dict, sd: StateDict):
 def convert_baichuan(cfg: dict, sd: StateDict):
     """Baichuan-7B / Baichuan2-7B (reference models/baichuan.py:206-286): llama with a packed ``W_pack``; Baichuan2's
     ``NormHead`` normalizes the lm_head rows at inference, folded into the weight here (reference
-    convert.py:909-923).  The 13B models use ALiBi instead of rotary embeddings."""
-    if _get(cfg, "hidden_size") == 5120 or "max_position_embeddings" not in cfg:
-        raise NotImplementedError("Baichuan-13B (ALiBi attention) is not covered by the native engine")
-    dc = _base_config(cfg, "baichuan")
+    convert.py:909-923).  The 13B models (``model_max_length`` instead of ``max_position_embeddings`` in their config)
+    use ALiBi instead of rotary embeddings (reference models/baichuan.py:289-372)."""
+    dc = _base_config(cfg, "baichuan", alibi="max_position_embeddings" not in cfg)
     out = _llama_keys(cfg, sd, dc, qkv="W_pack")
     if cfg.get("vocab_size", 0) >= 125696:           # Baichuan2 vocabulary: NormHead
         out["lm_head"] = F.normalize(out["lm_head"].float(), dim=-1).to(out["lm_head"].dtype)
@@ -254,15 +253,18 @@ def reference_forward(dc: DecoderConfig, sd: StateDict, ids: torch.Tensor, past=
         q = qkv[..., : hq * d].view(b, s, hq, d).transpose(1, 2)
         k = qkv[..., hq * d:(hq + hkv) * d].view(b, s, hkv, d).transpose(1, 2)
         v = qkv[..., (hq + hkv) * d:].view(b, s, hkv, d).transpose(1, 2)
-        q, k = _rope(q, pos, inv, rot, dc.rope_interleaved, scaling), _rope(k, pos, inv, rot, dc.rope_interleaved, scaling)
+        if not dc.alibi:
+            q, k = _rope(q, pos, inv, rot, dc.rope_interleaved, scaling), _rope(k, pos, inv, rot, dc.rope_interleaved, scaling)
         if past:
             k, v = torch.cat([past[i][0], k], 2), torch.cat([past[i][1], v], 2)
         new_past.append((k, v))
         kk, vv = k.repeat_interleave(hq // hkv, 1), v.repeat_interleave(hq // hkv, 1)
         sc = q @ kk.transpose(-1, -2) * scale
         L = k.shape[2]
-        mask = torch.arange(L)[None] > (p0 + torch.arange(s))[:, None]
-        sc = sc.masked_fill(mask, float("-inf"))
+        rel = torch.arange(L)[None] - (p0 + torch.arange(s))[:, None]
+        if dc.alibi:
+            sc = sc + alibi_slopes(hq)[None, :, None, None] * rel.float()
+        sc = sc.masked_fill(rel > 0, float("-inf"))
         a = (torch.softmax(sc, -1) @ vv).transpose(1, 2).reshape(b, s, hq * d)
         h = h + lin(f"L{i}.o", a)
         x = norm(h, sd[f"L{i}.post_norm"])

@@ -52,6 +52,7 @@ class DecoderConfig:
     sliding_pattern: int = 0          # gemma2: every `pattern`-th layer is global; 0 = all layers alike
     rot_dim: Optional[int] = None     # partial rotary
     rope_interleaved: bool = False
+    alibi: bool = False               # baichuan-13B / bloom / mpt: per-head linear position bias instead of RoPE
     post_norms: bool = False          # gemma2: extra norms after attention / mlp
     model_type: str = "llama"
     # MoE
@@ -69,6 +70,21 @@ class DecoderConfig:
     @property
     def kv_size(self):
         return self.num_kv_heads * self.head_dim
+
+
+def alibi_slopes(n_heads: int) -> torch.Tensor:
+    """fp32 [n_heads] ALiBi slopes: the geometric sequence 2^(-8 i / n) for a power-of-two head count, interleaved
+    with the odd terms of the next power of two otherwise (Baichuan-13B ``_get_interleave``, bloom
+    ``build_alibi_tensor``; reference models/baichuan.py:289-330, models/bloom.py:60-120)."""
+    def pow2(n):
+        start = 2.0 ** (-(2.0 ** -(math.log2(n) - 3)))
+        return [start * start ** i for i in range(n)]
+    if math.log2(n_heads).is_integer():
+        v = pow2(n_heads)
+    else:
+        c = 2 ** math.floor(math.log2(n_heads))
+        v = pow2(c) + pow2(2 * c)[0::2][: n_heads - c]
+    return torch.tensor(v, dtype=torch.float32)
 
 
 def compute_inv_freq(cfg: DecoderConfig, device=None):
@@ -234,6 +250,8 @@ class NativeDecoder:
         self._graphs = {}
         self._static = {}
         self.attn_scale = cfg.attn_scale if cfg.attn_scale is not None else 1.0 / math.sqrt(cfg.head_dim)
+        # ALiBi slopes of this rank's heads (tensor parallelism re-slices them)
+        self.alibi = alibi_slopes(cfg.num_heads).to(self.device) if cfg.alibi else None
         self.use_graph = True
         if os.environ.get("BIGDL_PREFILL_DENSE_CACHE") == "1":
             Lin.cache_dense = True
@@ -261,11 +279,13 @@ class NativeDecoder:
     def _build_rope_table(self, max_pos: int):
         """cos/sin table [max_pos, rot/2, 2] (fp32) read by the fused RoPE in the attention kernel; trig is
         evaluated once here in full precision instead of per token on the device."""
+        cfg = self.cfg
         pos = torch.arange(max_pos, device=self.device, dtype=torch.float32)
         ang = pos[:, None] * self.inv_freq[None].float()
+        if cfg.alibi:
+            ang = torch.zeros_like(ang)          # identity rotation: the prompt path only appends k / v
         self.rope_table = torch.stack([ang.cos(), ang.sin()], -1).mul_(self.rope_scaling_factor).contiguous()
-        cfg = self.cfg
-        self.fused_rope = cfg.rope_interleaved or (cfg.rot_dim or cfg.head_dim) == cfg.head_dim
+        self.fused_rope = cfg.alibi or cfg.rope_interleaved or (cfg.rot_dim or cfg.head_dim) == cfg.head_dim
 
     # ------------------------------------------------------------------ prefill (eager)
     def _linear_dense(self, x, lin: Lin):
@@ -396,7 +416,9 @@ class NativeDecoder:
         if cfg.head_dim in (64, 128) and vt.stride(2) % 8 == 0 and vt.data_ptr() % 16 == 0:
             from ..ops import hip
             return hip.attn_prefill(q, k, vt, scale=self.attn_scale, causal=True, softcap=cfg.attn_softcap, window=window,
-                                    v_transposed=True)
+                                    v_transposed=True, alibi=self.alibi)
+        if self.alibi is not None:
+            raise NotImplementedError("ALiBi attention needs head_dim 64 or 128")
         return self._sdpa_torch(q, k, vt.transpose(-1, -2), past, window).transpose(1, 2).reshape(q.shape[0], q.shape[2], -1)
 
     def _sdpa_torch(self, q, k, v, past, window):
@@ -505,7 +527,9 @@ class NativeDecoder:
             hip.attn_decode(qkv, cache.k[li], cache.v[li], cache.past_len, attn, st["ws"], st["counters"],
                             n_heads=cfg.num_heads, n_kv_heads=cfg.num_kv_heads, head_dim=cfg.head_dim, q_len=q_len,
                             batch=batch, scale=self.attn_scale, splits=st["splits"], softcap=cfg.attn_softcap,
-                            window=lw.window, rope_table=self.rope_table if self.fused_rope else None,
+                            window=lw.window,
+                            rope_table=self.rope_table if self.fused_rope and self.alibi is None else None,
+                            append=self.alibi is not None, alibi=self.alibi,
                             interleaved=cfg.rope_interleaved, defer_combine=st["defer"] and lw.o.fused)
             att_partials = st["att_partials"] if st["defer"] and lw.o.fused else None
             if lw.post_attn_out_norm is None and self.tp_group is None:

@@ -37,7 +37,7 @@ def lib():
         L = ctypes.CDLL(str(_LIB_PATH))
         vp, i64, ci, cf = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
         L.bigdl_gemv_lowbit.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, cf, cf, ci, ci, ci, ci, ci, ci, ci, ci, vp, ci, ci, ci, ci, ci, ci, vp]
-        L.bigdl_attn_decode.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, ci, ci, ci, cf, cf] + [ci] * 14 + [vp]
+        L.bigdl_attn_decode.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, ci, ci, ci, cf, cf] + [ci] * 14 + [vp]
         L.bigdl_attn_decode_ws_floats.argtypes = [ci] * 6
         L.bigdl_attn_decode_ws_floats.restype = i64
         L.bigdl_rope_append.argtypes = [vp, vp, vp, vp, vp, vp, cf] + [ci] * 10 + [vp]
@@ -64,7 +64,7 @@ def lib():
         L.bigdl_rwkv4_wkv.argtypes = [vp] * 8 + [ci] * 5 + [vp]
         L.bigdl_rwkv5_wkv.argtypes = [vp] * 7 + [ci] * 4 + [vp]
         L.bigdl_prefill_rope_append.argtypes = [vp, vp, vp, vp, vp, vp] + [ci] * 10 + [i64, i64, ci, vp]
-        L.bigdl_attn_prefill.argtypes = [vp, vp, vp, vp, vp] + [ci] * 6 + [i64] * 13 + [cf, cf, ci, ci, ci, vp]
+        L.bigdl_attn_prefill.argtypes = [vp, vp, vp, vp, vp] + [ci] * 6 + [i64] * 14 + [vp, cf, cf, ci, ci, ci, vp]
         _LIB = L
     return _LIB
 
@@ -556,8 +556,11 @@ def rope_append(qkv, k_cache, v_cache, past_len, inv_freq, *, n_heads, n_kv_head
 
 def attn_decode(qkv, k_cache, v_cache, past_len, out, ws, counters, *, n_heads, n_kv_heads, head_dim, q_len, batch,
                 scale, splits, softcap=0.0, window=0, mask=None, rope_table=None, rot_dim=None, interleaved=False,
-                position_ids=None, append=False, defer_combine=False):
+                position_ids=None, append=False, defer_combine=False, alibi=None):
     """Split-KV decode attention over the fixed-capacity caches.
+
+    ``alibi``: optional fp32 [n_heads] slopes; the score of key position j for the query at position i gets the ALiBi
+    bias ``slope * (j - i)`` added.
 
     With ``rope_table`` ([max_pos, rot/2, 2] fp32 cos/sin) the kernel also rotates q in registers and
     rotates + appends the new k / v^T (one launch instead of rope_append + attention); ``append=True``
@@ -607,11 +610,12 @@ def attn_decode(qkv, k_cache, v_cache, past_len, out, ws, counters, *, n_heads, 
         raise ValueError("position_ids must be int32 [batch*q_len]")
     if defer_combine and q_len > chunk:
         raise ValueError("defer_combine needs all rows in one launch")
+    _check_alibi(alibi, n_heads)
     for off in range(0, q_len, chunk):
         cnt = min(chunk, q_len - off)
         do_append = (rope_table is not None or append) and off == 0
         rc = lib().bigdl_attn_decode(_ptr(qkv), _ptr(k_cache), _ptr(v_cache), _ptr(out), _ptr(ws), _ptr(counters),
-                                     _ptr(past_len), _ptr(mask), mask_ld,
+                                     _ptr(past_len), _ptr(mask), mask_ld, _ptr(alibi),
                                      _ptr(rope_table), _ptr(position_ids), rope_max, rot,
                                      int(bool(interleaved)), scale, softcap, batch, n_heads, n_kv_heads, q_len, off, cnt,
                                      qkv.stride(0), lmax, head_dim, splits, window, int(fp8), int(bool(do_append)),
@@ -620,11 +624,18 @@ def attn_decode(qkv, k_cache, v_cache, past_len, out, ws, counters, *, n_heads, 
     return out
 
 
-def attn_prefill(q, k, v, *, scale, causal=True, mask=None, softcap=0.0, window=0, out=None, v_transposed=False):
+def _check_alibi(alibi, n_heads):
+    if alibi is not None and (alibi.dtype != torch.float32 or alibi.numel() != n_heads or not alibi.is_contiguous()
+                              or alibi.device.type != "cuda"):
+        raise ValueError("alibi must be a contiguous fp32 device tensor [n_heads]")
+
+
+def attn_prefill(q, k, v, *, scale, causal=True, mask=None, softcap=0.0, window=0, out=None, v_transposed=False,
+                 alibi=None):
     """Flash-style attention for many query tokens.  q [B, Hq, Sq, D], k / v [B, Hkv, Lk, D]: fp16, any strides with
     a contiguous last dim (views into a fused qkv buffer or a KV cache are fine); with ``v_transposed`` v is
     [B, Hkv, D, Lk] (the engine's V^T cache layout, row stride multiple of 8).  mask: optional additive fp16
-    [B, 1 | none, Sq, Lk].  Returns out [B, Sq, Hq * D].  Causal alignment: query i sees keys <= i + (Lk - Sq)."""
+    [B, 1 | Hq | none, Sq, Lk].  alibi: optional fp32 [Hq] slopes (score += slope * (key - query position)).  Returns out [B, Sq, Hq * D].  Causal alignment: query i sees keys <= i + (Lk - Sq)."""
     _need_cuda(q, k, v, mask, out)
     b, hq, sq, d = q.shape
     hkv, lk = k.shape[1], k.shape[2]
@@ -644,20 +655,21 @@ def attn_prefill(q, k, v, *, scale, causal=True, mask=None, softcap=0.0, window=
         out = torch.empty((b, sq, hq * d), dtype=torch.float16, device=q.device)
     if out.shape != (b, sq, hq * d) or out.stride(-1) != 1 or out.dtype != torch.float16:
         raise ValueError("bad out tensor")
-    m_sb = m_sq = 0
+    m_sb = m_sq = m_sh = 0
     if mask is not None:
-        if mask.dim() == 4:
-            if mask.shape[1] != 1:
-                raise ValueError("per-head masks are not supported")
-            mask = mask[:, 0]
-        if mask.dtype != torch.float16 or mask.stride(-1) != 1 or mask.shape[-2:] != (sq, lk) or mask.shape[0] not in (1, b):
-            raise ValueError("mask must be additive fp16 [B, (1,) Sq, Lk] with a contiguous last dim")
+        if mask.dim() == 3:
+            mask = mask[:, None]
+        if mask.dtype != torch.float16 or mask.dim() != 4 or mask.stride(-1) != 1 or mask.shape[-2:] != (sq, lk) \
+                or mask.shape[0] not in (1, b) or mask.shape[1] not in (1, hq):
+            raise ValueError("mask must be additive fp16 [B, (1 | Hq,) Sq, Lk] with a contiguous last dim")
         m_sb = mask.stride(0) if mask.shape[0] == b else 0
-        m_sq = mask.stride(1)
+        m_sh = mask.stride(1) if mask.shape[1] == hq and hq > 1 else 0
+        m_sq = mask.stride(2)
+    _check_alibi(alibi, hq)
     rc = lib().bigdl_attn_prefill(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(mask), b, hq, hkv, sq, lk, d,
                                   q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
-                                  v.stride(0), v.stride(1), v.stride(2), out.stride(0), out.stride(1), m_sb, m_sq,
-                                  float(scale), float(softcap or 0.0), int(bool(causal)), int(window or 0),
+                                  v.stride(0), v.stride(1), v.stride(2), out.stride(0), out.stride(1), m_sb, m_sq, m_sh,
+                                  _ptr(alibi), float(scale), float(softcap or 0.0), int(bool(causal)), int(window or 0),
                                   int(bool(v_transposed)), _stream())
     _check(rc, "attn_prefill")
     return out

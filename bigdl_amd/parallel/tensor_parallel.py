@@ -252,6 +252,9 @@ def shard_engine(engine, rank: int, world: int, group=None, fast_allreduce=None)
             lw.down = _shard_lin(lw.down, rank, world, "row")
     engine.cfg = dataclasses.replace(cfg, num_heads=cfg.num_heads // world, num_kv_heads=cfg.num_kv_heads // world,
                                      intermediate_size=cfg.intermediate_size // world)
+    if getattr(engine, "alibi", None) is not None:
+        per = cfg.num_heads // world
+        engine.alibi = engine.alibi[rank * per:(rank + 1) * per].contiguous()
     engine.tp_group = group if group is not None else dist.group.WORLD
     engine.tp_world = world
     if fast_allreduce is None:

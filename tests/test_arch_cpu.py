@@ -24,12 +24,14 @@ def _norm(x, w, eps):
     return x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps) * w
 
 
-def _attend(q, k, v):
-    """q [B,S,Hq,D], k/v [B,S,Hkv,D] -> [B,S,Hq*D], causal"""
+def _attend(q, k, v, bias=None):
+    """q [B,S,Hq,D], k/v [B,S,Hkv,D] -> [B,S,Hq*D], causal; bias: additive [Hq, 1, S]"""
     b, s, hq, d = q.shape
     g = hq // k.shape[2]
     q, k, v = q.transpose(1, 2), k.transpose(1, 2).repeat_interleave(g, 1), v.transpose(1, 2).repeat_interleave(g, 1)
     sc = q @ k.transpose(-1, -2) / math.sqrt(d)
+    if bias is not None:
+        sc = sc + bias
     sc = sc.masked_fill(torch.triu(torch.ones(s, s, dtype=torch.bool), 1), float("-inf"))
     return (torch.softmax(sc, -1) @ v).transpose(1, 2).reshape(b, s, hq * d)
 
@@ -159,7 +161,7 @@ def qwen_forward(cfg, sd, ids):
 
 
 # ---------------------------------------------------------------- llama-named families (baichuan2, internlm, minicpm)
-def llama_named_ckpt(kind):
+def llama_named_ckpt(kind, alibi=False):
     cfg = dict(model_type=kind, num_hidden_layers=L, hidden_size=H, intermediate_size=192, num_attention_heads=NH,
                rms_norm_eps=1e-6, vocab_size=V, max_position_embeddings=256)
     sd = {"model.embed_tokens.weight": _w(V, H, s=0.5), "model.norm.weight": 1 + _w(H), "lm_head.weight": _w(V, H)}
@@ -177,6 +179,9 @@ def llama_named_ckpt(kind):
         if kind == "internlm":
             sd[p + "self_attn.o_proj.bias"] = _w(H)
         sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"], sd[p + "mlp.down_proj.weight"] = _w(192, H), _w(192, H), _w(H, 192)
+    if kind == "baichuan" and alibi:
+        del cfg["max_position_embeddings"]   # the 13B configs carry model_max_length instead
+        cfg["model_max_length"] = 256
     if kind == "baichuan":
         cfg["vocab_size"] = 125696          # Baichuan2: NormHead
         sd["model.embed_tokens.weight"], sd["lm_head.weight"] = _w(125696, H, s=0.5), _w(125696, H)
@@ -203,7 +208,13 @@ def llama_named_forward(cfg, sd, ids):
         else:
             q, k, v = (x @ sd[p + f"self_attn.{n}_proj.weight"].t() + sd.get(p + f"self_attn.{n}_proj.bias", 0) for n in "qkv")
         q, k, v = (t.reshape(b, s, NH, D) for t in (q, k, v))
-        o = _attend(_rope_half(q), _rope_half(k), v) @ sd[p + "self_attn.o_proj.weight"].t() + sd.get(p + "self_attn.o_proj.bias", 0)
+        if "max_position_embeddings" not in cfg:
+            # Baichuan-13B: no rotary; bias = slope_h * key position (its _gen_alibi_mask), slopes 2^(-8 (h+1) / NH)
+            slopes = torch.tensor([2.0 ** (-8.0 * (j + 1) / NH) for j in range(NH)])
+            att = _attend(q, k, v, bias=slopes[:, None, None] * torch.arange(s)[None, None, :].float())
+        else:
+            att = _attend(_rope_half(q), _rope_half(k), v)
+        o = att @ sd[p + "self_attn.o_proj.weight"].t() + sd.get(p + "self_attn.o_proj.bias", 0)
         h = h + o * rs
         x = _norm(h, sd[p + "post_attention_layernorm.weight"], 1e-6)
         m = (F.silu(x @ sd[p + "mlp.gate_proj.weight"].t()) * (x @ sd[p + "mlp.up_proj.weight"].t())) @ sd[p + "mlp.down_proj.weight"].t()
@@ -222,6 +233,7 @@ CASES = {
     "internlm2": (internlm2_ckpt, internlm2_forward),
     "qwen": (qwen_ckpt, qwen_forward),
     "baichuan2": (lambda: llama_named_ckpt("baichuan"), llama_named_forward),
+    "baichuan2_13b": (lambda: llama_named_ckpt("baichuan", alibi=True), llama_named_forward),
     "internlm": (lambda: llama_named_ckpt("internlm"), llama_named_forward),
     "minicpm": (lambda: llama_named_ckpt("minicpm"), llama_named_forward),
 }

@@ -17,7 +17,7 @@ def _helpers():
     return mod
 
 
-@pytest.mark.parametrize("case", ["chatglm3", "internlm2", "qwen", "minicpm", "internlm"])
+@pytest.mark.parametrize("case", ["chatglm3", "internlm2", "qwen", "minicpm", "internlm", "baichuan2_13b"])
 def test_engine_matches_cpu_forward(case):
     from bigdl_amd.models import arch
     T = _helpers()

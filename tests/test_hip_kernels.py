@@ -523,6 +523,69 @@ def test_attn_prefill_mask_softcap_window(hip):
     assert float(out[1, :20].abs().max()) == 0.0
 
 
+def _alibi_slopes(n):
+    base = 2.0 ** (-8.0 / n)
+    return torch.tensor([base ** (i + 1) for i in range(n)], dtype=torch.float32)
+
+
+@pytest.mark.parametrize("cfg", [(1, 8, 8, 128, 200, 200), (2, 8, 2, 64, 77, 77), (1, 4, 4, 128, 64, 300)])
+def test_attn_prefill_alibi_and_per_head_mask(hip, cfg):
+    """ALiBi slopes inside the kernel == the same bias passed as a per-head additive mask == fp32 reference."""
+    b, hq, hkv, d, sq, lk = cfg
+    torch.manual_seed(33)
+    q = torch.randn(b, hq, sq, d, device="cuda").half()
+    k, v = (torch.randn(b, hkv, lk, d, device="cuda").half() for _ in range(2))
+    slopes = _alibi_slopes(hq).cuda()
+    qi = torch.arange(sq, device="cuda")[:, None] + (lk - sq)
+    ki = torch.arange(lk, device="cuda")[None]
+    bias = (slopes[:, None, None] * (ki - qi).float()[None])[None].expand(b, hq, sq, lk)
+    scale = d ** -0.5
+    ref = _sdpa_ref(q, k, v, scale, True, mask=bias)
+    out = hip.attn_prefill(q, k, v, scale=scale, causal=True, alibi=slopes)
+    torch.testing.assert_close(out.float(), ref, rtol=2e-2, atol=2e-3)
+    out = hip.attn_prefill(q, k, v, scale=scale, causal=True, mask=bias.half().contiguous())
+    torch.testing.assert_close(out.float(), ref, rtol=2e-2, atol=4e-3)
+
+
+@pytest.mark.parametrize("fp8", [False, True])
+@pytest.mark.parametrize("cfg", [(1, 32, 32, 128, 1, 1000), (2, 8, 2, 128, 3, 255), (1, 4, 4, 64, 6, 254)])
+def test_attn_decode_alibi(hip, fp8, cfg):
+    """Decode attention with ALiBi slopes and an unrotated fused append (no RoPE table), against fp32 math on what the
+    cache holds."""
+    torch.manual_seed(34)
+    b, hq, hkv, d, q_len, past = cfg
+    lmax = 1280
+    ld = (hq + 2 * hkv) * d
+    kc = (torch.randn(b, hkv, lmax, d) * 0.5).half().cuda()
+    vc = (torch.randn(b, hkv, d, lmax) * 0.5).half().cuda()
+    if fp8:
+        kq, vq = torch.empty_like(kc, dtype=torch.uint8), torch.empty_like(vc, dtype=torch.uint8)
+        hip.to_e5m2(kc, kq)
+        hip.to_e5m2(vc, vq)
+        kc, vc = kq, vq
+    qkv = (torch.randn(b * q_len, ld) * 0.5).half().cuda()
+    past_len = torch.full((b,), past, dtype=torch.int32, device="cuda")
+    slopes = _alibi_slopes(hq).cuda()
+    scale = 1.0 / math.sqrt(d)
+    for splits in (1, 3):
+        ws = torch.empty(hip.attn_decode_ws_floats(b, hq, hkv, q_len, d, splits) + 16, dtype=torch.float32, device="cuda")
+        cnt = torch.zeros(b * hkv, dtype=torch.int32, device="cuda")
+        out = torch.empty(b * q_len, hq * d, dtype=torch.float16, device="cuda")
+        hip.attn_decode(qkv, kc, vc, past_len, out, ws, cnt, n_heads=hq, n_kv_heads=hkv, head_dim=d, q_len=q_len,
+                        batch=b, scale=scale, splits=splits, append=True, alibi=slopes)
+        total = past + q_len
+        kf = (kc.view(torch.float8_e5m2) if fp8 else kc).float()[:, :, :total]
+        vf = (vc.view(torch.float8_e5m2) if fp8 else vc).float()[:, :, :, :total].transpose(-1, -2)
+        x = qkv.float().view(b, q_len, hq + 2 * hkv, d).transpose(1, 2)
+        if not fp8:   # the appended rows are the new tokens' k / v
+            torch.testing.assert_close(kf[:, :, past:], x[:, hq:hq + hkv], rtol=1e-3, atol=1e-3)
+        qi = torch.arange(q_len, device="cuda")[:, None] + past
+        ki = torch.arange(total, device="cuda")[None]
+        bias = (slopes[:, None, None] * (ki - qi).float()[None])[None]
+        ref = _sdpa_ref(x[:, :hq], kf, vf, scale, True, mask=bias)
+        torch.testing.assert_close(out.float().view(b, q_len, hq * d), ref, rtol=1e-2, atol=1e-2)
+
+
 @pytest.mark.parametrize("fp8", [False, True])
 @pytest.mark.parametrize("cfg", [(1, 8, 2, 128, 100, 0, 128, False), (2, 4, 4, 64, 70, 0, 64, True), (1, 4, 2, 128, 37, 19, 64, False),
                                  (1, 4, 1, 96, 64, 0, 96, False)])
