@@ -18,13 +18,16 @@ static size_t t16_bytes(int n, int k) {   // sym_int4: 4-bit codes + fp16 scale 
 int main() {
   const int M = getenv("PROBE_M") ? atoi(getenv("PROBE_M")) : 1;          // rows of x (1..16)
   const bool with_norm = getenv("PROBE_NORM") != nullptr;                  // fused RMSNorm prologue as in the decode step
+  // bytes of weight copies the launches rotate over: 600 MB defeats every cache, ~150 MB stays in the memory-side
+  // cache, ~16 MB stays in the L2s
+  const double footprint = (getenv("PROBE_FOOTPRINT_MB") ? atof(getenv("PROBE_FOOTPRINT_MB")) : 600.0) * 1e6;
   struct Shape { const char* name; int n, k; bool gate_up; } shapes[] = {
       {"o", 4096, 4096, false}, {"qkv", 12288, 4096, false}, {"down", 4096, 11008, false}, {"gate_up", 11008, 4096, true}};
   hipStream_t st;
   CK(hipStreamCreate(&st));
   for (auto& sh : shapes) {
     const size_t nb = t16_bytes(sh.n, sh.k);
-    const int copies = (int)(600e6 / nb) < 2 ? 2 : (int)(600e6 / nb);
+    const int copies = (int)(footprint / nb) < 2 ? 2 : (int)(footprint / nb);
     std::vector<void*> ws(copies);
     for (auto& w : ws) { CK(hipMalloc(&w, nb)); CK(hipMemset(w, 0x11, nb)); }
     _Float16 *x, *out;
@@ -57,8 +60,8 @@ int main() {
       CK(hipEventElapsedTime(&ms, e0, e1));
       if (ms < best) best = ms;
     }
-    printf("{\"probe\": %d, \"M\": %d, \"norm\": %d, \"shape\": \"%s\", \"us\": %.2f, \"MB\": %.1f}\n", GEMV_PROBE, M,
-           (int)with_norm, sh.name, best * 1e3 / iters, nb * (sh.gate_up ? 2 : 1) / 1e6);
+    printf("{\"probe\": %d, \"M\": %d, \"norm\": %d, \"shape\": \"%s\", \"us\": %.2f, \"MB\": %.1f, \"copies\": %d}\n", GEMV_PROBE, M,
+           (int)with_norm, sh.name, best * 1e3 / iters, nb * (sh.gate_up ? 2 : 1) / 1e6, copies);
     for (auto& w : ws) CK(hipFree(w));
     CK(hipFree(x)); CK(hipFree(out));
   }

@@ -457,6 +457,9 @@ def native_engine_supported(model) -> bool:
     first = model.model.layers[0].self_attn
     if not (hasattr(first, "qkv_proj")):
         return False
+    from ..transformers.hybrid import HostResident
+    if any(isinstance(m, HostResident) for m in model.modules()):
+        return False          # CPU-GPU hybrid placement runs on the module path
     hd = getattr(cfg, "head_dim", None) or cfg.hidden_size // cfg.num_attention_heads
     if hd not in (64, 96, 128, 256):
         return False

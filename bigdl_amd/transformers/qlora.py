@@ -318,6 +318,20 @@ class PeftModelForCausalLM(nn.Module):
             if isinstance(m, LoraLayer):
                 m.disable_adapters = disabled
 
+    def disable_adapter(self):
+        """Context manager: run the frozen base model (PEFT's ``with model.disable_adapter():``; the implicit
+        reference model of DPO)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def _ctx():
+            self.disable_adapter_layers(True)
+            try:
+                yield
+            finally:
+                self.disable_adapter_layers(False)
+        return _ctx()
+
     def gradient_checkpointing_enable(self, *a, **k):
         return self.base_model.gradient_checkpointing_enable(*a, **k)
 
