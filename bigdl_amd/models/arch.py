@@ -65,8 +65,8 @@ def _llama_keys(cfg: dict, sd: StateDict, dc: DecoderConfig, *, qkv: Optional[st
 
 
 def _base_config(cfg: dict, model_type: str, **over) -> DecoderConfig:
-    heads = _get(cfg, "num_attention_heads", "n_head")
-    hidden = _get(cfg, "hidden_size", "n_embd")
+    heads = _get(cfg, "num_attention_heads", "n_head", "n_heads", default=over.get("num_heads"))
+    hidden = _get(cfg, "hidden_size", "n_embd", "d_model", default=over.get("hidden_size"))
     kw = dict(vocab_size=_get(cfg, "vocab_size", "padded_vocab_size"), hidden_size=hidden,
               intermediate_size=_get(cfg, "intermediate_size", "ffn_hidden_size", default=0),
               num_layers=_get(cfg, "num_hidden_layers", "num_layers", "n_layer"), num_heads=heads,
@@ -195,9 +195,390 @@ def convert_llama_like(cfg: dict, sd: StateDict):
     return dc, _llama_keys(cfg, sd, dc)
 
 
+# ------------------------------------------------------------------------------------------------
+# LayerNorm families (HuggingFace has classes for them; the native engine is opt-in: ``native_engine=True`` or
+# BIGDL_NATIVE_ENGINE=1).  Reference forwards: models/gptneox.py, bloom.py, mpt.py, falcon.py, gpt2.py,
+# gptbigcode.py, phi.py, starcoder2.py, stablelm.py (attention rebinding per family; here one engine with flags).
+# ------------------------------------------------------------------------------------------------
+def _ln_config(cfg: dict, model_type: str, **over) -> DecoderConfig:
+    kw = dict(norm="layer", gated_mlp=False,
+              rms_eps=_get(cfg, "layer_norm_eps", "layer_norm_epsilon", "norm_eps", "norm_epsilon", default=1e-5))
+    kw.update(over)
+    return _base_config(cfg, model_type, **kw)
+
+
+def _deinterleave_qkv(w, heads, d):
+    """[heads, (q, k, v), d, ...] rows -> q | k | v"""
+    return w.view(heads, 3, d, *w.shape[1:]).transpose(0, 1).reshape(3 * heads * d, *w.shape[1:])
+
+
+def _grouped_qkv(w, hq, hkv, d):
+    """per kv head: its group of query heads, then k, then v  ->  q | k | v"""
+    g = hq // hkv
+    w = w.view(hkv, g + 2, d, *w.shape[1:])
+    tail = w.shape[3:]
+    return torch.cat([w[:, :g].reshape(hq * d, *tail), w[:, g].reshape(hkv * d, *tail), w[:, g + 1].reshape(hkv * d, *tail)], 0)
+
+
+def _put(out, key, sd, name, fn=None):
+    """copy ``name`` (+ ``.bias``) of the checkpoint to canonical ``key``"""
+    for suffix, ck in ((".weight", key), (".bias", key + ".bias")):
+        if name + suffix in sd:
+            t = sd[name + suffix]
+            out[ck] = fn(t) if fn is not None else t
+
+
+def _cfg_gpt_neox(cfg):
+    d = cfg["hidden_size"] // cfg["num_attention_heads"]
+    rp = cfg.get("rope_parameters") or {}
+    pct = _get(cfg, "rotary_pct", "partial_rotary_factor", default=rp.get("partial_rotary_factor", 0.25))
+    return _ln_config(cfg, "gpt_neox", act=_get(cfg, "hidden_act", default="gelu"),
+                      parallel_residual=bool(_get(cfg, "use_parallel_residual", default=True)),
+                      rot_dim=int(d * pct) if pct != 1.0 else None,
+                      rope_theta=float(_get(cfg, "rotary_emb_base", "rope_theta", default=rp.get("rope_theta", 10000.0))))
+
+
+def convert_gpt_neox(cfg: dict, sd: StateDict):
+    """GPT-NeoX / Pythia / RedPajama / dolly-v2 (reference models/gptneox.py:35-151): per-head interleaved
+    ``query_key_value``, partial rotate-half rotary, parallel residual with two LayerNorms."""
+    dc = _cfg_gpt_neox(cfg)
+    out = {"embed": sd["gpt_neox.embed_in.weight"]}
+    out["lm_head"] = sd.get("embed_out.weight", sd.get("lm_head.weight", out["embed"]))
+    _put(out, "final_norm", sd, "gpt_neox.final_layer_norm")
+    for i in range(dc.num_layers):
+        p = f"gpt_neox.layers.{i}."
+        _put(out, f"L{i}.qkv", sd, p + "attention.query_key_value", lambda t: _deinterleave_qkv(t, dc.num_heads, dc.head_dim))
+        _put(out, f"L{i}.o", sd, p + "attention.dense")
+        _put(out, f"L{i}.input_norm", sd, p + "input_layernorm")
+        _put(out, f"L{i}.post_norm", sd, p + "post_attention_layernorm")
+        _put(out, f"L{i}.up", sd, p + "mlp.dense_h_to_4h")
+        _put(out, f"L{i}.down", sd, p + "mlp.dense_4h_to_h")
+    return dc, out
+
+
+def _cfg_bloom(cfg):
+    return _ln_config(cfg, "bloom", act="gelu_tanh", alibi=True, intermediate_size=4 * _get(cfg, "hidden_size", "n_embed"),
+                      hidden_size=_get(cfg, "hidden_size", "n_embed"), tie_word_embeddings=True)
+
+
+def convert_bloom(cfg: dict, sd: StateDict):
+    """BLOOM (reference models/bloom.py:60-208): ALiBi, LayerNorm on the embedding, interleaved qkv, tanh-GELU."""
+    if _get(cfg, "apply_residual_connection_post_layernorm", default=False):
+        raise NotImplementedError("bloom with apply_residual_connection_post_layernorm")
+    dc = _cfg_bloom(cfg)
+    pre = "transformer." if "transformer.word_embeddings.weight" in sd else ""
+    out = {"embed": sd[pre + "word_embeddings.weight"]}
+    out["lm_head"] = sd.get("lm_head.weight", out["embed"])
+    _put(out, "embed_norm", sd, pre + "word_embeddings_layernorm")
+    _put(out, "final_norm", sd, pre + "ln_f")
+    for i in range(dc.num_layers):
+        p = f"{pre}h.{i}."
+        _put(out, f"L{i}.qkv", sd, p + "self_attention.query_key_value", lambda t: _deinterleave_qkv(t, dc.num_heads, dc.head_dim))
+        _put(out, f"L{i}.o", sd, p + "self_attention.dense")
+        _put(out, f"L{i}.input_norm", sd, p + "input_layernorm")
+        _put(out, f"L{i}.post_norm", sd, p + "post_attention_layernorm")
+        _put(out, f"L{i}.up", sd, p + "mlp.dense_h_to_4h")
+        _put(out, f"L{i}.down", sd, p + "mlp.dense_4h_to_h")
+    return dc, out
+
+
+def _mpt_slopes(n_heads: int, bias_max: float = 8.0):
+    n2 = 2 ** math.ceil(math.log2(n_heads))
+    sl = [1.0 / 2.0 ** ((i + 1) * bias_max / n2) for i in range(n2)]
+    if n2 != n_heads:
+        sl = (sl[1::2] + sl[::2])[:n_heads]
+    return tuple(sl)
+
+
+def _cfg_mpt(cfg):
+    att = cfg.get("attn_config") or {}
+    if att.get("qk_ln") or att.get("clip_qkv") or not att.get("alibi", True):
+        raise NotImplementedError("mpt with qk_ln / clip_qkv / learned positions")
+    heads, hidden = cfg["n_heads"], cfg["d_model"]
+    return _ln_config(cfg, "mpt", act="gelu", alibi=True, alibi_slopes=_mpt_slopes(heads, att.get("alibi_bias_max", 8)),
+                      hidden_size=hidden, num_heads=heads, num_kv_heads=heads, head_dim=hidden // heads,
+                      num_layers=cfg["n_layers"], intermediate_size=int(cfg.get("expansion_ratio", 4) * hidden),
+                      max_position=cfg.get("max_seq_len", 2048), tie_word_embeddings=True,
+                      attn_scale=att.get("softmax_scale"), rms_eps=float(cfg.get("layer_norm_epsilon", 1e-5)))
+
+
+def convert_mpt(cfg: dict, sd: StateDict):
+    """MPT (reference models/mpt.py:29-151): ALiBi with mpt's slope ordering, bias-free LayerNorm, ``Wqkv`` = q | k | v."""
+    dc = _cfg_mpt(cfg)
+    out = {"embed": sd["transformer.wte.weight"]}
+    out["lm_head"] = sd.get("lm_head.weight", out["embed"])
+    _put(out, "final_norm", sd, "transformer.norm_f")
+    for i in range(dc.num_layers):
+        p = f"transformer.blocks.{i}."
+        _put(out, f"L{i}.qkv", sd, p + "attn.Wqkv")
+        _put(out, f"L{i}.o", sd, p + "attn.out_proj")
+        _put(out, f"L{i}.input_norm", sd, p + "norm_1")
+        _put(out, f"L{i}.post_norm", sd, p + "norm_2")
+        _put(out, f"L{i}.up", sd, p + "ffn.up_proj")
+        _put(out, f"L{i}.down", sd, p + "ffn.down_proj")
+    return dc, out
+
+
+def _cfg_falcon(cfg):
+    heads = _get(cfg, "num_attention_heads", "n_head")
+    hidden = cfg["hidden_size"]
+    d = hidden // heads
+    new_arch = bool(cfg.get("new_decoder_architecture", False))
+    if new_arch:
+        nkv = _get(cfg, "num_kv_heads", default=heads)
+    else:
+        nkv = 1 if cfg.get("multi_query", True) else heads
+    alibi = bool(cfg.get("alibi", False))
+    over = {}
+    if alibi:      # falcon scales the ALiBi bias together with the scores: slope / sqrt(d)
+        over = dict(alibi=True, alibi_slopes=tuple((alibi_slopes(heads) / math.sqrt(d)).tolist()))
+    return _ln_config(cfg, "falcon", act=_get(cfg, "activation", default="gelu"), num_heads=heads, num_kv_heads=nkv, head_dim=d,
+                      num_layers=_get(cfg, "num_hidden_layers", "n_layer"),
+                      intermediate_size=_get(cfg, "ffn_hidden_size", default=4 * hidden),
+                      parallel_residual=new_arch or bool(cfg.get("parallel_attn", True)),
+                      max_position=_get(cfg, "max_position_embeddings", default=2048), **over)
+
+
+def convert_falcon(cfg: dict, sd: StateDict):
+    """Falcon 7B / 40B / 180B / RW (reference models/falcon.py): multi-query (q | k | v), grouped (new decoder
+    architecture: per kv group) or per-head interleaved (RW) fused qkv; parallel attention + MLP."""
+    dc = _cfg_falcon(cfg)
+    new_arch = bool(cfg.get("new_decoder_architecture", False))
+    out = {"embed": sd["transformer.word_embeddings.weight"]}
+    out["lm_head"] = sd.get("lm_head.weight", out["embed"])
+    _put(out, "final_norm", sd, "transformer.ln_f")
+    hq, hkv, d = dc.num_heads, dc.num_kv_heads, dc.head_dim
+    for i in range(dc.num_layers):
+        p = f"transformer.h.{i}."
+        if new_arch:
+            fn = lambda t: _grouped_qkv(t, hq, hkv, d)      # noqa: E731
+        elif hkv == 1:
+            fn = None
+        else:
+            fn = lambda t: _deinterleave_qkv(t, hq, d)      # noqa: E731
+        _put(out, f"L{i}.qkv", sd, p + "self_attention.query_key_value", fn)
+        _put(out, f"L{i}.o", sd, p + "self_attention.dense")
+        if p + "ln_attn.weight" in sd:
+            _put(out, f"L{i}.input_norm", sd, p + "ln_attn")
+            _put(out, f"L{i}.post_norm", sd, p + "ln_mlp")
+        else:
+            _put(out, f"L{i}.input_norm", sd, p + "input_layernorm")
+            if not dc.parallel_residual:
+                _put(out, f"L{i}.post_norm", sd, p + "post_attention_layernorm")
+        _put(out, f"L{i}.up", sd, p + "mlp.dense_h_to_4h")
+        _put(out, f"L{i}.down", sd, p + "mlp.dense_4h_to_h")
+    return dc, out
+
+
+def _cfg_gpt2(cfg):
+    hidden, heads = _get(cfg, "n_embd", "hidden_size"), _get(cfg, "n_head", "num_attention_heads")
+    if cfg.get("scale_attn_by_inverse_layer_idx") or cfg.get("reorder_and_upcast_attn"):
+        raise NotImplementedError("gpt2 with per-layer attention scaling")
+    return _ln_config(cfg, "gpt2", act=_get(cfg, "activation_function", default="gelu_new"), no_rope=True,
+                      hidden_size=hidden, num_heads=heads, num_kv_heads=heads, head_dim=hidden // heads,
+                      intermediate_size=_get(cfg, "n_inner", default=4 * hidden), max_position=_get(cfg, "n_positions", default=1024),
+                      tie_word_embeddings=True)
+
+
+def convert_gpt2(cfg: dict, sd: StateDict):
+    """GPT-2 (reference models/gpt2.py): learned positions, ``Conv1D`` weights stored [in, out]."""
+    dc = _cfg_gpt2(cfg)
+    pre = "transformer." if "transformer.wte.weight" in sd else ""
+    out = {"embed": sd[pre + "wte.weight"], "pos_embed": sd[pre + "wpe.weight"]}
+    out["lm_head"] = sd.get("lm_head.weight", out["embed"])
+    _put(out, "final_norm", sd, pre + "ln_f")
+    tr = lambda t: t.t().contiguous() if t.dim() == 2 else t      # noqa: E731
+    for i in range(dc.num_layers):
+        p = f"{pre}h.{i}."
+        _put(out, f"L{i}.qkv", sd, p + "attn.c_attn", tr)
+        _put(out, f"L{i}.o", sd, p + "attn.c_proj", tr)
+        _put(out, f"L{i}.input_norm", sd, p + "ln_1")
+        _put(out, f"L{i}.post_norm", sd, p + "ln_2")
+        _put(out, f"L{i}.up", sd, p + "mlp.c_fc", tr)
+        _put(out, f"L{i}.down", sd, p + "mlp.c_proj", tr)
+    return dc, out
+
+
+def _cfg_gpt_bigcode(cfg):
+    hidden, heads = cfg["n_embd"], cfg["n_head"]
+    return _ln_config(cfg, "gpt_bigcode", act=_get(cfg, "activation_function", default="gelu_pytorch_tanh"), no_rope=True,
+                      hidden_size=hidden, num_heads=heads, num_kv_heads=1 if cfg.get("multi_query", True) else heads,
+                      head_dim=hidden // heads, intermediate_size=_get(cfg, "n_inner", default=4 * hidden),
+                      max_position=_get(cfg, "n_positions", default=8192), tie_word_embeddings=True)
+
+
+def convert_gpt_bigcode(cfg: dict, sd: StateDict):
+    """StarCoder / SantaCoder (reference models/gptbigcode.py): learned positions, multi-query ``c_attn`` = q | k | v."""
+    dc = _cfg_gpt_bigcode(cfg)
+    out = {"embed": sd["transformer.wte.weight"], "pos_embed": sd["transformer.wpe.weight"]}
+    out["lm_head"] = sd.get("lm_head.weight", out["embed"])
+    _put(out, "final_norm", sd, "transformer.ln_f")
+    fn = None if dc.num_kv_heads == 1 else (lambda t: _deinterleave_qkv(t, dc.num_heads, dc.head_dim))
+    for i in range(dc.num_layers):
+        p = f"transformer.h.{i}."
+        _put(out, f"L{i}.qkv", sd, p + "attn.c_attn", fn)
+        _put(out, f"L{i}.o", sd, p + "attn.c_proj")
+        _put(out, f"L{i}.input_norm", sd, p + "ln_1")
+        _put(out, f"L{i}.post_norm", sd, p + "ln_2")
+        _put(out, f"L{i}.up", sd, p + "mlp.c_fc")
+        _put(out, f"L{i}.down", sd, p + "mlp.c_proj")
+    return dc, out
+
+
+def _cfg_opt(cfg):
+    if cfg.get("word_embed_proj_dim", cfg["hidden_size"]) != cfg["hidden_size"] or not cfg.get("do_layer_norm_before", True):
+        raise NotImplementedError("opt with projected embeddings / post-LayerNorm (opt-350m)")
+    return _ln_config(cfg, "opt", act=_get(cfg, "activation_function", default="relu"), no_rope=True, pos_offset=2,
+                      intermediate_size=cfg["ffn_dim"], tie_word_embeddings=True)
+
+
+def convert_opt(cfg: dict, sd: StateDict):
+    """OPT: learned positions with an index offset of 2, ReLU MLP, separate q / k / v with bias."""
+    dc = _cfg_opt(cfg)
+    pre = "model.decoder."
+    out = {"embed": sd[pre + "embed_tokens.weight"], "pos_embed": sd[pre + "embed_positions.weight"]}
+    out["lm_head"] = sd.get("lm_head.weight", out["embed"])
+    _put(out, "final_norm", sd, pre + "final_layer_norm")
+    for i in range(dc.num_layers):
+        p = f"{pre}layers.{i}."
+        out[f"L{i}.qkv"] = torch.cat([sd[p + f"self_attn.{n}_proj.weight"] for n in "qkv"], 0)
+        out[f"L{i}.qkv.bias"] = torch.cat([sd[p + f"self_attn.{n}_proj.bias"] for n in "qkv"], 0)
+        _put(out, f"L{i}.o", sd, p + "self_attn.out_proj")
+        _put(out, f"L{i}.input_norm", sd, p + "self_attn_layer_norm")
+        _put(out, f"L{i}.post_norm", sd, p + "final_layer_norm")
+        _put(out, f"L{i}.up", sd, p + "fc1")
+        _put(out, f"L{i}.down", sd, p + "fc2")
+    return dc, out
+
+
+def _partial_rot(cfg, d, default=1.0):
+    rp = cfg.get("rope_parameters") or {}
+    pct = _get(cfg, "partial_rotary_factor", "rope_pct", default=rp.get("partial_rotary_factor", default))
+    theta = float(_get(cfg, "rope_theta", default=rp.get("rope_theta", 10000.0)))
+    return (int(d * pct) if pct != 1.0 else None), theta
+
+
+def _sep_qkv(out, sd, p, i, names=("q_proj", "k_proj", "v_proj")):
+    out[f"L{i}.qkv"] = torch.cat([sd[p + n + ".weight"] for n in names], 0)
+    if p + names[0] + ".bias" in sd:
+        out[f"L{i}.qkv.bias"] = torch.cat([sd[p + n + ".bias"] for n in names], 0)
+
+
+def _cfg_phi(cfg):
+    if cfg.get("qk_layernorm"):
+        raise NotImplementedError("phi with qk_layernorm")
+    d = cfg["hidden_size"] // cfg["num_attention_heads"]
+    rot, theta = _partial_rot(cfg, d, 0.5)
+    return _ln_config(cfg, "phi", act=_get(cfg, "hidden_act", default="gelu_new"), parallel_residual=True, rot_dim=rot,
+                      rope_theta=theta)
+
+
+def convert_phi(cfg: dict, sd: StateDict):
+    """Phi-1 / 1.5 / 2 (reference models/phi.py:43-162): one LayerNorm feeds attention and MLP in parallel, partial
+    rotary, biases everywhere including the lm_head."""
+    dc = _cfg_phi(cfg)
+    out = {"embed": sd["model.embed_tokens.weight"]}
+    _put(out, "lm_head", sd, "lm_head")
+    _put(out, "final_norm", sd, "model.final_layernorm")
+    for i in range(dc.num_layers):
+        p = f"model.layers.{i}."
+        _sep_qkv(out, sd, p + "self_attn.", i)
+        _put(out, f"L{i}.o", sd, p + "self_attn.dense")
+        _put(out, f"L{i}.input_norm", sd, p + "input_layernorm")
+        _put(out, f"L{i}.up", sd, p + "mlp.fc1")
+        _put(out, f"L{i}.down", sd, p + "mlp.fc2")
+    return dc, out
+
+
+def _cfg_starcoder2(cfg):
+    rot, theta = _partial_rot(cfg, cfg["hidden_size"] // cfg["num_attention_heads"])
+    return _ln_config(cfg, "starcoder2", act=_get(cfg, "hidden_act", default="gelu_pytorch_tanh"), rot_dim=rot, rope_theta=theta,
+                      rms_eps=_get(cfg, "norm_epsilon", default=1e-5), sliding_window=int(cfg.get("sliding_window") or 0),
+                      tie_word_embeddings=bool(cfg.get("tie_word_embeddings", True)))
+
+
+def convert_starcoder2(cfg: dict, sd: StateDict):
+    """StarCoder2 (reference models/starcoder2.py:56-140): llama-shaped blocks with LayerNorm, biases, a plain
+    ``c_fc`` / ``c_proj`` MLP, grouped-query attention and a sliding window."""
+    dc = _cfg_starcoder2(cfg)
+    out = {"embed": sd["model.embed_tokens.weight"]}
+    out["lm_head"] = sd.get("lm_head.weight", out["embed"])
+    _put(out, "final_norm", sd, "model.norm")
+    for i in range(dc.num_layers):
+        p = f"model.layers.{i}."
+        _sep_qkv(out, sd, p + "self_attn.", i)
+        _put(out, f"L{i}.o", sd, p + "self_attn.o_proj")
+        _put(out, f"L{i}.input_norm", sd, p + "input_layernorm")
+        _put(out, f"L{i}.post_norm", sd, p + "post_attention_layernorm")
+        _put(out, f"L{i}.up", sd, p + "mlp.c_fc")
+        _put(out, f"L{i}.down", sd, p + "mlp.c_proj")
+    return dc, out
+
+
+def _cfg_stablelm(cfg):
+    if cfg.get("qk_layernorm"):
+        raise NotImplementedError("stablelm with per-head qk LayerNorm")
+    rot, theta = _partial_rot(cfg, cfg["hidden_size"] // cfg["num_attention_heads"], 0.25)
+    return _ln_config(cfg, "stablelm", act=_get(cfg, "hidden_act", default="silu"), gated_mlp=True, rot_dim=rot, rope_theta=theta,
+                      parallel_residual=bool(cfg.get("use_parallel_residual", False)))
+
+
+def convert_stablelm(cfg: dict, sd: StateDict):
+    """StableLM (reference models/stablelm.py:62-200): llama's gated MLP and module names with LayerNorm and
+    25 % rotary."""
+    dc = _cfg_stablelm(cfg)
+    out = {"embed": sd["model.embed_tokens.weight"], "lm_head": sd["lm_head.weight"]}
+    _put(out, "final_norm", sd, "model.norm")
+    for i in range(dc.num_layers):
+        p = f"model.layers.{i}."
+        _sep_qkv(out, sd, p + "self_attn.", i)
+        _put(out, f"L{i}.o", sd, p + "self_attn.o_proj")
+        _put(out, f"L{i}.input_norm", sd, p + "input_layernorm")
+        if not dc.parallel_residual:
+            _put(out, f"L{i}.post_norm", sd, p + "post_attention_layernorm")
+        for n in ("gate", "up", "down"):
+            _put(out, f"L{i}.{n}", sd, p + f"mlp.{n}_proj")
+    return dc, out
+
+
+def _cfg_gptj(cfg):
+    hidden, heads = cfg["n_embd"], cfg["n_head"]
+    d = hidden // heads
+    rot = cfg.get("rotary_dim") or d
+    return _ln_config(cfg, "gptj", act=_get(cfg, "activation_function", default="gelu_new"), parallel_residual=True,
+                      hidden_size=hidden, num_heads=heads, num_kv_heads=heads, head_dim=d, rot_dim=rot if rot != d else None,
+                      rope_interleaved=True, intermediate_size=_get(cfg, "n_inner", default=4 * hidden),
+                      max_position=_get(cfg, "n_positions", default=2048))
+
+
+def convert_gptj(cfg: dict, sd: StateDict):
+    """GPT-J (reference models/gptj.py): interleaved partial rotary, one LayerNorm for the parallel attention + MLP."""
+    dc = _cfg_gptj(cfg)
+    out = {"embed": sd["transformer.wte.weight"]}
+    _put(out, "lm_head", sd, "lm_head")
+    _put(out, "final_norm", sd, "transformer.ln_f")
+    for i in range(dc.num_layers):
+        p = f"transformer.h.{i}."
+        _sep_qkv(out, sd, p + "attn.", i)
+        _put(out, f"L{i}.o", sd, p + "attn.out_proj")
+        _put(out, f"L{i}.input_norm", sd, p + "ln_1")
+        _put(out, f"L{i}.up", sd, p + "mlp.fc_in")
+        _put(out, f"L{i}.down", sd, p + "mlp.fc_out")
+    return dc, out
+
+
+LN_CONVERTERS = {"gpt_neox": convert_gpt_neox, "bloom": convert_bloom, "mpt": convert_mpt, "falcon": convert_falcon,
+                 "gpt2": convert_gpt2, "gpt_bigcode": convert_gpt_bigcode, "opt": convert_opt, "phi": convert_phi,
+                 "starcoder2": convert_starcoder2, "stablelm": convert_stablelm, "gptj": convert_gptj}
+LN_CONFIGS = {"gpt_neox": _cfg_gpt_neox, "bloom": _cfg_bloom, "mpt": _cfg_mpt, "falcon": _cfg_falcon, "gpt2": _cfg_gpt2,
+              "gpt_bigcode": _cfg_gpt_bigcode, "opt": _cfg_opt, "phi": _cfg_phi, "starcoder2": _cfg_starcoder2,
+              "stablelm": _cfg_stablelm, "gptj": _cfg_gptj}
+
+
 ARCH_CONVERTERS: Dict[str, Callable[[dict, StateDict], Tuple[DecoderConfig, StateDict]]] = {
     "chatglm": convert_chatglm, "baichuan": convert_baichuan, "qwen": convert_qwen, "internlm": convert_internlm,
     "internlm2": convert_internlm2, "minicpm": convert_minicpm, "aquila": convert_llama_like, "yi": convert_llama_like,
+    **LN_CONVERTERS,
 }
 
 
@@ -234,8 +615,16 @@ def reference_forward(dc: DecoderConfig, sd: StateDict, ids: torch.Tensor, past=
         b = sd.get(name + ".bias")
         return y if b is None else y + b.float()
 
-    def norm(x, w):
+    def norm(x, name):
+        w, nb = sd[name], sd.get(name + ".bias")
+        if dc.norm == "layer":
+            return F.layer_norm(x, (x.shape[-1],), w.float(), None if nb is None else nb.float(), dc.rms_eps)
         return x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + dc.rms_eps) * (w.float() + dc.norm_offset)
+
+    def mlp(i, x):
+        if dc.gated_mlp:
+            return lin(f"L{i}.down", act(lin(f"L{i}.gate", x)) * lin(f"L{i}.up", x))
+        return lin(f"L{i}.down", act(lin(f"L{i}.up", x)))
 
     b, s = ids.shape
     hq, hkv, d = dc.num_heads, dc.num_kv_heads, dc.head_dim
@@ -244,16 +633,23 @@ def reference_forward(dc: DecoderConfig, sd: StateDict, ids: torch.Tensor, past=
     p0 = 0 if not past else past[0][0].shape[2]
     pos = torch.arange(p0, p0 + s)
     h = sd["embed"][ids].float() * dc.embed_scale
+    if "pos_embed" in sd:
+        h = h + sd["pos_embed"][pos + dc.pos_offset].float()
+    if "embed_norm" in sd:
+        h = norm(h, "embed_norm")
+    slopes = None
+    if dc.alibi:
+        slopes = torch.tensor(dc.alibi_slopes, dtype=torch.float32) if dc.alibi_slopes else alibi_slopes(hq)
     act = _ACTS[dc.act]
     scale = dc.attn_scale if dc.attn_scale is not None else 1.0 / math.sqrt(d)
     new_past = []
     for i in range(dc.num_layers):
-        x = norm(h, sd[f"L{i}.input_norm"])
+        x = norm(h, f"L{i}.input_norm")
         qkv = lin(f"L{i}.qkv", x)
         q = qkv[..., : hq * d].view(b, s, hq, d).transpose(1, 2)
         k = qkv[..., hq * d:(hq + hkv) * d].view(b, s, hkv, d).transpose(1, 2)
         v = qkv[..., (hq + hkv) * d:].view(b, s, hkv, d).transpose(1, 2)
-        if not dc.alibi:
+        if not (dc.alibi or dc.no_rope):
             q, k = _rope(q, pos, inv, rot, dc.rope_interleaved, scaling), _rope(k, pos, inv, rot, dc.rope_interleaved, scaling)
         if past:
             k, v = torch.cat([past[i][0], k], 2), torch.cat([past[i][1], v], 2)
@@ -263,13 +659,18 @@ def reference_forward(dc: DecoderConfig, sd: StateDict, ids: torch.Tensor, past=
         L = k.shape[2]
         rel = torch.arange(L)[None] - (p0 + torch.arange(s))[:, None]
         if dc.alibi:
-            sc = sc + alibi_slopes(hq)[None, :, None, None] * rel.float()
+            sc = sc + slopes[None, :, None, None] * rel.float()
         sc = sc.masked_fill(rel > 0, float("-inf"))
+        if dc.sliding_window:
+            sc = sc.masked_fill(rel <= -dc.sliding_window, float("-inf"))
         a = (torch.softmax(sc, -1) @ vv).transpose(1, 2).reshape(b, s, hq * d)
+        if dc.parallel_residual:
+            x2 = norm(h, f"L{i}.post_norm") if f"L{i}.post_norm" in sd else x
+            h = h + lin(f"L{i}.o", a) + mlp(i, x2)
+            continue
         h = h + lin(f"L{i}.o", a)
-        x = norm(h, sd[f"L{i}.post_norm"])
-        h = h + lin(f"L{i}.down", act(lin(f"L{i}.gate", x)) * lin(f"L{i}.up", x))
-    logits = lin("lm_head", norm(h, sd["final_norm"])) * dc.logit_scale
+        h = h + mlp(i, norm(h, f"L{i}.post_norm"))
+    logits = lin("lm_head", norm(h, "final_norm")) * dc.logit_scale
     return logits, new_past
 
 
@@ -308,12 +709,16 @@ def build_engine(dc: DecoderConfig, qsd: dict, device="cuda"):
         return Lin(w, None if b is None else b.to(dev))
 
     def vec(name):
-        return qsd[name].to(dev, torch.float16).contiguous()
+        return qsd[name].to(dev, torch.float16).contiguous() if name in qsd else None
 
     layers = [LayerWeights(input_norm=vec(f"L{i}.input_norm"), qkv=lin(f"L{i}.qkv"), o=lin(f"L{i}.o"),
-                           post_norm=vec(f"L{i}.post_norm"), gate=lin(f"L{i}.gate"), up=lin(f"L{i}.up"),
-                           down=lin(f"L{i}.down")) for i in range(dc.num_layers)]
-    return NativeDecoder(dc, vec("embed"), layers, vec("final_norm"), lin("lm_head"), device=dev)
+                           post_norm=vec(f"L{i}.post_norm"), gate=lin(f"L{i}.gate") if dc.gated_mlp else None,
+                           up=lin(f"L{i}.up"), down=lin(f"L{i}.down"), input_norm_b=vec(f"L{i}.input_norm.bias"),
+                           post_norm_b=vec(f"L{i}.post_norm.bias"), window=dc.sliding_window)
+              for i in range(dc.num_layers)]
+    embed_norm = (vec("embed_norm"), vec("embed_norm.bias")) if "embed_norm" in qsd else None
+    return NativeDecoder(dc, vec("embed"), layers, vec("final_norm"), lin("lm_head"), device=dev,
+                         final_norm_b=vec("final_norm.bias"), pos_embed=vec("pos_embed"), embed_norm=embed_norm)
 
 
 class NativeCausalLM:
@@ -444,6 +849,10 @@ def arch_config_only(cfg: dict) -> DecoderConfig:
     probe = {"chatglm": _probe_chatglm, "minicpm": _probe_minicpm}.get(mt)
     if probe is not None:
         return probe(cfg)
+    if mt in LN_CONFIGS:
+        return LN_CONFIGS[mt](cfg)
+    if mt == "baichuan":
+        return _base_config(cfg, "baichuan", alibi="max_position_embeddings" not in cfg)
     if mt == "qwen":
         return _base_config(cfg, "qwen", intermediate_size=cfg["intermediate_size"] // 2,
                             head_dim=_get(cfg, "kv_channels", default=cfg["hidden_size"] // cfg["num_attention_heads"]))
@@ -486,10 +895,16 @@ def load_checkpoint_tensors(path: str) -> StateDict:
     return sd
 
 
-def is_native_arch(config_dict: dict) -> bool:
-    """True when the checkpoint's model_type has a weight map here and HuggingFace has no built-in class for it."""
+def is_native_arch(config_dict: dict, opt_in: Optional[bool] = None) -> bool:
+    """True when the checkpoint's model_type has a weight map here and either HuggingFace has no built-in class for it
+    or the caller opted into the native engine (``native_engine=True`` / BIGDL_NATIVE_ENGINE=1) for a family that also
+    has a module path."""
     mt = config_dict.get("model_type")
     if mt not in ARCH_CONVERTERS:
         return False
+    if opt_in is None:
+        opt_in = os.environ.get("BIGDL_NATIVE_ENGINE") == "1"
+    if opt_in:
+        return True
     from transformers.models.auto.configuration_auto import CONFIG_MAPPING_NAMES
     return mt not in CONFIG_MAPPING_NAMES

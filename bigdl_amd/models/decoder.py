@@ -53,6 +53,12 @@ class DecoderConfig:
     rot_dim: Optional[int] = None     # partial rotary
     rope_interleaved: bool = False
     alibi: bool = False               # baichuan-13B / bloom / mpt: per-head linear position bias instead of RoPE
+    alibi_slopes: Optional[tuple] = None   # explicit per-head slopes (mpt's ordering, falcon's 1/sqrt(d) scaling)
+    norm: str = "rms"                 # "layer": LayerNorm with bias (gpt-neox, bloom, mpt, falcon, gpt2, opt, phi, ...)
+    gated_mlp: bool = True            # False: down(act(up(x)))
+    parallel_residual: bool = False   # h + attn(ln1(h)) + mlp(ln2(h))  (gpt-neox, falcon, phi, gpt-j)
+    no_rope: bool = False             # learned absolute positions (gpt2, gpt_bigcode, opt) or ALiBi
+    pos_offset: int = 0               # opt: the position table starts at index 2
     post_norms: bool = False          # gemma2: extra norms after attention / mlp
     model_type: str = "llama"
     # MoE
@@ -70,6 +76,11 @@ class DecoderConfig:
     @property
     def kv_size(self):
         return self.num_kv_heads * self.head_dim
+
+
+_ACT_FNS = {"silu": F.silu, "swish": F.silu, "gelu": F.gelu, "relu": F.relu,
+            "gelu_tanh": lambda x: F.gelu(x, approximate="tanh"), "gelu_pytorch_tanh": lambda x: F.gelu(x, approximate="tanh"),
+            "gelu_new": lambda x: F.gelu(x, approximate="tanh"), "gelu_fast": lambda x: F.gelu(x, approximate="tanh")}
 
 
 def alibi_slopes(n_heads: int) -> torch.Tensor:
@@ -171,7 +182,7 @@ class LayerWeights:
     input_norm: torch.Tensor
     qkv: Lin
     o: Lin
-    post_norm: torch.Tensor
+    post_norm: Optional[torch.Tensor]      # None: the MLP reads the input norm's output (shared LayerNorm)
     gate: Optional[Lin] = None
     up: Optional[Lin] = None
     down: Optional[Lin] = None
@@ -180,6 +191,8 @@ class LayerWeights:
     post_ffn_out_norm: Optional[torch.Tensor] = None
     moe: Optional[object] = None
     window: int = 0
+    input_norm_b: Optional[torch.Tensor] = None      # LayerNorm biases
+    post_norm_b: Optional[torch.Tensor] = None
 
 
 class KVCache:
@@ -236,12 +249,15 @@ class KVCache:
 
 class NativeDecoder:
     def __init__(self, cfg: DecoderConfig, embed: torch.Tensor, layers: list, final_norm: torch.Tensor, lm_head: Lin,
-                 device="cuda"):
+                 device="cuda", final_norm_b=None, pos_embed=None, embed_norm=None):
         self.cfg = cfg
         self.device = torch.device(device)
         self.embed = embed
         self.layers = layers
         self.final_norm = final_norm
+        self.final_norm_b = final_norm_b
+        self.pos_embed = pos_embed              # [max_pos (+ offset), hidden] learned absolute positions
+        self.embed_norm = embed_norm            # (weight, bias) LayerNorm right after the embedding (bloom)
         self.lm_head = lm_head
         inv, scaling = compute_inv_freq(cfg, self.device)
         self.inv_freq = inv
@@ -251,7 +267,10 @@ class NativeDecoder:
         self._static = {}
         self.attn_scale = cfg.attn_scale if cfg.attn_scale is not None else 1.0 / math.sqrt(cfg.head_dim)
         # ALiBi slopes of this rank's heads (tensor parallelism re-slices them)
-        self.alibi = alibi_slopes(cfg.num_heads).to(self.device) if cfg.alibi else None
+        self.alibi = None
+        if cfg.alibi:
+            sl = torch.tensor(cfg.alibi_slopes, dtype=torch.float32) if cfg.alibi_slopes else alibi_slopes(cfg.num_heads)
+            self.alibi = sl.to(self.device).contiguous()
         self.use_graph = True
         if os.environ.get("BIGDL_PREFILL_DENSE_CACHE") == "1":
             Lin.cache_dense = True
@@ -282,10 +301,11 @@ class NativeDecoder:
         cfg = self.cfg
         pos = torch.arange(max_pos, device=self.device, dtype=torch.float32)
         ang = pos[:, None] * self.inv_freq[None].float()
-        if cfg.alibi:
+        self.no_rope = cfg.alibi or cfg.no_rope
+        if self.no_rope:
             ang = torch.zeros_like(ang)          # identity rotation: the prompt path only appends k / v
         self.rope_table = torch.stack([ang.cos(), ang.sin()], -1).mul_(self.rope_scaling_factor).contiguous()
-        self.fused_rope = cfg.alibi or cfg.rope_interleaved or (cfg.rot_dim or cfg.head_dim) == cfg.head_dim
+        self.fused_rope = self.no_rope or cfg.rope_interleaved or (cfg.rot_dim or cfg.head_dim) == cfg.head_dim
 
     # ------------------------------------------------------------------ prefill (eager)
     def _linear_dense(self, x, lin: Lin):
@@ -307,9 +327,31 @@ class NativeDecoder:
                 torch.distributed.all_reduce(t, group=self.tp_group)
         return t
 
-    def _norm(self, x, w, residual=None, res_out=None):
+    def _norm(self, x, w, b=None, residual=None, res_out=None):
         from ..ops import hip
+        if self.cfg.norm == "layer":
+            return hip.layer_norm(x, w, b, self.cfg.rms_eps)
         return hip.rms_norm(x, w, self.cfg.rms_eps, offset=self.cfg.norm_offset, residual=residual, res_out=res_out)
+
+    def _embed_extras(self, h, pos):
+        """learned absolute positions and the embedding LayerNorm; h [rows, hidden], pos [rows] (device, int64)"""
+        from ..ops import hip
+        if self.pos_embed is not None:
+            h = h + F.embedding(pos + self.cfg.pos_offset, self.pos_embed)
+        if self.embed_norm is not None:
+            h = hip.layer_norm(h, self.embed_norm[0], self.embed_norm[1], self.cfg.rms_eps)
+        return h
+
+    def _mlp_dense(self, x, lw):
+        from ..ops import hip
+        cfg = self.cfg
+        if cfg.gated_mlp:
+            g = self._linear_dense(x, lw.gate)
+            u = self._linear_dense(x, lw.up)
+            hip.act_mul(g, u, cfg.act)
+        else:
+            g = _ACT_FNS[cfg.act](self._linear_dense(x, lw.up))
+        return self._tp_reduce(self._linear_dense(g, lw.down))
 
     @torch.no_grad()
     def prefill(self, input_ids: torch.Tensor, last_only: bool = True, slot: Optional[int] = None):
@@ -330,9 +372,10 @@ class NativeDecoder:
             h = h * cfg.embed_scale
         h = h.reshape(b * s, cfg.hidden_size)
         pos = torch.arange(past, past + s, device=self.device)[None].expand(b, s)
+        h = self._embed_extras(h, pos.reshape(-1))
         hq, hkv, d = cfg.num_heads, cfg.num_kv_heads, cfg.head_dim
         for li, lw in enumerate(self.layers):
-            x = self._norm(h, lw.input_norm)
+            x = self._norm(h, lw.input_norm, lw.input_norm_b)
             qkv = self._linear_dense(x, lw.qkv).view(b, s, (hq + 2 * hkv) * d)
             q = qkv[..., : hq * d].view(b, s, hq, d).transpose(1, 2)
             k = qkv[..., hq * d: (hq + hkv) * d].view(b, s, hkv, d).transpose(1, 2)
@@ -355,15 +398,16 @@ class NativeDecoder:
             o = self._tp_reduce(self._linear_dense(attn, lw.o))
             if lw.post_attn_out_norm is not None:
                 o = self._norm(o, lw.post_attn_out_norm)
+            if cfg.parallel_residual:
+                x2 = x if lw.post_norm is None else self._norm(h, lw.post_norm, lw.post_norm_b)
+                h = h + o + self._mlp_dense(x2, lw)
+                continue
             h = h + o
-            x = self._norm(h, lw.pre_ffn_norm if lw.pre_ffn_norm is not None else lw.post_norm)
+            x = self._norm(h, lw.pre_ffn_norm if lw.pre_ffn_norm is not None else lw.post_norm, lw.post_norm_b)
             if lw.moe is not None:
                 m = lw.moe.forward_dense(x, self)
             else:
-                g = self._linear_dense(x, lw.gate)
-                u = self._linear_dense(x, lw.up)
-                hip.act_mul(g, u, cfg.act)
-                m = self._tp_reduce(self._linear_dense(g, lw.down))
+                m = self._mlp_dense(x, lw)
             if lw.post_ffn_out_norm is not None:
                 m = self._norm(m, lw.post_ffn_out_norm)
             h = h + m
@@ -376,7 +420,7 @@ class NativeDecoder:
         h = h.view(b, s, -1)
         if last_only:
             h = h[:, -1:, :]
-        x = self._norm(h.reshape(-1, cfg.hidden_size), self.final_norm)
+        x = self._norm(h.reshape(-1, cfg.hidden_size), self.final_norm, self.final_norm_b)
         logits = self._linear_dense(x, self.lm_head).float().view(b, -1, cfg.vocab_size)
         return self._finish_logits(logits)
 
@@ -517,8 +561,18 @@ class NativeDecoder:
             h.copy_(F.embedding(st["tokens"].view(-1), self.embed) * cfg.embed_scale)
         else:
             torch.index_select(self.embed, 0, st["tokens"].view(-1), out=h)      # gather straight into the residual stream
+        layer_norm = cfg.norm == "layer"
+        if self.pos_embed is not None or self.embed_norm is not None:
+            pos = cache.past_len.to(torch.int64)[:, None] + torch.arange(q_len, device=self.device)[None]
+            h.copy_(self._embed_extras(h, pos.reshape(-1)))
         for li, lw in enumerate(self.layers):
-            self._gemv(h, lw.qkv, qkv, gamma=lw.input_norm)
+            if layer_norm:
+                x1 = hip.layer_norm(h, lw.input_norm, lw.input_norm_b, cfg.rms_eps)
+                self._gemv(x1, lw.qkv, qkv)
+                if cfg.parallel_residual:      # the MLP input is taken before the attention output lands in h
+                    x2 = x1 if lw.post_norm is None else hip.layer_norm(h, lw.post_norm, lw.post_norm_b, cfg.rms_eps)
+            else:
+                self._gemv(h, lw.qkv, qkv, gamma=lw.input_norm)
             if not self.fused_rope:
                 hip.rope_append(qkv, cache.k[li], cache.v[li], cache.past_len, self.inv_freq, n_heads=cfg.num_heads,
                                 n_kv_heads=cfg.num_kv_heads, head_dim=cfg.head_dim, q_len=q_len, batch=batch,
@@ -528,8 +582,8 @@ class NativeDecoder:
                             n_heads=cfg.num_heads, n_kv_heads=cfg.num_kv_heads, head_dim=cfg.head_dim, q_len=q_len,
                             batch=batch, scale=self.attn_scale, splits=st["splits"], softcap=cfg.attn_softcap,
                             window=lw.window,
-                            rope_table=self.rope_table if self.fused_rope and self.alibi is None else None,
-                            append=self.alibi is not None, alibi=self.alibi,
+                            rope_table=self.rope_table if self.fused_rope and not self.no_rope else None,
+                            append=self.no_rope, alibi=self.alibi,
                             interleaved=cfg.rope_interleaved, defer_combine=st["defer"] and lw.o.fused)
             att_partials = st["att_partials"] if st["defer"] and lw.o.fused else None
             if lw.post_attn_out_norm is None and self.tp_group is None:
@@ -543,8 +597,18 @@ class NativeDecoder:
             if lw.moe is not None:
                 lw.moe.forward_decode(self, h, ffn_norm)
                 continue
-            a = act[:, : lw.gate.n]
-            self._gemv(h, lw.gate, a, gamma=ffn_norm, w2=lw.up, act=cfg.act)
+            a = act[:, : lw.up.n]
+            if layer_norm:
+                if not cfg.parallel_residual:
+                    x2 = hip.layer_norm(h, ffn_norm, lw.post_norm_b, cfg.rms_eps)
+                if cfg.gated_mlp:
+                    self._gemv(x2, lw.gate, a, w2=lw.up, act=cfg.act)
+                else:
+                    self._gemv(x2, lw.up, a, act=cfg.act)
+            elif cfg.gated_mlp:
+                self._gemv(h, lw.gate, a, gamma=ffn_norm, w2=lw.up, act=cfg.act)
+            else:
+                self._gemv(h, lw.up, a, gamma=ffn_norm, act=cfg.act)
             if lw.post_ffn_out_norm is None and self.tp_group is None:
                 self._gemv(a, lw.down, h, residual=h)
             else:
@@ -552,7 +616,10 @@ class NativeDecoder:
                 if lw.post_ffn_out_norm is not None:
                     hip.rms_norm(tmp, lw.post_ffn_out_norm, cfg.rms_eps, offset=cfg.norm_offset, out=tmp)
                 h.add_(tmp)
-        self._gemv(h, self.lm_head, st["logits"], gamma=self.final_norm)
+        if layer_norm:
+            self._gemv(hip.layer_norm(h, self.final_norm, self.final_norm_b, cfg.rms_eps), self.lm_head, st["logits"])
+        else:
+            self._gemv(h, self.lm_head, st["logits"], gamma=self.final_norm)
         if cfg.logit_scale != 1.0 or cfg.final_softcap > 0:
             st["logits"].copy_(self._finish_logits(st["logits"]))
         if chain and q_len == 1:

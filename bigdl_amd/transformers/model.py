@@ -190,10 +190,11 @@ class _BaseAutoModelClass:
                 invalidInputError(False, "model_hub='modelscope' needs the `modelscope` package")
         config_dict, _ = PretrainedConfig.get_config_dict(pretrained_model_name_or_path)
         bigdl_transformers_low_bit = config_dict.pop("bigdl_transformers_low_bit", False)
+        native_engine = kwargs.pop("native_engine", None)
         if not bigdl_transformers_low_bit and isinstance(pretrained_model_name_or_path, str) \
                 and os.path.isdir(pretrained_model_name_or_path):
             from ..models.arch import NativeCausalLM, is_native_arch
-            if is_native_arch(config_dict):
+            if is_native_arch(config_dict, native_engine):
                 # families HuggingFace only has as remote code (chatglm, baichuan, qwen v1, internlm, minicpm, ...):
                 # loaded through their weight-name map into the native engine, no remote code is executed
                 low_bit = kwargs.get("load_in_low_bit") or "sym_int4"
