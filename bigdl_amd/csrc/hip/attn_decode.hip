@@ -42,6 +42,7 @@ struct AttnArgs {
   int window;            // sliding window (0 = off): keys < pos - window + 1 are masked
   int rot, interleaved, rope_max_pos;
   int defer_combine;     // 1: stop after writing the per-split partials (the consumer GEMV combines them)
+  int nchunk, gchunk;    // query-head chunks per kv head and heads per chunk (1, Hq/Hkv unless Hq/Hkv > 32)
 };
 
 constexpr float NEG_BIG = -1.0e30f;
@@ -67,9 +68,13 @@ __global__ __launch_bounds__(ATT_NW * 64) void attn_decode_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int rr = lane & 15, g = lane >> 4;
-  const int split = blockIdx.x, hkv = blockIdx.y, b = blockIdx.z;
+  const int split = blockIdx.x, b = blockIdx.z;
+  // a kv head's group of query heads is processed in `nchunk` chunks of at most `gchunk` heads, one workgroup column
+  // each (multi-query models with 48 / 71 query heads per kv head do not fit one 32-row tile pair)
   const int G = a.Hq / a.Hkv;
-  const int rows = G * a.q_cnt;
+  const int hkv = blockIdx.y / a.nchunk, g0 = (blockIdx.y % a.nchunk) * a.gchunk;
+  const int Gc = min(a.gchunk, G - g0);
+  const int rows = Gc * a.q_cnt;
   // merge buffers: per wave m,l per row, and O rows (only `rows` rows are ever touched)
   float* s_m = (float*)smem;                       // [NW][RT*16]
   float* s_l = s_m + NW * RT * 16;                 // [NW][RT*16]
@@ -143,7 +148,7 @@ __global__ __launch_bounds__(ATT_NW * 64) void attn_decode_kernel(AttnArgs a) {
 #pragma unroll
   for (int t = 0; t < RT; ++t) {
     const int row = 16 * t + rr;
-    const int tok = a.q_off + row / G, gq = row % G;
+    const int tok = a.q_off + row / Gc, gq = g0 + row % Gc;
     const bool valid = row < rows;
     slope[t] = a.alibi != nullptr ? a.alibi[hkv * G + gq] * 1.4426950408889634f : 0.0f;
     const int tokidx = b * a.q_total + tok;
@@ -252,7 +257,7 @@ __global__ __launch_bounds__(ATT_NW * 64) void attn_decode_kernel(AttnArgs a) {
       if (a.mask) {
         const int row = 16 * t + rr;
         if (row < rows) {
-          const _Float16* mp = a.mask + ((int64_t)b * a.q_total + a.q_off + row / G) * a.mask_ld + kfirst;
+          const _Float16* mp = a.mask + ((int64_t)b * a.q_total + a.q_off + row / Gc) * a.mask_ld + kfirst;
 #pragma unroll
           for (int q = 0; q < 8; ++q)
             if (kfirst + q < a.mask_ld) sv[q] += (float)mp[q] * 1.4426950408889634f;
@@ -309,7 +314,7 @@ __global__ __launch_bounds__(ATT_NW * 64) void attn_decode_kernel(AttnArgs a) {
   }
   __syncthreads();
 
-  const int bh = b * a.Hkv + hkv;
+  const int bh = b * gridDim.y + blockIdx.y;
   const bool single = a.splits == 1;
   float* wsp = a.ws + ((int64_t)bh * a.splits + split) * (RT * 16) * (D + 4);
   // thread -> (row, d-chunk): merge the NW wavefronts; with one split this is the final result
@@ -328,7 +333,7 @@ __global__ __launch_bounds__(ATT_NW * 64) void attn_decode_kernel(AttnArgs a) {
     }
     if (single) {
       const float inv = lt > 0.0f ? 1.0f / lt : 0.0f;
-      const int tok = a.q_off + row / G, gq = row % G;
+      const int tok = a.q_off + row / Gc, gq = g0 + row % Gc;
       _Float16* dst = a.out + (int64_t)(b * a.q_total + tok) * (a.Hq * D) + (hkv * G + gq) * D + d4;
       half4 hv = {(_Float16)(acc[0] * inv), (_Float16)(acc[1] * inv), (_Float16)(acc[2] * inv), (_Float16)(acc[3] * inv)};
       *(half4*)dst = hv;
@@ -372,7 +377,7 @@ __global__ __launch_bounds__(ATT_NW * 64) void attn_decode_kernel(AttnArgs a) {
       acc += *(const float4v*)(src + d4) * f;
     }
     const float inv = lt > 0.0f ? 1.0f / lt : 0.0f;
-    const int tok = a.q_off + row / G, gq = row % G;
+    const int tok = a.q_off + row / Gc, gq = g0 + row % Gc;
     _Float16* dst = a.out + (int64_t)(b * a.q_total + tok) * (a.Hq * D) + (hkv * G + gq) * D + d4;
     half4 hv = {(_Float16)(acc[0] * inv), (_Float16)(acc[1] * inv), (_Float16)(acc[2] * inv), (_Float16)(acc[3] * inv)};
     *(half4*)dst = hv;
@@ -381,9 +386,9 @@ __global__ __launch_bounds__(ATT_NW * 64) void attn_decode_kernel(AttnArgs a) {
 
 template <int D, bool FP8>
 static int launch_rt(const AttnArgs& a, hipStream_t st) {
-  const int rows = (a.Hq / a.Hkv) * a.q_cnt;
+  const int rows = a.gchunk * a.q_cnt;
   const int rt = (rows + 15) / 16;
-  const dim3 grid(a.splits, a.Hkv, a.B), block(ATT_NW * 64);
+  const dim3 grid(a.splits, a.Hkv * a.nchunk, a.B), block(ATT_NW * 64);
   auto smem = [&](int RT) { return (size_t)(ATT_NW * RT * 16 * 2 + ATT_NW * rows * D) * 4 + 16; };
   // more than 64 KiB of dynamic LDS has to be requested explicitly (once per kernel)
   static bool attr1 = false, attr2 = false;
@@ -495,7 +500,10 @@ extern "C" int bigdl_attn_decode(void* qkv, void* kc, void* vc, void* out, float
   if (B <= 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv || q_cnt <= 0 || q_off < 0 || q_off + q_cnt > q_total || splits <= 0 ||
       (Lmax & 255) || (ld & 7)) return -1;
   if (((uintptr_t)qkv | (uintptr_t)kc | (uintptr_t)vc | (uintptr_t)ws | (uintptr_t)out) & 15) return -1;
-  if ((Hq / Hkv) * q_cnt > 32) return -4;
+  const int G = Hq / Hkv;
+  const int nchunk = (G + 31) / 32, gchunk = (G + nchunk - 1) / nchunk;
+  if (gchunk * q_cnt > 32) return -4;
+  if (nchunk > 1 && defer_combine) return -4;     // the o_proj-side combine indexes the workspace per kv head
   if (rope) {
     if (rot <= 0 || rot > D || (rot & 7) || rope_max_pos <= 0) return -1;
     if (!interleaved && rot != D) return -6;
@@ -507,6 +515,7 @@ extern "C" int bigdl_attn_decode(void* qkv, void* kc, void* vc, void* out, float
   a.rot = rope ? rot : (append ? 0 : -1); a.interleaved = interleaved;
   a.B = B; a.Hq = Hq; a.Hkv = Hkv; a.ld = ld; a.Lmax = Lmax; a.splits = splits; a.window = window;
   a.q_total = q_total; a.q_off = q_off; a.q_cnt = q_cnt; a.defer_combine = defer_combine;
+  a.nchunk = nchunk; a.gchunk = gchunk;
 #define DISPATCH_D(DD)                                                   \
   case DD: return fp8 ? launch_rt<DD, true>(a, stream) : launch_rt<DD, false>(a, stream);
   switch (D) {
@@ -521,9 +530,16 @@ extern "C" int bigdl_attn_decode(void* qkv, void* kc, void* vc, void* out, float
 
 // workspace floats needed by bigdl_attn_decode
 extern "C" int64_t bigdl_attn_decode_ws_floats(int B, int Hq, int Hkv, int q_len, int D, int splits) {
-  const int rows = (Hq / Hkv) * q_len > 32 ? 32 : (Hq / Hkv) * q_len;
+  const int G = Hq / Hkv;
+  const int nchunk = (G + 31) / 32, gchunk = (G + nchunk - 1) / nchunk;
+  const int rows = gchunk * q_len > 32 ? 32 : gchunk * q_len;
   const int rt = (rows + 15) / 16;
-  return (int64_t)B * Hkv * splits * rt * 16 * (D + 4);
+  return (int64_t)B * Hkv * nchunk * splits * rt * 16 * (D + 4);
+}
+
+// int32 arrival counters needed by bigdl_attn_decode (zero-initialized by the caller, left zero by every launch)
+extern "C" int bigdl_attn_decode_counters(int B, int Hq, int Hkv) {
+  return B * Hkv * ((Hq / Hkv + 31) / 32);
 }
 
 extern "C" int bigdl_rope_append(void* qkv, void* kc, void* vc, const int* past_len, const float* inv_freq,

@@ -41,6 +41,13 @@ struct GemvArgs {
   const _Float16* gamma;  // [K] RMSNorm weight or null
   float eps;
   float gamma_offset;     // gemma-style (1 + w): 1.0f, else 0.0f
+  // optional LayerNorm prologue (needs gamma): with c1 = W . gamma and c2 = W . beta precomputed per output column,
+  //   W . ((x - mean) * rs * gamma + beta) = rs * (W . (x * gamma)) - rs * mean * c1 + c2,
+  // so the kernel stages x * gamma exactly as for RMSNorm and also accumulates the row sums.  ln2_* belong to w2.
+  const float* ln_c1;
+  const float* ln_c2;
+  const float* ln2_c1;
+  const float* ln2_c2;
   int M, N, K;
   int ldx, ldo;
   int act;
@@ -186,10 +193,11 @@ __global__ __launch_bounds__(NW * 64) void gemv_t16_kernel(GemvArgs a) {
   // weight tiles fetched per wavefront per round trip (per stream): 16 B x 64 lanes x 4 = 4 KiB in flight
   constexpr int U = (GATE_UP || NW > 8) ? 2 : 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // carve: red | ssq | lut | xsum | x
+  // carve: red | ssq | sum | lut | xsum | x
   float* red = (float*)smem;                                  // [NW][NACC*MT][64][4]
   float* ssq_sh = red + GEMV_NW * NACC * MT * 256;            // [MT*16] sum of squares per row
-  _Float16* nf4_lut = (_Float16*)(ssq_sh + MT * 16);          // [64*16] (nf4 only)
+  float* sum_sh = ssq_sh + MT * 16;                           // [MT*16] sum per row (LayerNorm prologue)
+  _Float16* nf4_lut = (_Float16*)(sum_sh + MT * 16);          // [64*16] (nf4 only)
   // formats with a block minimum: sum of (scaled) x over every 32-block, [Kp/32 + XTAIL/32][MT*16 rows], so that the
   // "+ min * sum(x)" term is one 16-byte LDS read per MFMA step instead of a cross-lane reduction of the fragment
   float* xsum = (float*)(nf4_lut + (QT == Q_NF4 ? 64 * 16 : 0));
@@ -244,12 +252,13 @@ __global__ __launch_bounds__(NW * 64) void gemv_t16_kernel(GemvArgs a) {
 
   // ---- 2. stage x (optionally scaled by the RMSNorm gamma) in LDS, all wavefronts together ----
   const bool norm = a.gamma != nullptr;
+  const bool lnorm = a.ln_c1 != nullptr;
   const _Float16* lut = nullptr;
   if constexpr (QT == Q_NF4) {
     fill_nf4_banked((uint32_t*)nf4_lut, threadIdx.x, GEMV_NW * 64);
     lut = (const _Float16*)((const uint32_t*)nf4_lut + (lane & 31));
   }
-  if (threadIdx.x < MT * 16) ssq_sh[threadIdx.x] = 0.0f;
+  if (threadIdx.x < 2 * MT * 16) ssq_sh[threadIdx.x] = 0.0f;   // ssq_sh and sum_sh are adjacent
   if constexpr (XSUM) {
     const float4v z4 = {0, 0, 0, 0};
     for (int i = threadIdx.x; i < (xsum_floats >> 2); i += GEMV_NW * 64) *(float4v*)(xsum + 4 * i) = z4;
@@ -288,6 +297,10 @@ __global__ __launch_bounds__(NW * 64) void gemv_t16_kernel(GemvArgs a) {
           if (norm) {
             const float ssq = wave_sum(frag_sumsq(v));
             if (lane == 0) atomicAdd(&ssq_sh[m0 + u], ssq);
+            if (lnorm) {
+              const float sm = wave_sum(frag_sum(v));
+              if (lane == 0) atomicAdd(&sum_sh[m0 + u], sm);
+            }
             v = v * g8;
           }
           if constexpr (XSUM) {
@@ -493,12 +506,19 @@ __global__ __launch_bounds__(NW * 64) void gemv_t16_kernel(GemvArgs a) {
     for (int q = 0; q < 4; ++q) {
       const int m = 16 * j + 4 * g + q;
       if (m >= a.M || n >= a.N) continue;
-      float rs = 1.0f;
-      if (norm) rs = rsqrtf(ssq_sh[m] / (float)a.K + a.eps);
+      float rs = 1.0f, mean = 0.0f;
+      if (lnorm) {
+        mean = sum_sh[m] / (float)a.K;
+        rs = rsqrtf(fmaxf(ssq_sh[m] / (float)a.K - mean * mean, 0.0f) + a.eps);
+      } else if (norm) {
+        rs = rsqrtf(ssq_sh[m] / (float)a.K + a.eps);
+      }
       float v = o[0][q] * rs;
+      if (lnorm) v += a.ln_c2[n] - rs * mean * a.ln_c1[n];
       if (a.bias) v += (float)((const _Float16*)a.bias)[n];
       if constexpr (GATE_UP) {
         float u = o[1][q] * rs;
+        if (lnorm) u += a.ln2_c2[n] - rs * mean * a.ln2_c1[n];
         if (a.bias2) u += (float)((const _Float16*)a.bias2)[n];
         v = act_apply(a.act, v) * u;
       } else {
@@ -543,7 +563,7 @@ static int launch_x(const GemvArgs& a, hipStream_t st) {
   const int Kp = (a.K + 127) / 128 * 128;
   const size_t xbytes = (size_t)a.M * (Kp + XTAIL + XPAD) * 2;
   auto fixed = [&](int nw, bool xlds = true) {
-    return (size_t)nw * (GATE_UP ? 2 : 1) * MT * 256 * 4 + MT * 16 * 4 + (QT == Q_NF4 ? 64 * 16 * 2 : 0) +
+    return (size_t)nw * (GATE_UP ? 2 : 1) * MT * 256 * 4 + 2 * MT * 16 * 4 + (QT == Q_NF4 ? 64 * 16 * 2 : 0) +
            (has_min_of(QT) && xlds ? (size_t)(Kp / 32 + XTAIL / 32) * MT * 16 * 4 : 0);
   };
   // 16 wavefronts when the grid is small (about one workgroup per CU) and every wavefront still gets
@@ -556,6 +576,7 @@ static int launch_x(const GemvArgs& a, hipStream_t st) {
              (a.M <= 8 && xbytes <= GEMV_XLDS_LIMIT_FEW_ROWS && gemv_allow_lds(gemv_t16_kernel<QT, MT, GATE_UP, true, 8>, fixed(8) + xbytes))) {
     hipLaunchKernelGGL((gemv_t16_kernel<QT, MT, GATE_UP, true, 8>), grid, dim3(512), fixed(8) + xbytes, st, a);
   } else {
+    if (a.ln_c1 != nullptr) return -7;     // the LayerNorm prologue lives in the LDS staging of x
     hipLaunchKernelGGL((gemv_t16_kernel<QT, MT, GATE_UP, false, 8>), grid, dim3(512), fixed(8, false), st, a);
   }
   return HIP_CHECK_LAUNCH();

@@ -38,12 +38,19 @@ static int dispatch(const GemvArgs& a, int qtype, hipStream_t stream) {
 
 // Returns 0 on success; negative = rejected on the host before any launch.
 // M <= 64 (<= 32 with w2).  x fp16 with ldx % 8 == 0 and 16-byte aligned rows; K % 32 == 0.
-extern "C" int bigdl_gemv_lowbit(const void* x, const void* w, const void* w2, void* out, const void* bias,
-                                 const void* bias2, const void* residual, const void* gamma, float eps,
-                                 float gamma_offset, int M, int N, int K, int ldx, int ldo, int qtype, int act,
-                                 int out_type, const float* att_ws, int att_splits, int att_D, int att_G, int att_Hkv,
-                                 int att_qlen, int att_rows_alloc, hipStream_t stream) {
+static int gemv_lowbit_impl(const void* x, const void* w, const void* w2, void* out, const void* bias,
+                            const void* bias2, const void* residual, const void* gamma, float eps,
+                            float gamma_offset, int M, int N, int K, int ldx, int ldo, int qtype, int act,
+                            int out_type, const float* att_ws, int att_splits, int att_D, int att_G, int att_Hkv,
+                            int att_qlen, int att_rows_alloc, const float* ln_c1, const float* ln_c2,
+                            const float* ln2_c1, const float* ln2_c2, hipStream_t stream) {
   qtype = t16_kernel_qtype(qtype);
+  if (ln_c1 != nullptr) {
+    // LayerNorm prologue: gamma and both per-column vectors (and those of w2), no gemma offset, x staged in LDS
+    if (!gamma || !ln_c2 || att_ws || gamma_offset != 0.0f || (w2 != nullptr) != (ln2_c1 != nullptr) ||
+        (ln2_c1 != nullptr) != (ln2_c2 != nullptr))
+      return -7;
+  }
   if (M <= 0 || N <= 0 || K <= 0 || (K & 31) || (ldx & 7) || ((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return -1;
   if (gamma && ((uintptr_t)gamma & 15)) return -1;
   if (w2 && ((uintptr_t)w2 & 15)) return -1;
@@ -62,8 +69,31 @@ extern "C" int bigdl_gemv_lowbit(const void* x, const void* w, const void* w2, v
   a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldo = ldo; a.act = act; a.out_type = out_type;
   a.att_ws = att_ws; a.att_splits = att_splits; a.att_D = att_D; a.att_G = att_G; a.att_Hkv = att_Hkv;
   a.att_qlen = att_qlen; a.att_rows_alloc = att_rows_alloc;
+  a.ln_c1 = ln_c1; a.ln_c2 = ln_c2; a.ln2_c1 = ln2_c1; a.ln2_c2 = ln2_c2;
   a.slot_expert = nullptr; a.slot_scale = nullptr; a.n_total = 0; a.slot_xdiv = 1; a.n_slots = 0;
   return dispatch(a, qtype, stream);
+}
+
+extern "C" int bigdl_gemv_lowbit(const void* x, const void* w, const void* w2, void* out, const void* bias,
+                                 const void* bias2, const void* residual, const void* gamma, float eps,
+                                 float gamma_offset, int M, int N, int K, int ldx, int ldo, int qtype, int act,
+                                 int out_type, const float* att_ws, int att_splits, int att_D, int att_G, int att_Hkv,
+                                 int att_qlen, int att_rows_alloc, hipStream_t stream) {
+  return gemv_lowbit_impl(x, w, w2, out, bias, bias2, residual, gamma, eps, gamma_offset, M, N, K, ldx, ldo, qtype, act,
+                          out_type, att_ws, att_splits, att_D, att_G, att_Hkv, att_qlen, att_rows_alloc, nullptr, nullptr,
+                          nullptr, nullptr, stream);
+}
+
+// y = act(LayerNorm(x; gamma, beta) @ W^T + bias) ...: gamma is the LayerNorm weight, ln_c1[n] = sum_k W[n,k] gamma[k]
+// and ln_c2[n] = sum_k W[n,k] beta[k] (fp32 [N], computed once per weight; ln2_* for w2).  Only for row counts whose
+// x fits the LDS staging budget (returns -7 otherwise).
+extern "C" int bigdl_gemv_lowbit_ln(const void* x, const void* w, const void* w2, void* out, const void* bias,
+                                    const void* bias2, const void* residual, const void* gamma, float eps, int M, int N,
+                                    int K, int ldx, int ldo, int qtype, int act, int out_type, const float* ln_c1,
+                                    const float* ln_c2, const float* ln2_c1, const float* ln2_c2, hipStream_t stream) {
+  if (!ln_c1) return -1;
+  return gemv_lowbit_impl(x, w, w2, out, bias, bias2, residual, gamma, eps, 0.0f, M, N, K, ldx, ldo, qtype, act, out_type,
+                          nullptr, 0, 0, 0, 0, 1, 0, ln_c1, ln_c2, ln2_c1, ln2_c2, stream);
 }
 
 // Routed-expert products for decode: for every slot s < n_slots (token-major, `slot_xdiv` consecutive slots share
@@ -88,6 +118,7 @@ extern "C" int bigdl_gemv_lowbit_moe(const void* x, const void* w, const void* w
   a.residual = nullptr; a.gamma = (const _Float16*)gamma; a.eps = eps; a.gamma_offset = gamma_offset;
   a.M = 1; a.N = N; a.K = K; a.ldx = ldx; a.ldo = ldo; a.act = act; a.out_type = out_type;
   a.att_ws = nullptr; a.att_splits = 0; a.att_D = 0; a.att_G = 0; a.att_Hkv = 0; a.att_qlen = 1; a.att_rows_alloc = 0;
+  a.ln_c1 = nullptr; a.ln_c2 = nullptr; a.ln2_c1 = nullptr; a.ln2_c2 = nullptr;
   a.slot_expert = slot_expert; a.slot_scale = slot_scale; a.n_total = n_experts * N; a.slot_xdiv = slot_xdiv;
   a.n_slots = n_slots;
   return dispatch(a, qtype, stream);

@@ -159,6 +159,21 @@ class Lin:
     def nbytes(self):
         return self.w.numel() * self.w.element_size()
 
+    def ln_fold(self, gamma, beta):
+        """(W @ gamma, W @ beta) for the LayerNorm-folding GEMV, computed once per (weight, norm) pair."""
+        key = (gamma.data_ptr(), None if beta is None else beta.data_ptr())
+        if getattr(self, "_ln_key", None) != key:
+            from ..ops import hip
+            dense, keep = Lin.cache_dense, getattr(self, "_dense", None)
+            Lin.cache_dense = False                       # a transient dequantized copy, not the resident one
+            try:
+                self._ln, self._ln_key = hip.layer_norm_fold(self.dense(), gamma, beta), key
+            finally:
+                Lin.cache_dense = dense
+                if keep is not None:
+                    self._dense = keep
+        return self._ln
+
     # opt-in (NativeDecoder.dense_prefill_cache / BIGDL_PREFILL_DENSE_CACHE=1): keep the fp16 form of every weight
     # resident next to the low-bit one, so that large-M prefill GEMMs skip the dequantization pass (3.7 ms of an 18.6 ms
     # first token for Llama-2-7B) at the price of 2 bytes per weight of HBM -- affordable on a 288 GB GPU for serving
@@ -510,7 +525,8 @@ class NativeDecoder:
             "next": torch.zeros(m, dtype=torch.int64, device=dev),
             "ws": torch.empty(hip.attn_decode_ws_floats(batch, cfg.num_heads, cfg.num_kv_heads, q_len, cfg.head_dim, splits) + 16,
                               dtype=torch.float32, device=dev),
-            "counters": torch.zeros(batch * cfg.num_kv_heads, dtype=torch.int32, device=dev),
+            "counters": torch.zeros(hip.attn_decode_counters(batch, cfg.num_heads, cfg.num_kv_heads), dtype=torch.int32,
+                                    device=dev),
             "splits": splits,
         }
         # with several KV splits the cross-split combine is folded into the o_proj GEMV's x staging
@@ -521,11 +537,20 @@ class NativeDecoder:
         st["att_partials"] = (st["ws"], splits, cfg.head_dim, g, cfg.num_kv_heads, q_len, (rows + 15) // 16 * 16)
         return st
 
-    def _gemv(self, x, lin: Lin, out, *, gamma=None, residual=None, w2: Lin = None, act=None, att_partials=None):
-        """out = epilogue(norm?(x) @ W^T): fused kernel for T16 weights, unfused torch ops otherwise."""
+    def _gemv(self, x, lin: Lin, out, *, gamma=None, residual=None, w2: Lin = None, act=None, att_partials=None,
+              beta=False):
+        """out = epilogue(norm?(x) @ W^T): fused kernel for T16 weights, unfused torch ops otherwise.  ``beta``
+        (a tensor or None, instead of the default False) selects LayerNorm(gamma, beta) as the norm."""
         from ..ops import hip
         cfg = self.cfg
         m = x.shape[0]
+        if beta is not False:
+            if lin.fused and (w2 is None or w2.fused) and m <= GEMV_MAX_ROWS and hip.gemv_x_in_lds(m, lin.k):
+                return hip.gemv_lowbit_ln(x, lin.w, lin.qtype, lin.n, lin.k, gamma, lin.ln_fold(gamma, beta),
+                                          w2=None if w2 is None else w2.w, ln2=None if w2 is None else w2.ln_fold(gamma, beta),
+                                          bias=lin.bias, bias2=None if w2 is None else w2.bias, residual=residual,
+                                          eps=cfg.rms_eps, act=act, out=out)
+            x, gamma = hip.layer_norm(x, gamma, beta, cfg.rms_eps), None
         if lin.fused and (w2 is None or w2.fused) and m > GEMV_MAX_ROWS and att_partials is None:
             # batched decode (17 .. 64 rows): RMSNorm kernel + MFMA GEMM with the epilogue fused
             xin = x if gamma is None else hip.rms_norm(x, gamma, cfg.rms_eps, offset=cfg.norm_offset)
@@ -553,6 +578,14 @@ class NativeDecoder:
         out.copy_(y)
         return out
 
+    def _mlp_in(self, h, lw, a, gamma, beta):
+        """a = act(gate(norm(h))) * up(norm(h))  or  act(up(norm(h)))"""
+        cfg = self.cfg
+        if cfg.gated_mlp:
+            self._gemv(h, lw.gate, a, gamma=gamma, beta=beta, w2=lw.up, act=cfg.act)
+        else:
+            self._gemv(h, lw.up, a, gamma=gamma, beta=beta, act=cfg.act)
+
     def _decode_body(self, st, batch: int, q_len: int, chain: bool):
         from ..ops import hip
         cfg, cache = self.cfg, self.cache
@@ -567,10 +600,7 @@ class NativeDecoder:
             h.copy_(self._embed_extras(h, pos.reshape(-1)))
         for li, lw in enumerate(self.layers):
             if layer_norm:
-                x1 = hip.layer_norm(h, lw.input_norm, lw.input_norm_b, cfg.rms_eps)
-                self._gemv(x1, lw.qkv, qkv)
-                if cfg.parallel_residual:      # the MLP input is taken before the attention output lands in h
-                    x2 = x1 if lw.post_norm is None else hip.layer_norm(h, lw.post_norm, lw.post_norm_b, cfg.rms_eps)
+                self._gemv(h, lw.qkv, qkv, gamma=lw.input_norm, beta=lw.input_norm_b)
             else:
                 self._gemv(h, lw.qkv, qkv, gamma=lw.input_norm)
             if not self.fused_rope:
@@ -586,6 +616,13 @@ class NativeDecoder:
                             append=self.no_rope, alibi=self.alibi,
                             interleaved=cfg.rope_interleaved, defer_combine=st["defer"] and lw.o.fused)
             att_partials = st["att_partials"] if st["defer"] and lw.o.fused else None
+            if layer_norm and cfg.parallel_residual:
+                # the MLP reads the layer input: its first GEMV runs before o_proj adds the attention output to h
+                a = act[:, : lw.up.n]
+                if lw.post_norm is None:
+                    self._mlp_in(h, lw, a, lw.input_norm, lw.input_norm_b)
+                else:
+                    self._mlp_in(h, lw, a, lw.post_norm, lw.post_norm_b)
             if lw.post_attn_out_norm is None and self.tp_group is None:
                 self._gemv(attn, lw.o, h, residual=h, att_partials=att_partials)
             else:
@@ -598,17 +635,8 @@ class NativeDecoder:
                 lw.moe.forward_decode(self, h, ffn_norm)
                 continue
             a = act[:, : lw.up.n]
-            if layer_norm:
-                if not cfg.parallel_residual:
-                    x2 = hip.layer_norm(h, ffn_norm, lw.post_norm_b, cfg.rms_eps)
-                if cfg.gated_mlp:
-                    self._gemv(x2, lw.gate, a, w2=lw.up, act=cfg.act)
-                else:
-                    self._gemv(x2, lw.up, a, act=cfg.act)
-            elif cfg.gated_mlp:
-                self._gemv(h, lw.gate, a, gamma=ffn_norm, w2=lw.up, act=cfg.act)
-            else:
-                self._gemv(h, lw.up, a, gamma=ffn_norm, act=cfg.act)
+            if not (layer_norm and cfg.parallel_residual):
+                self._mlp_in(h, lw, a, ffn_norm, lw.post_norm_b if layer_norm else False)
             if lw.post_ffn_out_norm is None and self.tp_group is None:
                 self._gemv(a, lw.down, h, residual=h)
             else:
@@ -616,10 +644,7 @@ class NativeDecoder:
                 if lw.post_ffn_out_norm is not None:
                     hip.rms_norm(tmp, lw.post_ffn_out_norm, cfg.rms_eps, offset=cfg.norm_offset, out=tmp)
                 h.add_(tmp)
-        if layer_norm:
-            self._gemv(hip.layer_norm(h, self.final_norm, self.final_norm_b, cfg.rms_eps), self.lm_head, st["logits"])
-        else:
-            self._gemv(h, self.lm_head, st["logits"], gamma=self.final_norm)
+        self._gemv(h, self.lm_head, st["logits"], gamma=self.final_norm, beta=self.final_norm_b if layer_norm else False)
         if cfg.logit_scale != 1.0 or cfg.final_softcap > 0:
             st["logits"].copy_(self._finish_logits(st["logits"]))
         if chain and q_len == 1:
@@ -819,11 +844,25 @@ def build_random_decoder(cfg: DecoderConfig, qtype: int = Q.SYM_INT4, device="cu
     def norm():
         return (1.0 + 0.02 * torch.randn(h, device=dev, generator=gen)).to(torch.float16) - cfg.norm_offset
 
+    layer_norm = cfg.norm == "layer"
+
+    def vec(n):        # biases of the LayerNorm families
+        return (0.02 * torch.randn(n, device=dev, generator=gen)).to(torch.float16) if layer_norm else None
+
+    def blin(n, k, qt=qtype):
+        l = lin(n, k, qt)
+        l.bias = vec(n)
+        return l
+
     embed = (torch.randn(cfg.vocab_size, h, device=dev, generator=gen) * 0.02).to(torch.float16)
     layers = []
     for _ in range(cfg.num_layers):
-        lw = LayerWeights(input_norm=norm(), qkv=lin(cfg.q_size + 2 * cfg.kv_size, h), o=lin(h, cfg.q_size),
-                          post_norm=norm())
+        lw = LayerWeights(input_norm=norm(), qkv=blin(cfg.q_size + 2 * cfg.kv_size, h), o=blin(h, cfg.q_size),
+                          post_norm=norm(), input_norm_b=vec(h), post_norm_b=vec(h))
+        if layer_norm and not cfg.gated_mlp:
+            lw.up, lw.down = blin(i, h), blin(h, i)
+            layers.append(lw)
+            continue
         if cfg.num_experts:
             from .moe import MoEWeights
             e, mi = cfg.num_experts, cfg.moe_intermediate_size
@@ -844,7 +883,11 @@ def build_random_decoder(cfg: DecoderConfig, qtype: int = Q.SYM_INT4, device="cu
             lw.gate, lw.up, lw.down = lin(i, h), lin(i, h), lin(h, i)
         layers.append(lw)
     lm = lin(cfg.vocab_size, h, lm_head_qtype or qtype)
-    return NativeDecoder(cfg, embed, layers, norm(), lm, device=device)
+    pos_embed = None
+    if cfg.no_rope and not cfg.alibi:
+        pos_embed = (torch.randn(cfg.max_position + cfg.pos_offset, h, device=dev, generator=gen) * 0.02).to(torch.float16)
+    return NativeDecoder(cfg, embed, layers, norm(), lm, device=device, final_norm_b=vec(h), pos_embed=pos_embed,
+                         embed_norm=(norm(), vec(h)) if cfg.model_type == "bloom" else None)
 
 
 MIXTRAL_8X7B = dict(vocab_size=32000, hidden_size=4096, intermediate_size=14336, num_layers=32, num_heads=32,
@@ -854,3 +897,15 @@ LLAMA2_7B = dict(vocab_size=32000, hidden_size=4096, intermediate_size=11008, nu
                  num_kv_heads=32, head_dim=128, rms_eps=1e-5, max_position=4096, model_type="llama")
 TINY_LLAMA = dict(vocab_size=32000, hidden_size=2048, intermediate_size=5632, num_layers=22, num_heads=32,
                   num_kv_heads=4, head_dim=64, rms_eps=1e-5, max_position=2048, model_type="llama")
+BLOOM_7B = dict(vocab_size=250880, hidden_size=4096, intermediate_size=16384, num_layers=30, num_heads=32, num_kv_heads=32,
+                head_dim=128, rms_eps=1e-5, max_position=2048, model_type="bloom", norm="layer", gated_mlp=False,
+                act="gelu_tanh", alibi=True, tie_word_embeddings=True)
+PYTHIA_6_9B = dict(vocab_size=50432, hidden_size=4096, intermediate_size=16384, num_layers=32, num_heads=32, num_kv_heads=32,
+                   head_dim=128, rms_eps=1e-5, max_position=2048, model_type="gpt_neox", norm="layer", gated_mlp=False,
+                   act="gelu", parallel_residual=True, rot_dim=32)
+FALCON_7B = dict(vocab_size=65024, hidden_size=4544, intermediate_size=18176, num_layers=32, num_heads=71, num_kv_heads=1,
+                 head_dim=64, rms_eps=1e-5, max_position=2048, model_type="falcon", norm="layer", gated_mlp=False,
+                 act="gelu", parallel_residual=True)
+STARCODER_15B = dict(vocab_size=49152, hidden_size=6144, intermediate_size=24576, num_layers=40, num_heads=48, num_kv_heads=1,
+                     head_dim=128, rms_eps=1e-5, max_position=8192, model_type="gpt_bigcode", norm="layer", gated_mlp=False,
+                     act="gelu_tanh", no_rope=True)

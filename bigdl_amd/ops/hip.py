@@ -37,9 +37,11 @@ def lib():
         L = ctypes.CDLL(str(_LIB_PATH))
         vp, i64, ci, cf = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
         L.bigdl_gemv_lowbit.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, cf, cf, ci, ci, ci, ci, ci, ci, ci, ci, vp, ci, ci, ci, ci, ci, ci, vp]
+        L.bigdl_gemv_lowbit_ln.argtypes = [vp] * 8 + [cf] + [ci] * 8 + [vp] * 5
         L.bigdl_attn_decode.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, ci, ci, ci, cf, cf] + [ci] * 14 + [vp]
         L.bigdl_attn_decode_ws_floats.argtypes = [ci] * 6
         L.bigdl_attn_decode_ws_floats.restype = i64
+        L.bigdl_attn_decode_counters.argtypes = [ci] * 3
         L.bigdl_rope_append.argtypes = [vp, vp, vp, vp, vp, vp, cf] + [ci] * 10 + [vp]
         L.bigdl_rms_norm.argtypes = [vp, vp, vp, vp, vp, i64, ci, i64, cf, cf, ci, vp]
         L.bigdl_layer_norm.argtypes = [vp, vp, vp, vp, i64, ci, i64, cf, ci, vp]
@@ -384,6 +386,65 @@ def rms_norm(x, weight, eps, *, residual=None, res_out=None, offset=0.0, out=Non
     return out
 
 
+def gemv_x_in_lds(m: int, k: int) -> bool:
+    """True when ``gemv_lowbit`` stages ``m`` rows of ``k`` features in LDS (the fused attention-combine and LayerNorm
+    prologues only exist on that path); mirrors the launcher's budget."""
+    xbytes = m * ((k + 127) // 128 * 128 + 136) * 2
+    return xbytes <= 48 * 1024 or (m <= 8 and xbytes <= 100 * 1024)
+
+
+def gemv_lowbit_ln(x, w, qtype, out_features, in_features, gamma, ln, *, w2=None, ln2=None, bias=None, bias2=None,
+                   residual=None, eps=1e-5, act=None, out=None):
+    """``y = act(LayerNorm(x; gamma, beta) @ dequant(w)^T + bias) [* (LayerNorm(x) @ dequant(w2)^T + bias2)] [+ residual]``
+    with the LayerNorm folded into the GEMV: ``ln = (c1, c2)`` are fp32 [N] vectors ``W @ gamma`` and ``W @ beta``
+    (``layer_norm_fold``).  fp16 in / out; ``gemv_x_in_lds(M, K)`` must hold."""
+    _need_cuda(x, w, w2, bias, bias2, residual, gamma, out, *ln, *(ln2 or ()))
+    m, k = x.shape
+    if x.dtype != torch.float16 or x.stride(1) != 1 or k != in_features or not gemv_x_in_lds(m, k):
+        raise ValueError("x must be fp16 [M, K] with contiguous rows that fit the LDS staging budget")
+    if qtype not in Q.T16_QTYPES:
+        raise ValueError(f"qtype {qtype} has no fused GEMV kernel")
+    if gamma.dtype != torch.float16 or gamma.numel() != k or not gamma.is_contiguous():
+        raise ValueError("gamma must be contiguous fp16 [in_features]")
+    for pair in (ln, ln2):
+        if pair is not None:
+            for t in pair:
+                if t.dtype != torch.float32 or t.numel() != out_features or not t.is_contiguous():
+                    raise ValueError("LayerNorm fold vectors must be contiguous fp32 [out_features]")
+    if (w2 is None) != (ln2 is None):
+        raise ValueError("w2 and ln2 go together")
+    from .host import device_nbytes
+    need = device_nbytes(qtype, out_features, in_features)
+    for ww in (w, w2):
+        if ww is not None and ww.numel() * ww.element_size() != need:
+            raise ValueError("weight buffer size does not match [out_features, in_features]")
+    for b in (bias, bias2):
+        if b is not None and (b.dtype != torch.float16 or b.numel() != out_features or not b.is_contiguous()):
+            raise ValueError("bias must be contiguous fp16 [out_features]")
+    if out is None:
+        out = torch.empty((m, out_features), dtype=torch.float16, device=x.device)
+    if out.shape != (m, out_features) or out.stride(1) != 1 or out.dtype not in _DT:
+        raise ValueError("bad out tensor")
+    if residual is not None and (residual.shape != out.shape or residual.dtype != out.dtype
+                                 or residual.stride() != out.stride()):
+        raise ValueError("residual must match out")
+    rc = lib().bigdl_gemv_lowbit_ln(_ptr(x), _ptr(w), _ptr(w2), _ptr(out), _ptr(bias), _ptr(bias2), _ptr(residual),
+                                    _ptr(gamma), eps, m, out_features, k, x.stride(0), out.stride(0), qtype, ACT[act],
+                                    _out_type(out.dtype), _ptr(ln[0]), _ptr(ln[1]), _ptr(ln2[0] if ln2 else None),
+                                    _ptr(ln2[1] if ln2 else None), _stream())
+    _check(rc, "gemv_lowbit_ln")
+    return out
+
+
+def layer_norm_fold(w_dense, gamma, beta):
+    """(W @ gamma, W @ beta) in fp32 for ``gemv_lowbit_ln``; ``w_dense`` is the dequantized [N, K] weight, so the
+    vectors match what the kernel multiplies with."""
+    w = w_dense.float()
+    c1 = (w @ gamma.float()).contiguous()
+    c2 = (w @ beta.float()).contiguous() if beta is not None else torch.zeros_like(c1)
+    return c1, c2
+
+
 def layer_norm(x, weight, bias, eps):
     _need_cuda(x, weight, bias)
     h = x.shape[-1]
@@ -525,6 +586,11 @@ def attn_decode_ws_floats(b, hq, hkv, q_len, d, splits) -> int:
     return lib().bigdl_attn_decode_ws_floats(b, hq, hkv, q_len, d, splits)
 
 
+def attn_decode_counters(b, hq, hkv) -> int:
+    """int32 arrival counters ``attn_decode`` needs (zeroed once by the caller; every launch leaves them zero)"""
+    return lib().bigdl_attn_decode_counters(b, hq, hkv)
+
+
 def rope_append(qkv, k_cache, v_cache, past_len, inv_freq, *, n_heads, n_kv_heads, head_dim, q_len, batch,
                 rot_dim=None, interleaved=False, attn_scaling=1.0, position_ids=None):
     """Rotate q (in place in ``qkv``) and k, and append k / v^T of the ``q_len`` new tokens to the caches."""
@@ -584,12 +650,16 @@ def attn_decode(qkv, k_cache, v_cache, past_len, out, ws, counters, *, n_heads, 
     if not fp8 and k_cache.dtype != torch.float16:
         raise ValueError("cache dtype must be float16 or uint8 (e5m2)")
     g = n_heads // n_kv_heads
-    chunk = max(1, 32 // g)
+    nchunk = (g + 31) // 32                      # groups above 32 query heads are split over workgroup columns
+    gchunk = (g + nchunk - 1) // nchunk
+    chunk = max(1, 32 // gchunk)
     need = attn_decode_ws_floats(batch, n_heads, n_kv_heads, min(q_len, chunk), head_dim, splits)
     if ws.dtype != torch.float32 or ws.numel() < need:
         raise ValueError(f"workspace needs {need} floats")
-    if counters.dtype != torch.int32 or counters.numel() < batch * n_kv_heads:
-        raise ValueError("counters must be int32 [batch*n_kv_heads]")
+    if counters.dtype != torch.int32 or counters.numel() < batch * n_kv_heads * nchunk:
+        raise ValueError("counters must be int32 [attn_decode_counters(batch, n_heads, n_kv_heads)]")
+    if defer_combine and nchunk > 1:
+        raise ValueError("defer_combine needs at most 32 query heads per kv head")
     if past_len.dtype != torch.int32 or past_len.numel() != batch:
         raise ValueError("past_len must be int32 [batch]")
     mask_ld = 0

@@ -219,7 +219,9 @@ def _ref_attention(q, k, v, scale, softcap=0.0, window=0, past=0):
 
 @pytest.mark.parametrize("fp8", [False, True])
 @pytest.mark.parametrize("cfg", [(1, 32, 32, 128, 1, 1000), (2, 32, 8, 128, 1, 300), (1, 8, 2, 64, 5, 77),
-                                 (1, 4, 4, 256, 3, 513), (2, 6, 2, 96, 2, 130)])
+                                 (1, 4, 4, 256, 3, 513), (2, 6, 2, 96, 2, 130),
+                                 # multi-query groups above 32 query heads per kv head (starcoder 48, falcon-7b 71)
+                                 (1, 48, 1, 128, 1, 300), (2, 71, 1, 64, 2, 130)])
 def test_rope_append_and_attn_decode(hip, fp8, cfg):
     torch.manual_seed(7)
     b, hq, hkv, d, q_len, past = cfg
@@ -274,7 +276,7 @@ def test_rope_append_and_attn_decode(hip, fp8, cfg):
     for splits, softcap, window in ((1, 0.0, 0), (4, 0.0, 0), (3, 30.0, 0), (2, 0.0, 64)):
         out = torch.empty(b * c, hq * d, dtype=torch.float16, device="cuda")
         ws = torch.empty(hip.attn_decode_ws_floats(b, hq, hkv, c, d, splits), dtype=torch.float32, device="cuda")
-        counters = torch.zeros(b * hkv, dtype=torch.int32, device="cuda")
+        counters = torch.zeros(hip.attn_decode_counters(b, hq, hkv), dtype=torch.int32, device="cuda")
         past_len.fill_(p0)
         hip.attn_decode(qkv_d, kc, vc, past_len, out, ws, counters, n_heads=hq, n_kv_heads=hkv, head_dim=d, q_len=c,
                         batch=b, scale=scale, splits=splits, softcap=softcap, window=window)
@@ -670,3 +672,45 @@ def test_rwkv5_wkv(hip):
     out = hip.rwkv_linear_attention_v5(w.cuda(), u.cuda(), r.cuda(), k.cuda(), v.cuda(), dev_state)
     torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(dev_state.cpu(), st, rtol=1e-4, atol=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------
+# GEMV with the LayerNorm folded in
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["sym_int4", "asym_int4", "nf4", "sym_int8"])
+@pytest.mark.parametrize("cfg", [(1, 96, 512, False), (3, 200, 1024, False), (5, 64, 4096, True), (2, 128, 4544, False)])
+def test_gemv_layernorm_fold(hip, name, cfg):
+    """rs * (W.(x*gamma)) - rs*mean*(W.gamma) + W.beta == LayerNorm(x) @ W^T, with a DC offset on x so that the mean
+    term matters; plain, with bias + activation + residual, and the gated two-weight form."""
+    m, n, k, gated = cfg
+    qt = Q.ggml_tensor_qtype[name]
+    torch.manual_seed(41)
+    w, wr = _quant_dev(torch.randn(n, k) / math.sqrt(k), qt)
+    x = (torch.randn(m, k) * 0.7 + 0.3).half()
+    gamma, beta = (1 + 0.1 * torch.randn(k)).half(), (0.1 * torch.randn(k)).half()
+    bias = (0.1 * torch.randn(n)).half()
+    res = torch.randn(m, n).half()
+    xn = torch.nn.functional.layer_norm(x.float(), (k,), gamma.float(), beta.float(), 1e-5)
+    ln = hip.layer_norm_fold(wr.cuda(), gamma.cuda(), beta.cuda())
+    got = hip.gemv_lowbit_ln(x.cuda(), w, qt, n, k, gamma.cuda(), ln, eps=1e-5)
+    want = xn @ wr.float().t()
+    torch.testing.assert_close(got.float().cpu(), want, rtol=2e-2, atol=2e-2)
+    got = hip.gemv_lowbit_ln(x.cuda(), w, qt, n, k, gamma.cuda(), ln, bias=bias.cuda(), residual=res.cuda(), eps=1e-5,
+                             act="gelu_tanh")
+    want2 = torch.nn.functional.gelu(want + bias.float(), approximate="tanh") + res.float()
+    torch.testing.assert_close(got.float().cpu(), want2, rtol=2e-2, atol=2e-2)
+    # fp32 output (the lm_head form) and no beta
+    ln0 = hip.layer_norm_fold(wr.cuda(), gamma.cuda(), None)
+    out32 = torch.empty(m, n, dtype=torch.float32, device="cuda")
+    hip.gemv_lowbit_ln(x.cuda(), w, qt, n, k, gamma.cuda(), ln0, eps=1e-5, out=out32)
+    xn0 = torch.nn.functional.layer_norm(x.float(), (k,), gamma.float(), None, 1e-5)
+    torch.testing.assert_close(out32.cpu(), xn0 @ wr.float().t(), rtol=2e-2, atol=2e-2)
+    if gated:
+        w2, w2r = _quant_dev(torch.randn(n, k) / math.sqrt(k), qt)
+        ln2 = hip.layer_norm_fold(w2r.cuda(), gamma.cuda(), beta.cuda())
+        got = hip.gemv_lowbit_ln(x.cuda(), w, qt, n, k, gamma.cuda(), ln, w2=w2, ln2=ln2, eps=1e-5, act="silu")
+        want3 = torch.nn.functional.silu(want) * (xn @ w2r.float().t())
+        torch.testing.assert_close(got.float().cpu(), want3, rtol=2e-2, atol=2e-2)
+    assert not hip.gemv_x_in_lds(16, 11008)
+    with pytest.raises(ValueError):
+        hip.gemv_lowbit_ln(torch.zeros(16, 11008, dtype=torch.float16, device="cuda"), w, qt, n, 11008, gamma.cuda(), ln)
