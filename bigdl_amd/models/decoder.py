@@ -439,6 +439,63 @@ class NativeDecoder:
         logits = self._linear_dense(x, self.lm_head).float().view(b, -1, cfg.vocab_size)
         return self._finish_logits(logits)
 
+    @torch.no_grad()
+    def prefill_context_parallel(self, input_ids: torch.Tensor, group=None):
+        """Prompt pass of ONE long sequence split over the ranks of ``group`` (parallel/context_parallel.py): this rank
+        embeds and runs the linears for its two zigzag chunks only, K / V chunks are all-gathered into every rank's
+        cache per layer, attention runs per chunk over the keys before it.  ``input_ids`` [1, S] is the full prompt on
+        every rank, S a multiple of 2 * world; the cache must be empty.  Returns the last token's logits [1, 1, V] on
+        every rank; afterwards every rank holds the complete KV cache and can decode."""
+        from ..ops import hip
+        from ..parallel import context_parallel as cp
+        cfg, cache = self.cfg, self.cache
+        b, s = input_ids.shape
+        assert b == 1 and cache.host_len == 0 and cache.slot_len is None, "context-parallel prefill: one sequence, empty cache"
+        assert s <= cache.capacity, "KV cache capacity exceeded"
+        world, rank = cp._world(group), cp._rank(group)
+        n = s // (2 * world)
+        chunks = cp.zigzag_chunks(world, rank)
+        pos = cp.local_token_index(s, world, rank, device=self.device)          # [2n]
+        h = F.embedding(input_ids[0, pos], self.embed).to(torch.float16)
+        if cfg.embed_scale != 1.0:
+            h = h * cfg.embed_scale
+        h = self._embed_extras(h, pos)
+        hq, hkv, d = cfg.num_heads, cfg.num_kv_heads, cfg.head_dim
+        rot = cfg.rot_dim or d
+        for li, lw in enumerate(self.layers):
+            x = self._norm(h, lw.input_norm, lw.input_norm_b)
+            qkv = self._linear_dense(x, lw.qkv).view(2, n, (hq + 2 * hkv) * d)
+            kc, vc = cache.k[li], cache.v[li]
+            for j, c in enumerate(chunks):      # RoPE at the chunk's global positions, K / V^T into the cache there
+                hip.prefill_rope_append(qkv[j:j + 1], kc, vc, self.rope_table, n_heads=hq, n_kv_heads=hkv, head_dim=d,
+                                        past=c * n, rot_dim=rot, interleaved=cfg.rope_interleaved)
+            cp.gather_kv_chunks(kc, vc, n, group)
+            outs = []
+            for j, c in enumerate(chunks):
+                q = qkv[j:j + 1, :, : hq * d].view(1, n, hq, d).transpose(1, 2)
+                kk, vt = self._read_cache(li, (c + 1) * n)
+                outs.append(self._sdpa(q, kk, vt, c * n, lw.window).reshape(n, hq * d))
+            o = self._tp_reduce(self._linear_dense(torch.cat(outs, 0), lw.o))
+            if lw.post_attn_out_norm is not None:
+                o = self._norm(o, lw.post_attn_out_norm)
+            if cfg.parallel_residual:
+                x2 = x if lw.post_norm is None else self._norm(h, lw.post_norm, lw.post_norm_b)
+                h = h + o + self._mlp_dense(x2, lw)
+                continue
+            h = h + o
+            x = self._norm(h, lw.pre_ffn_norm if lw.pre_ffn_norm is not None else lw.post_norm, lw.post_norm_b)
+            m = lw.moe.forward_dense(x, self) if lw.moe is not None else self._mlp_dense(x, lw)
+            if lw.post_ffn_out_norm is not None:
+                m = self._norm(m, lw.post_ffn_out_norm)
+            h = h + m
+        cache.past_len.fill_(s)
+        cache.host_len = s
+        # the last prompt token is the last row of rank 0's second chunk
+        x = self._norm(h[-1:], self.final_norm, self.final_norm_b)
+        logits = self._linear_dense(x, self.lm_head).float().view(1, 1, cfg.vocab_size)
+        logits = self._finish_logits(logits)
+        return cp.broadcast_from_last_token_owner(logits.contiguous(), group)
+
     def _finish_logits(self, logits):
         cfg = self.cfg
         if cfg.logit_scale != 1.0:

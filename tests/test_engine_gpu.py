@@ -135,3 +135,29 @@ def test_continuous_batching_matches_per_request_generation():
     # a near-tie argmax can flip once and change that request's tail
     assert all(w[0] == o[0] for w, o in zip(want, got)), (want, got)
     assert agree >= 0.8 * total, (want, got)
+
+
+@pytest.mark.parametrize("fp8", [False, True])
+def test_context_parallel_prefill_matches_plain_prefill(fp8):
+    """One rank, two zigzag chunks: chunked RoPE positions, cache writes at chunk offsets and per-chunk causal
+    attention reproduce the plain prompt pass; decoding continues from the cache it leaves."""
+    from bigdl_amd.models import decoder as D
+    cfg = D.DecoderConfig(vocab_size=512, hidden_size=256, intermediate_size=512, num_layers=3, num_heads=4, num_kv_heads=2,
+                          head_dim=64, max_position=1024)
+    eng = D.build_random_decoder(cfg, device="cuda")
+    torch.manual_seed(0)
+    ids = torch.randint(0, 512, (1, 600), device="cuda")
+    eng.ensure_cache(1, 700, fp8=fp8)
+    eng.cache.reset()
+    want = eng.prefill(ids)
+    _, nxt = eng.decode(want[:, -1].argmax(-1).view(1, 1))
+    k_ref = eng.cache.k[1][:, :, :600].clone()
+    eng.cache.reset()
+    got = eng.prefill_context_parallel(ids)
+    rel = ((got - want).abs().mean() / want.abs().mean()).item()
+    assert rel < (0.05 if fp8 else 5e-3), rel
+    if not fp8:
+        torch.testing.assert_close(eng.cache.k[1][:, :, :600].float(), k_ref.float(), rtol=2e-2, atol=2e-2)
+    assert eng.cache.host_len == 600 and int(eng.cache.past_len[0]) == 600
+    _, nxt2 = eng.decode(got[:, -1].argmax(-1).view(1, 1))
+    assert got[:, -1].argmax(-1).item() != want[:, -1].argmax(-1).item() or torch.equal(nxt, nxt2)

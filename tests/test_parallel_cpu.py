@@ -222,3 +222,35 @@ def test_zero_sharded_optimizer_matches_single_process(tmp_path):
     """ZeRO stage 1/2 (sharded optimizer state + reduce-scattered gradients) and stage 3 (parameters released between
     steps) reproduce single-process AdamW on the global batch."""
     _run(_zero_worker, str(tmp_path))
+
+
+def _cp_worker(rank, port):
+    from bigdl_amd.parallel import context_parallel as cp
+    _boot(rank, port)
+    torch.manual_seed(5)
+    b, hkv, d, n = 1, 2, 8, 3
+    total = 2 * WORLD * n
+    full_k = torch.randn(b, hkv, 16, d)
+    full_v = torch.randn(b, hkv, d, 16)
+    for dtype in (torch.float32, torch.uint8):
+        fk = full_k if dtype == torch.float32 else (full_k * 40).to(torch.uint8)
+        fv = full_v if dtype == torch.float32 else (full_v * 40).to(torch.uint8)
+        kc, vc = torch.zeros_like(fk), torch.zeros_like(fv)
+        for c in cp.zigzag_chunks(WORLD, rank):            # this rank only has its own two chunks
+            kc[:, :, c * n:(c + 1) * n] = fk[:, :, c * n:(c + 1) * n]
+            vc[..., c * n:(c + 1) * n] = fv[..., c * n:(c + 1) * n]
+        cp.gather_kv_chunks(kc, vc, n, None)
+        assert torch.equal(kc[:, :, :total], fk[:, :, :total]) and torch.equal(vc[..., :total], fv[..., :total])
+        assert float(kc[:, :, total:].float().abs().sum()) == 0.0       # nothing past the prompt is touched
+    idx = cp.local_token_index(total, WORLD, rank)
+    got = [torch.empty_like(idx) for _ in range(WORLD)]
+    dist.all_gather(got, idx)
+    assert sorted(torch.cat(got).tolist()) == list(range(total))        # the chunks tile the prompt exactly
+    t = torch.full((3,), float(rank + 7))
+    cp.broadcast_from_last_token_owner(t)
+    assert t.tolist() == [7.0] * 3
+    dist.destroy_process_group()
+
+
+def test_context_parallel_kv_gather():
+    _run(_cp_worker)
