@@ -49,6 +49,9 @@ if __name__ == "__main__":
         torch.cuda.synchronize()
         first = time.perf_counter() - t0
     tok = logits[:, -1].argmax(-1).view(1, 1)
+    _, nxt = eng.decode(tok)                             # untimed: captures the decode graph
+    tok = nxt.view(1, 1)
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.new_tokens):
         _, nxt = eng.decode(tok)
