@@ -261,8 +261,8 @@ def shard_engine(engine, rank: int, world: int, group=None, fast_allreduce=None)
         import os
         fast_allreduce = os.environ.get("BIGDL_XGMI_ALLREDUCE") == "1"
     if fast_allreduce and engine.device.type == "cuda":
-        from .xgmi_allreduce import OneShotAllReduce
-        engine.tp_fast_allreduce = OneShotAllReduce(engine.tp_group, device=engine.device)
+        from .xgmi_allreduce import XgmiAllReduce
+        engine.tp_fast_allreduce = XgmiAllReduce(engine.tp_group, device=engine.device)
     engine.cache = None
     engine._graphs.clear()
     engine._static.clear()

@@ -1,5 +1,6 @@
-"""One-shot all-reduce over IPC-mapped peer buffers (kernel: ``csrc/hip/allreduce_xgmi.hip``) for the small,
-latency-bound all-reduces of a tensor-parallel decode step.
+"""All-reduce over IPC-mapped peer buffers (kernels: ``csrc/hip/allreduce_xgmi.hip``): a one-shot form for the
+small, latency-bound all-reduces of a tensor-parallel decode step, and a two-shot (reduce-scatter + all-gather) form
+for the multi-megabyte all-reduces of the prompt pass.
 
 Every rank allocates one fine-grained device buffer, the ranks exchange ``hipIpcMemHandle``s through the (RCCL or
 gloo) process group, and each call is a single kernel launch on the current stream -- capturable into the decode
@@ -45,8 +46,13 @@ class OneShotAllReduce:
         L.bigdl_ar_ipc_close.argtypes = [ctypes.c_void_p]
         L.bigdl_allreduce_oneshot.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                               ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.bigdl_ar2_buffer_bytes.restype = ctypes.c_int64
+        L.bigdl_ar2_buffer_bytes.argtypes = [ctypes.c_int, ctypes.c_int64]
+        L.bigdl_allreduce_twoshot.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                              ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        self.max_bytes = self._round_max_bytes(self.max_bytes)
         with torch.cuda.device(self.device):
-            nbytes = L.bigdl_ar_buffer_bytes(self.world, self.max_bytes)
+            nbytes = self._buffer_bytes()
             own = ctypes.c_void_p()
             if L.bigdl_ar_alloc(nbytes, ctypes.byref(own)) != 0:
                 raise RuntimeError("fine-grained buffer allocation failed")
@@ -68,9 +74,18 @@ class OneShotAllReduce:
                 self._opened.append(p)
                 ptrs.append(p.value)
             self._peers = (ctypes.c_int64 * self.world)(*ptrs)
-            self.epoch = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self.epoch = torch.zeros(self._epoch_words(), dtype=torch.int32, device=self.device)
             self.error = torch.zeros(1, dtype=torch.int32, device=self.device)
         dist.barrier(group=group)          # every buffer is mapped everywhere before the first call
+
+    def _round_max_bytes(self, n):
+        return n
+
+    def _buffer_bytes(self):
+        return self.lib.bigdl_ar_buffer_bytes(self.world, self.max_bytes)
+
+    def _epoch_words(self):
+        return 1
 
     def usable(self, t: torch.Tensor) -> bool:
         return (t.device.type == "cuda" and t.dtype == torch.float16 and t.is_contiguous() and t.numel() % 8 == 0
@@ -102,3 +117,61 @@ class OneShotAllReduce:
         if getattr(self, "_own", None) is not None:
             self.lib.bigdl_ar_free(self._own)
             self._own = None
+
+
+class TwoShotAllReduce(OneShotAllReduce):
+    """Reduce-scatter + all-gather by direct peer stores for the large all-reduces of a tensor-parallel prompt pass
+    (kernel ``allreduce_twoshot_kernel``): each GPU moves 2 (W-1)/W of the message once over all its xGMI links.
+    Same set-up, fallback and error handling as the one-shot form; 64 workgroups, one launch, capturable."""
+
+    def __init__(self, group=None, max_bytes: int = 64 << 20, device=None):
+        super().__init__(group, max_bytes, device)
+
+    def _round_max_bytes(self, n):
+        q = 64 * self.world
+        return (n + q - 1) // q * q
+
+    def _buffer_bytes(self):
+        return self.lib.bigdl_ar2_buffer_bytes(self.world, self.max_bytes)
+
+    def _epoch_words(self):
+        return self.lib.bigdl_ar2_epoch_words()
+
+    def all_reduce(self, t: torch.Tensor) -> torch.Tensor:
+        if not self.usable(t):
+            dist.all_reduce(t, group=self.group)
+            return t
+        rc = self.lib.bigdl_allreduce_twoshot(self._peers, self.rank, self.world, t.data_ptr(), t.data_ptr(), t.numel(),
+                                              self.max_bytes, self.epoch.data_ptr(), self.error.data_ptr(),
+                                              torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            raise RuntimeError(f"allreduce_twoshot: native launcher rejected the call (code {rc})")
+        return t
+
+    __call__ = all_reduce
+
+
+class XgmiAllReduce:
+    """Size-switched front: one-shot below ``small_bytes`` (decode), two-shot up to ``large_bytes`` (prompt), RCCL
+    above.  This is what ``shard_engine(..., fast_allreduce=True)`` installs."""
+
+    def __init__(self, group=None, small_bytes: int = DEFAULT_MAX_BYTES, large_bytes: int = 64 << 20, device=None):
+        self.group = group
+        self.small = OneShotAllReduce(group, small_bytes, device)
+        self.large = TwoShotAllReduce(group, large_bytes, device)
+
+    def usable(self, t):
+        return self.small.usable(t) or self.large.usable(t)
+
+    def __call__(self, t):
+        return self.small(t) if self.small.usable(t) else self.large(t)
+
+    all_reduce = __call__
+
+    def check(self):
+        self.small.check()
+        self.large.check()
+
+    def close(self):
+        self.small.close()
+        self.large.close()

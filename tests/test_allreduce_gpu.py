@@ -72,6 +72,41 @@ def test_one_shot_all_reduce_two_processes_one_gpu(tmp_path):
         assert int(torch.load(tmp_path / f"ok{r}.pt")) == WORLD
 
 
+def _twoshot_worker(rank, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    from bigdl_amd.parallel.xgmi_allreduce import XgmiAllReduce
+    ar = XgmiAllReduce(small_bytes=16 * 1024, large_bytes=4 << 20)
+    ok = True
+    g = torch.Generator().manual_seed(99)
+    # below 16 KiB: one-shot; above: two-shot, with chunk sizes that do and do not divide evenly; twice each (both sets)
+    for n in [4096, 8 * 1001, 8 * 1001, 1 << 20, 1 << 20, 8 * 65, 2 << 20, 24]:
+        parts = [torch.randn(n, generator=g).half() for _ in range(WORLD)]
+        want = sum(p.float() for p in parts).half()
+        t = parts[rank].cuda()
+        ar(t)
+        torch.cuda.synchronize()
+        ar.check()
+        ok &= bool(torch.equal(t.cpu(), want))
+    assert ar.large.usable(torch.empty(1 << 20, dtype=torch.float16, device="cuda"))
+    assert not ar.usable(torch.empty(4 << 20, dtype=torch.float16, device="cuda"))      # 8 MiB: RCCL / gloo path
+    flag = torch.tensor([1 if ok else 0])
+    dist.all_reduce(flag)
+    torch.save(flag, os.path.join(out_dir, f"ok{rank}.pt"))
+    dist.barrier()
+    ar.close()
+    dist.destroy_process_group()
+
+
+def test_two_shot_all_reduce_two_processes_one_gpu(tmp_path):
+    port = _free_port()
+    mp.spawn(_twoshot_worker, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
+    for r in range(WORLD):
+        assert int(torch.load(tmp_path / f"ok{r}.pt")) == WORLD
+
+
 def _tp_engine_worker(rank, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD),
                       HSA_ENABLE_IPC_MODE_LEGACY="0")
