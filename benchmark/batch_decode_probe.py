@@ -1,15 +1,41 @@
-"""Decode step time of the native engine at a given batch size (random-init Llama-2-7B sym_int4, 32-token prompts,
-32 new tokens, fp8 KV): prints `<batch> <ms per step>`.  Used to attribute how the step scales with the row count."""
-import sys
+"""Decode step time of the native engine at a given batch size and context length (random-init Llama-2-7B sym_int4,
+fp8 KV): prints one JSON line per batch size.  The cache is filled by a real prompt pass of ``--ctx`` tokens per row.
+    PYTHONPATH=. python benchmark/batch_decode_probe.py --batch 1,8,32,64 --ctx 1024 [--steps 32]
+Run under ``rocprofv3 --kernel-trace --stats`` with one batch size to attribute the step to kernels."""
+import argparse
+import json
+import time
 
 import torch
 
 from bigdl_amd import qtypes as Q
 from bigdl_amd.models.decoder import LLAMA2_7B, DecoderConfig, build_random_decoder
 
-b = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-eng = build_random_decoder(DecoderConfig(**LLAMA2_7B), Q.SYM_INT4, device="cuda", seed=1)
-ids = torch.randint(3, 32000, (b, 32)).cuda()
-for _ in range(2):
-    eng.generate(ids, max_new_tokens=32, kv_fp8=True)
-print(b, round(eng.rest_cost_mean * 1e3, 4))
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", default="1")
+    ap.add_argument("--ctx", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--kv", default="fp8", choices=["fp8", "fp16"])
+    args = ap.parse_args()
+    eng = build_random_decoder(DecoderConfig(**LLAMA2_7B), Q.SYM_INT4, device="cuda", seed=1)
+    for b in [int(x) for x in args.batch.split(",")]:
+        eng.ensure_cache(b, args.ctx + args.steps + 8, fp8=args.kv == "fp8")
+        eng.cache.reset()
+        ids = torch.randint(3, 32000, (b, args.ctx)).cuda()
+        logits = eng.prefill(ids)
+        tok = logits[:, -1].argmax(-1).view(b, 1)
+        for _ in range(3):                             # graph capture + warm-up
+            _, nxt = eng.decode(tok)
+            tok = nxt.view(b, 1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            _, nxt = eng.decode(tok)
+            tok = nxt.view(b, 1)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / args.steps * 1e3
+        kv_gb = (1 if args.kv == "fp8" else 2) * 2 * b * (args.ctx + args.steps // 2) * 4096 * 32 / 1e9
+        print(json.dumps({"kv": args.kv, "batch": b, "ctx": args.ctx, "ms_per_step": round(ms, 3), "tokens_per_s": round(b / ms * 1e3, 1),
+                          "kv_read_gb": round(kv_gb, 2), "weights_gb": round(eng.weight_bytes() / 1e9, 2),
+                          "hbm_floor_ms": round((kv_gb + eng.weight_bytes() / 1e9) / 8e3 * 1e3, 3)}), flush=True)

@@ -47,7 +47,6 @@ struct AttnArgs {
 
 constexpr float NEG_BIG = -1.0e30f;
 constexpr int ATT_NW = 8;          // wavefronts per workgroup
-constexpr int ATT_KEYS = ATT_NW * 32;  // keys per workgroup iteration
 
 template <bool FP8>
 __device__ __forceinline__ half8 load_kv8(const void* base, int64_t elem_off) {
@@ -59,12 +58,24 @@ __device__ __forceinline__ half8 load_kv8(const void* base, int64_t elem_off) {
   }
 }
 
-// D = head dim (multiple of 32), RT = number of 16-row tiles
-template <int D, bool FP8, int RT>
+// D = head dim (multiple of 32), RT = number of 16-row tiles, KW = keys per wavefront per iteration.
+// KW = 64 (e5m2 caches, D % 128 == 0): every lane loads 16 bytes of a key row / of a V^T channel row instead of 8, i.e.
+// half as many load instructions and 64-byte instead of 32-byte contiguous pieces per 4 lanes.  With 8-byte pieces the
+// e5m2 path is bound by the number of memory instructions, not by bytes (batch 64, 1024 keys: 184 us per layer where
+// the fp16 cache needs 258 us for twice the bytes).  The MFMA k index <-> head channel assignment is free as long as
+// Q and K agree, so lane group g takes channels [16 (g + 4 c2), +16) of a row for the k-steps 2 c2 and 2 c2 + 1.
+template <int D, bool FP8, int RT, int KW>
 __global__ __launch_bounds__(ATT_NW * 64) void attn_decode_kernel(AttnArgs a) {
   constexpr int DC = D / 32;   // QK k-steps
   constexpr int DT = D / 16;   // O^T d-tiles
   constexpr int NW = ATT_NW;
+  constexpr int ATT_KEYS = NW * KW;    // keys per workgroup iteration
+  constexpr int NU = KW / 16;          // 16-key score tiles per wavefront
+  constexpr int KL = KW / 4;           // consecutive keys per lane
+  constexpr bool WIDE = KW == 64;
+  static_assert(!WIDE || (FP8 && D % 128 == 0), "16-byte fragments: e5m2 cache, rotate-half partner in k-step c + DC/2");
+  // first head channel of this lane's 8 values in k-step c
+  auto chan = [](int c, int g) { return WIDE ? 64 * (c >> 1) + 16 * g + 8 * (c & 1) : 32 * c + 8 * g; };
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int rr = lane & 15, g = lane >> 4;
@@ -159,7 +170,7 @@ __global__ __launch_bounds__(ATT_NW * 64) void attn_decode_kernel(AttnArgs a) {
 #pragma unroll
     for (int c = 0; c < DC; ++c) {
       half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (valid) v = *(const half8*)(qp + 32 * c + 8 * g);
+      if (valid) v = *(const half8*)(qp + chan(c, g));
 #pragma unroll
       for (int j = 0; j < 8; ++j) qv[c][j] = (float)v[j];
     }
@@ -169,7 +180,7 @@ __global__ __launch_bounds__(ATT_NW * 64) void attn_decode_kernel(AttnArgs a) {
       if (a.interleaved) {
 #pragma unroll
         for (int c = 0; c < DC; ++c) {
-          const int d0 = 32 * c + 8 * g;
+          const int d0 = chan(c, g);
           if (d0 < a.rot) {
 #pragma unroll
             for (int j = 0; j < 8; j += 2) {
@@ -185,7 +196,7 @@ __global__ __launch_bounds__(ATT_NW * 64) void attn_decode_kernel(AttnArgs a) {
         // (rot == D), so the partner lives in chunk c + DC/2 of the same lane
 #pragma unroll
         for (int c = 0; c < DC / 2; ++c) {
-          const int d0 = 32 * c + 8 * g;
+          const int d0 = chan(c, g);          // < D/2 in both channel orders; the partner d0 + D/2 is k-step c + DC/2
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const float2 cs = *(const float2*)(tab + (d0 + j) * 2);
@@ -217,55 +228,75 @@ __global__ __launch_bounds__(ATT_NW * 64) void attn_decode_kernel(AttnArgs a) {
   const float4v zero4 = {0, 0, 0, 0};
 
   for (int blk = blk0; blk < blk1; ++blk) {
-    const int kb = blk * ATT_KEYS + wave * 32;
+    const int kb = blk * ATT_KEYS + wave * KW;
     if (kb >= kv_len) break;
-    // ---- S^T = K . Q^T for two 16-key tiles ----
-    // A-row i of tile u  <->  key kb + 8*(i>>2) + 4*u + (i&3)
-    const int key0 = kb + 8 * (rr >> 2) + (rr & 3);
-    half8 kf0[DC], kf1[DC];
+    // ---- S^T = K . Q^T for NU 16-key tiles ----
+    // A-row i of tile u  <->  key kb + KL*(i>>2) + 4*u + (i&3), so that lane group g ends up with the KL consecutive
+    // keys kb + KL*g .. of every query row
+    const int key0 = kb + KL * (rr >> 2) + (rr & 3);
+    half8 kf[NU][DC];
+    if constexpr (WIDE) {
 #pragma unroll
-    for (int c = 0; c < DC; ++c) {
-      kf0[c] = load_kv8<FP8>(kc, (int64_t)key0 * D + 32 * c + 8 * g);
-      kf1[c] = load_kv8<FP8>(kc, (int64_t)(key0 + 4) * D + 32 * c + 8 * g);
+      for (int u = 0; u < NU; ++u)
+#pragma unroll
+        for (int c2 = 0; c2 < DC / 2; ++c2) {
+          const uint4v w = *(const uint4v*)((const uint8_t*)kc + (int64_t)(key0 + 4 * u) * D + 64 * c2 + 16 * g);
+          kf[u][2 * c2] = dec_e5m2(w[0], w[1]);
+          kf[u][2 * c2 + 1] = dec_e5m2(w[2], w[3]);
+        }
+    } else {
+#pragma unroll
+      for (int u = 0; u < NU; ++u)
+#pragma unroll
+        for (int c = 0; c < DC; ++c) kf[u][c] = load_kv8<FP8>(kc, (int64_t)(key0 + 4 * u) * D + 32 * c + 8 * g);
     }
-    // V^T fragments: lane (d_local, g) holds keys kb + 8g .. +7 of channel 16*dt + d_local
-    half8 vf[DT];
+    // V^T fragments: lane (d_local, g) holds keys kb + KL*g .. of channel 16*dt + d_local (KL/8 k-steps)
+    half8 vf[DT][KL / 8];
+    if constexpr (WIDE) {
 #pragma unroll
-    for (int d = 0; d < DT; ++d) vf[d] = load_kv8<FP8>(vc, (int64_t)(16 * d + rr) * a.Lmax + kb + 8 * g);
+      for (int d = 0; d < DT; ++d) {
+        const uint4v w = *(const uint4v*)((const uint8_t*)vc + (int64_t)(16 * d + rr) * a.Lmax + kb + 16 * g);
+        vf[d][0] = dec_e5m2(w[0], w[1]);
+        vf[d][1] = dec_e5m2(w[2], w[3]);
+      }
+    } else {
+#pragma unroll
+      for (int d = 0; d < DT; ++d) vf[d][0] = load_kv8<FP8>(vc, (int64_t)(16 * d + rr) * a.Lmax + kb + 8 * g);
+    }
 
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
-      float4v s0 = zero4, s1 = zero4;
+      // lane (row rr, g): tile u, register q  <->  key kb + KL*g + 4*u + q
+      float sv[KL];
 #pragma unroll
-      for (int c = 0; c < DC; ++c) {
-        s0 = mfma16(kf0[c], qf[t][c], s0);
-        s1 = mfma16(kf1[c], qf[t][c], s1);
+      for (int u = 0; u < NU; ++u) {
+        float4v su = zero4;
+#pragma unroll
+        for (int c = 0; c < DC; ++c) su = mfma16(kf[u][c], qf[t][c], su);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sv[4 * u + q] = su[q];
       }
-      // lane (row rr, g): s0[q] <-> key kb+8g+q ; s1[q] <-> key kb+8g+4+q
-      float sv[8];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { sv[q] = s0[q]; sv[4 + q] = s1[q]; }
       if (a.softcap > 0.0f) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) sv[q] = a.softcap * tanhf(sv[q] / a.softcap) * 1.4426950408889634f;
+        for (int q = 0; q < KL; ++q) sv[q] = a.softcap * tanhf(sv[q] / a.softcap) * 1.4426950408889634f;
       }
-      const int kfirst = kb + 8 * g;
+      const int kfirst = kb + KL * g;
       if (a.alibi != nullptr) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) sv[q] += slope[t] * (float)(kfirst + q - lim[t]);   // slope * (key - query)
+        for (int q = 0; q < KL; ++q) sv[q] += slope[t] * (float)(kfirst + q - lim[t]);   // slope * (key - query)
       }
       if (a.mask) {
         const int row = 16 * t + rr;
         if (row < rows) {
           const _Float16* mp = a.mask + ((int64_t)b * a.q_total + a.q_off + row / Gc) * a.mask_ld + kfirst;
 #pragma unroll
-          for (int q = 0; q < 8; ++q)
+          for (int q = 0; q < KL; ++q)
             if (kfirst + q < a.mask_ld) sv[q] += (float)mp[q] * 1.4426950408889634f;
         }
       }
       float mx = NEG_BIG;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
+      for (int q = 0; q < KL; ++q) {
         const int key = kfirst + q;
         if (key > lim[t] || key < lo_lim[t]) sv[q] = NEG_BIG;
         mx = fmaxf(mx, sv[q]);
@@ -275,16 +306,16 @@ __global__ __launch_bounds__(ATT_NW * 64) void attn_decode_kernel(AttnArgs a) {
       const float m_new = fmaxf(m_run[t], mx);
       const float alpha = exp2f(m_run[t] - m_new);
       m_run[t] = m_new;
-      H8 pf;
+      H8 pf[KL / 8];
       float ps = 0.0f;
 #pragma unroll
-      for (int q = 0; q < 8; q += 2) {
+      for (int q = 0; q < KL; q += 2) {
         // masked entries: sv = NEG_BIG; when the whole row is still masked m_new = NEG_BIG too and
         // exp2(0) would be 1, so masked entries are forced to 0 explicitly
         const float p0 = sv[q] <= NEG_BIG ? 0.0f : exp2f(sv[q] - m_new);
         const float p1 = sv[q + 1] <= NEG_BIG ? 0.0f : exp2f(sv[q + 1] - m_new);
         ps += p0 + p1;
-        pf.h2[q >> 1] = half2v{(_Float16)p0, (_Float16)p1};
+        pf[q >> 3].h2[(q & 7) >> 1] = half2v{(_Float16)p0, (_Float16)p1};
       }
       l_run[t] = l_run[t] * alpha + ps;
       if (__any(alpha != 1.0f)) {
@@ -292,7 +323,9 @@ __global__ __launch_bounds__(ATT_NW * 64) void attn_decode_kernel(AttnArgs a) {
         for (int d = 0; d < DT; ++d) o[t][d] *= alpha;
       }
 #pragma unroll
-      for (int d = 0; d < DT; ++d) o[t][d] = mfma16(vf[d], pf.v, o[t][d]);
+      for (int h = 0; h < KL / 8; ++h)
+#pragma unroll
+        for (int d = 0; d < DT; ++d) o[t][d] = mfma16(vf[d][h], pf[h].v, o[t][d]);
     }
   }
 
@@ -384,32 +417,37 @@ __global__ __launch_bounds__(ATT_NW * 64) void attn_decode_kernel(AttnArgs a) {
   }
 }
 
+template <int D, bool FP8, int RT, int KW>
+static int launch_one(const AttnArgs& a, size_t smem, hipStream_t st) {
+  const dim3 grid(a.splits, a.Hkv * a.nchunk, a.B), block(ATT_NW * 64);
+  // more than 64 KiB of dynamic LDS has to be requested explicitly (once per kernel)
+  static bool attr = false;
+  if (!attr && smem > 65536) {
+    if (hipFuncSetAttribute((const void*)attn_decode_kernel<D, FP8, RT, KW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess)
+      return -5;
+    attr = true;
+  }
+  hipLaunchKernelGGL((attn_decode_kernel<D, FP8, RT, KW>), grid, block, smem, st, a);
+  return HIP_CHECK_LAUNCH();
+}
+
 template <int D, bool FP8>
 static int launch_rt(const AttnArgs& a, hipStream_t st) {
   const int rows = a.gchunk * a.q_cnt;
   const int rt = (rows + 15) / 16;
-  const dim3 grid(a.splits, a.Hkv * a.nchunk, a.B), block(ATT_NW * 64);
-  auto smem = [&](int RT) { return (size_t)(ATT_NW * RT * 16 * 2 + ATT_NW * rows * D) * 4 + 16; };
-  // more than 64 KiB of dynamic LDS has to be requested explicitly (once per kernel)
-  static bool attr1 = false, attr2 = false;
-  switch (rt) {
-    case 1:
-      if (!attr1 && smem(1) > 65536) {
-        if (hipFuncSetAttribute((const void*)attn_decode_kernel<D, FP8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -5;
-        attr1 = true;
-      }
-      hipLaunchKernelGGL((attn_decode_kernel<D, FP8, 1>), grid, block, smem(1), st, a);
-      break;
-    case 2:
-      if (!attr2 && smem(2) > 65536) {
-        if (hipFuncSetAttribute((const void*)attn_decode_kernel<D, FP8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -5;
-        attr2 = true;
-      }
-      hipLaunchKernelGGL((attn_decode_kernel<D, FP8, 2>), grid, block, smem(2), st, a);
-      break;
-    default: return -4;
+  const size_t smem = (size_t)(ATT_NW * rt * 16 * 2 + ATT_NW * rows * D) * 4 + 16;
+  if (rt == 1) {
+    // 64 keys per wavefront (16-byte fragments) once every workgroup has several iterations of work anyway: one KV
+    // split, i.e. enough (batch, head) pairs to fill the GPU.  Latency-bound launches with few keys per workgroup
+    // keep 32 keys per wavefront and more workgroups.
+    if constexpr (FP8 && D % 128 == 0) {
+      if (a.splits == 1) return launch_one<D, FP8, 1, 64>(a, smem, st);
+    }
+    return launch_one<D, FP8, 1, 32>(a, smem, st);
   }
-  return HIP_CHECK_LAUNCH();
+  if (rt == 2) return launch_one<D, FP8, 2, 32>(a, smem, st);
+  return -4;
 }
 
 // ---------------------------------------------------------------------------------------------

