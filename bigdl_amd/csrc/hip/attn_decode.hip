@@ -19,6 +19,7 @@
 // with keys {8g+q} and {8g+4+q} so that lane group g ends up owning 8 consecutive keys, which
 // is exactly the k-slice its P^T fragment must hold for the O^T product.
 #include "common.h"
+#include <stdlib.h>
 
 namespace bigdl {
 
@@ -439,10 +440,12 @@ static int launch_rt(const AttnArgs& a, hipStream_t st) {
   const size_t smem = (size_t)(ATT_NW * rt * 16 * 2 + ATT_NW * rows * D) * 4 + 16;
   if (rt == 1) {
     // 64 keys per wavefront (16-byte fragments) once every workgroup has several iterations of work anyway: one KV
-    // split, i.e. enough (batch, head) pairs to fill the GPU.  Latency-bound launches with few keys per workgroup
-    // keep 32 keys per wavefront and more workgroups.
+    // split (enough (batch, head) pairs to fill the GPU) or a long cache.  Latency-bound launches with few keys per
+    // workgroup keep 32 keys per wavefront and more workgroups.
     if constexpr (FP8 && D % 128 == 0) {
-      if (a.splits == 1) return launch_one<D, FP8, 1, 64>(a, smem, st);
+      static const char* force = getenv("BIGDL_ATTN_KEYS");      // "32" / "64": override for measurements
+      const bool wide = force ? atoi(force) == 64 : (a.splits == 1 || a.Lmax / a.splits >= 2048);
+      if (wide) return launch_one<D, FP8, 1, 64>(a, smem, st);
     }
     return launch_one<D, FP8, 1, 32>(a, smem, st);
   }
