@@ -89,17 +89,19 @@ __global__ __launch_bounds__(256, 2) void gemm_t16_kernel(GemmArgs a) {
 
   // x staging: thread t moves 16 bytes of row (16 p + t / 16), slot t % 16, for p = 0 .. MT-1
   const int srow = threadIdx.x >> 4, sslot = threadIdx.x & 15;
-  // element offsets into x (32 bits: the host checks rows * ldx < 2^31); ~0u marks a row past the block
+  // element offsets into x (32 bits: the host checks rows * ldx < 2^31).  Rows past the block read the block's last
+  // row and are zeroed afterwards: every load below is unconditional, from a clamped address.  A load under a
+  // condition leaves the compiler without a static count of younger loads in flight, and it then waits for ALL of
+  // them (s_waitcnt vmcnt(0)) before the LDS store of the x tile, including the weight tiles just requested four
+  // k-tiles ahead, which put a full memory round trip into every k-tile.
   uint32_t xsrc[MT];
+  bool xok[MT];
 #pragma unroll
   for (int p = 0; p < MT; ++p) {
-    const int row = 16 * p + srow;
-    if (row < rows) {
-      const int64_t xr = a.x_rows != nullptr ? a.x_rows[row0 + row] : row0 + row;
-      xsrc[p] = (uint32_t)(xr * a.ldx + sslot * 8);
-    } else {
-      xsrc[p] = ~0u;
-    }
+    const int row = min(16 * p + srow, max(rows - 1, 0));
+    xok[p] = 16 * p + srow < rows;
+    const int64_t xr = a.x_rows != nullptr ? a.x_rows[row0 + row] : row0 + row;
+    xsrc[p] = (uint32_t)(xr * a.ldx);
   }
   const int swz = ((sslot ^ srow) & 15) << 4;   // (16 p + srow) & 15 == srow
   // x tiles travel global -> registers -> LDS two k-tiles ahead of their use: tile t sits in register set t & 1
@@ -107,11 +109,14 @@ __global__ __launch_bounds__(256, 2) void gemm_t16_kernel(GemmArgs a) {
   uint4v areg[2][MT];
   auto gload_a = [&](uint4v (&dst)[MT], int kt) {
     const int k = kt * 128 + sslot * 8;
+    const int kc = min(k, a.K - 8);           // K % 32 == 0: the clamped address is a whole valid 16-byte slot
+    const bool kin = k < a.K;
 #pragma unroll
     for (int p = 0; p < MT; ++p) {
-      uint4v v = {0, 0, 0, 0};
-      if (xsrc[p] != ~0u && k < a.K) v = *(const uint4v*)(a.x + xsrc[p] + kt * 128);
-      dst[p] = v;
+      // zeroing by mask, not by a select the compiler could turn back into a branch around the load
+      const uint32_t keep = 0u - (uint32_t)(kin & xok[p]);
+      const uint4v v = *(const uint4v*)(a.x + xsrc[p] + kc);
+      dst[p] = v & uint4v{keep, keep, keep, keep};
     }
   };
   auto store_a = [&](uint4v (&src)[MT], int stage) {
@@ -157,23 +162,24 @@ __global__ __launch_bounds__(256, 2) void gemm_t16_kernel(GemmArgs a) {
     }
   };
 
-  // prologue
+  // prologue.  Tile indices past the end are clamped to the last tile of the range (a redundant load of data that
+  // is already on its way) so that the number of loads per iteration is fixed.
+  const int klast = max(kt1 - 1, kt0);
   gload_a(areg[0], kt0);
 #pragma unroll
-  for (int d = 0; d < DEPTH; ++d)
-    if (kt0 + d < kt1) fetch_b(tt[d], kt0 + d);
+  for (int d = 0; d < DEPTH; ++d) fetch_b(tt[d], min(kt0 + d, klast));
   store_a(areg[0], 0);
-  if (kt0 + 1 < kt1) gload_a(areg[1], kt0 + 1);
+  gload_a(areg[1], min(kt0 + 1, klast));
   __syncthreads();
   for (int kt = kt0; kt < kt1; kt += DEPTH) {
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
       const int k = kt + d;                 // block-uniform
       if (k >= kt1) break;
-      if (k + 2 < kt1) gload_a(areg[d & 1], k + 2);      // (k - kt0) & 1 == d & 1: DEPTH is even
+      gload_a(areg[d & 1], min(k + 2, klast));           // (k - kt0) & 1 == d & 1: DEPTH is even
       compute(tt[d], d & 1);
-      if (k + DEPTH < kt1) fetch_b(tt[d], k + DEPTH);
-      if (k + 1 < kt1) store_a(areg[(d + 1) & 1], (d + 1) & 1);
+      fetch_b(tt[d], min(k + DEPTH, klast));
+      store_a(areg[(d + 1) & 1], (d + 1) & 1);
       __syncthreads();
     }
   }
