@@ -41,11 +41,40 @@ def _save_low_bit(self, save_dir, *args, **kwargs):
 
 @contextmanager
 def low_memory_init():
-    """Build models on the meta device: no storage is allocated for weights that ``load_low_bit`` is about to
-    replace by quantized ones (the reference additionally disables tensor allocation and lazy-unpickles;
-    meta-device construction gives the same effect with stock PyTorch)."""
-    with torch.device("meta"):
-        yield
+    """Build models without allocating storage for weights that ``load_low_bit`` is about to replace by quantized
+    ones.  The reference disables tensor allocation and lazy-unpickles the checkpoint (optimize.py:63-86, 124-134);
+    here modules are constructed on the meta device, and HuggingFace's ``from_pretrained`` (which refuses to run under a
+    meta-device context, and whose weight loading would not match the low-bit buffers anyway) returns the architecture
+    built from the directory's config for the duration of the context:
+
+        with low_memory_init():
+            model = AutoModelForCausalLM.from_pretrained(saved_dir, torch_dtype="auto")
+        model = load_low_bit(model, saved_dir)
+    """
+    import transformers
+    base = transformers.PreTrainedModel
+    original = base.__dict__["from_pretrained"]
+
+    def meta_from_pretrained(cls, pretrained_model_name_or_path, *args, **kwargs):
+        config = kwargs.pop("config", None)
+        if config is None:
+            config = transformers.AutoConfig.from_pretrained(pretrained_model_name_or_path,
+                                                             trust_remote_code=kwargs.get("trust_remote_code", False))
+        dtype = kwargs.get("torch_dtype", kwargs.get("dtype"))
+        if dtype == "auto":
+            dtype = getattr(config, "torch_dtype", None) or getattr(config, "dtype", None)
+        with torch.device("meta"):
+            model = cls(config)
+        if isinstance(dtype, torch.dtype):
+            model = model.to(dtype)
+        return model.eval()
+
+    base.from_pretrained = classmethod(meta_from_pretrained)
+    try:
+        with torch.device("meta"):
+            yield
+    finally:
+        base.from_pretrained = original
 
 
 def load_low_bit(model, model_path):

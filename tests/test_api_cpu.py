@@ -148,6 +148,15 @@ def test_generic_optimize_model_api(tiny_llama, tmp_path):
     ids = torch.randint(0, 320, (1, 6))
     with torch.no_grad():
         assert torch.equal(m(ids).logits, e(ids).logits)
+    # the documented call shape: from_pretrained on the saved directory inside the context
+    with low_memory_init():
+        e2 = transformers.AutoModelForCausalLM.from_pretrained(out, torch_dtype="auto")
+    assert next(e2.parameters()).device.type == "meta"
+    e2 = load_low_bit(e2, out)
+    with torch.no_grad():
+        assert torch.equal(m(ids).logits, e2(ids).logits.to(m(ids).logits.dtype))
+    # and from_pretrained is back to normal afterwards
+    assert next(transformers.AutoModelForCausalLM.from_pretrained(d).parameters()).device.type == "cpu"
 
     class Tiny(torch.nn.Module):   # a plain torch module, no HF
         def __init__(self):

@@ -1,0 +1,80 @@
+"""Example scripts end to end on the GPU against a tiny random checkpoint (the reference runs its examples the same
+way, python/llm/test/run-llm-example-tests-gpu.sh).  Each script runs in its own interpreter, exit status 0 and a
+non-empty output are required."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ckpt(tmp_path_factory):
+    from tokenizers import Tokenizer
+    from tokenizers.models import WordLevel
+    from tokenizers.pre_tokenizers import Whitespace
+    from transformers import LlamaConfig, LlamaForCausalLM, PreTrainedTokenizerFast
+    d = tmp_path_factory.mktemp("tiny_llama")
+    torch.manual_seed(0)
+    cfg = LlamaConfig(vocab_size=320, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                      num_key_value_heads=2, max_position_embeddings=2048, tie_word_embeddings=False)
+    model = LlamaForCausalLM(cfg).eval()
+    model.generation_config.eos_token_id = None
+    model.save_pretrained(str(d), safe_serialization=True)
+    vocab = {"<unk>": 0, "<s>": 1, "</s>": 2}
+    vocab.update({f"w{i}": i + 3 for i in range(317)})
+    t = Tokenizer(WordLevel(vocab, unk_token="<unk>"))
+    t.pre_tokenizer = Whitespace()
+    tok = PreTrainedTokenizerFast(tokenizer_object=t, bos_token="<s>", eos_token="</s>", unk_token="<unk>", pad_token="</s>")
+    tok.save_pretrained(str(d))
+    prompt = d / "prompt.txt"
+    prompt.write_text(" ".join(f"w{(7 * i) % 300}" for i in range(400)))
+    alpaca = d / "alpaca.json"
+    alpaca.write_text(json.dumps([{"instruction": f"w{i} w{i + 1}", "input": "", "output": f"w{i + 2} w{i + 3}"}
+                                  for i in range(16)]))
+    return d
+
+
+def _run(script, *args, timeout=240):
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "GPU", script), *map(str, args)], env=env,
+                       capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, f"{script} failed:\n{r.stdout[-2000:]}\n{r.stderr[-3000:]}"
+    assert r.stdout.strip(), f"{script} printed nothing"
+    return r.stdout
+
+
+def test_generate_and_data_types(ckpt):
+    _run("HuggingFace/generate.py", "--repo-id-or-model-path", ckpt, "--prompt", "w1 w2 w3", "--n-predict", 8)
+    out = _run("HuggingFace/More-Data-Types/generate.py", "--repo-id-or-model-path", ckpt, "--low-bit", "nf4", "fp8_e5m2",
+               "--prompt", "w1 w2 w3", "--n-predict", 8)
+    assert "nf4" in out and "fp8_e5m2" in out
+
+
+def test_save_load_and_generic_optimize(ckpt, tmp_path):
+    _run("Save-Load/save_load.py", "--repo-id-or-model-path", ckpt, "--save-path", tmp_path / "lb")
+    assert (tmp_path / "lb" / "load_keys.json").exists()
+    _run("PyTorch-Models/optimize_any_model.py", "--repo-id-or-model-path", ckpt, "--save-dir", tmp_path / "opt")
+
+
+def test_lookup_speculative_long_context(ckpt):
+    _run("Lookahead/lookup.py", "--repo-id-or-model-path", ckpt, "--prompt-file", ckpt / "prompt.txt", "--n-predict", 16)
+    _run("Speculative-Decoding/speculative.py", "--repo-id-or-model-path", ckpt, "--prompt", "w1 w2 w3", "--n-predict", 16)
+    _run("Long-Context/generate.py", "--repo-id-or-model-path", ckpt, "--prompt-file", ckpt / "prompt.txt", "--n-predict", 8,
+         "--fp8-kv")
+
+
+def test_qlora_finetuning_example(ckpt, tmp_path):
+    _run("LLM-Finetuning/QLoRA/alpaca_qlora_finetuning.py", "--base_model", ckpt, "--data_path", ckpt / "alpaca.json",
+         "--output_dir", tmp_path / "out", "--micro_batch_size", 2, "--batch_size", 4, "--cutoff_len", 32,
+         "--lora_target_modules", "q_proj", "v_proj")
+
+
+def test_graph_mode_example():
+    out = _run("GraphMode/graph_decode.py", "--n-predict", 16)
+    assert "ms" in out
