@@ -67,6 +67,7 @@ class DPOConfig:
     learning_rate: float = 5e-5
     max_grad_norm: float = 0.3
     gradient_accumulation_steps: int = 1
+    bf16: bool = True          # on the GPU the forwards run under bf16 autocast (the reference's TrainingArguments force bf16)
 
 
 class DPOTrainer:
@@ -83,7 +84,9 @@ class DPOTrainer:
         self.history: List[Dict[str, float]] = []
 
     def _logps(self, model, batch):
-        out = model(input_ids=batch["input_ids"], attention_mask=batch.get("attention_mask"))
+        ids = batch["input_ids"]
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.cfg.bf16 and ids.device.type == "cuda"):
+            out = model(input_ids=ids, attention_mask=batch.get("attention_mask"))
         return sequence_logps(out.logits, batch["labels"], average=self.cfg.loss_type == "ipo")
 
     def reference_logps(self, batch):

@@ -336,8 +336,8 @@ class LowBitLinear(nn.Linear):
                 x = x.to(torch.get_autocast_dtype(x.device.type))
         if self.bias is not None and self.bias.dtype != x.dtype:
             self.bias.data = self.bias.data.to(x.dtype)
-        if self.optimize_lm_head:
-            x = reshape_lm_head_input(x)
+        if self.optimize_lm_head and not (self.training and torch.is_grad_enabled()):
+            x = reshape_lm_head_input(x)       # inference only: a training step needs the logits of every position
         new_shape = x.shape[:-1] + (self.out_len,)
         if 0 in x.shape:
             return torch.empty(new_shape, dtype=x.dtype, device=x.device)
@@ -378,7 +378,7 @@ class _HalfLinear(nn.Linear):
         self.compute_dtype = None
 
     def forward(self, x: torch.Tensor):
-        if self.optimize_lm_head:
+        if self.optimize_lm_head and not (self.training and torch.is_grad_enabled()):
             x = reshape_lm_head_input(x)
         if self.weight.dtype != self._dtype:
             self.weight.data = self.weight.data.to(self._dtype)

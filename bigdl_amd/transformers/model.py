@@ -165,6 +165,12 @@ def _materialize_meta_buffers(model):
                 module._buffers[bname] = torch.zeros(buf.shape, dtype=buf.dtype, device="cpu")
 
 
+def _one_rank_pipeline(stages) -> bool:
+    """``pipeline_parallel_stages=1`` passed explicitly while a one-rank process group is up"""
+    return stages == 1 and torch.distributed.is_available() and torch.distributed.is_initialized() \
+        and torch.distributed.get_world_size() == 1
+
+
 class _BaseAutoModelClass:
     HF_MODEL = None
 
@@ -208,7 +214,7 @@ class _BaseAutoModelClass:
         optimize_model = kwargs.pop("optimize_model", True)
         user_quantization_config = kwargs.pop("quantization_config", None)
         speculative = kwargs.pop("speculative", False)
-        pipeline_parallel_stages = kwargs.pop("pipeline_parallel_stages", 1)
+        pipeline_parallel_stages = kwargs.pop("pipeline_parallel_stages", 0) or 0
         torch_dtype = kwargs.pop("torch_dtype", kwargs.pop("dtype", None))
         embedding_qtype = kwargs.pop("embedding_qtype", None)
 
@@ -302,7 +308,9 @@ class _BaseAutoModelClass:
         kwargs["embedding_qtype"] = embedding_qtype
         model = cls.load_convert(q_k, optimize_model, *args, **kwargs)
 
-        if pipeline_parallel_stages > 1:
+        # one stage under an initialized one-rank process group is a valid (degenerate) pipeline: same code path,
+        # same timing attributes, no peers to talk to
+        if pipeline_parallel_stages > 1 or _one_rank_pipeline(pipeline_parallel_stages):
             invalidInputError(not speculative, "Please do not set speculative=True when using pipeline_parallel_stages")
             invalidInputError(torch.distributed.is_initialized() and
                               torch.distributed.get_world_size() == pipeline_parallel_stages,
@@ -423,7 +431,7 @@ class _BaseAutoModelClass:
         cpu_embedding = kwargs.pop("cpu_embedding", False)
         embedding_qtype = kwargs.pop("embedding_qtype", None)
         disk_embedding = kwargs.pop("disk_embedding", False)
-        pipeline_parallel_stages = kwargs.pop("pipeline_parallel_stages", 1)
+        pipeline_parallel_stages = kwargs.pop("pipeline_parallel_stages", 0) or 0
         speculative = kwargs.pop("speculative", False)
         torch_dtype = kwargs.pop("torch_dtype", kwargs.pop("dtype", "auto"))
         trust_remote_code = kwargs.pop("trust_remote_code", False)
@@ -522,7 +530,7 @@ class _BaseAutoModelClass:
             except Exception:
                 pass
         model.save_low_bit = types.MethodType(save_low_bit, model)
-        if pipeline_parallel_stages > 1:
+        if pipeline_parallel_stages > 1 or _one_rank_pipeline(pipeline_parallel_stages):
             from .pipeline_parallel import pipeline_parallel, pipeline_parallel_generate
             model = pipeline_parallel(model, pipeline_parallel_stages, dt)
             model.pipeline_parallel_generate = types.MethodType(pipeline_parallel_generate, model)

@@ -127,7 +127,7 @@ def pipeline_parallel(model, pipeline_parallel_stages, torch_dtype=torch.float32
 
 def generate(self, inputs=None, generation_config=None, streamer=None, **kwargs):
     """``model.generate`` of a pipelined model: greedy pipelined decoding."""
-    if getattr(self, "pipeline_parallel_stages", 1) > 1:
+    if getattr(self, "pipeline_parallel_stages", 0) >= 1:
         for k in ("do_sample", "num_beams"):
             if kwargs.get(k) not in (None, False, 1):
                 invalidInputError(False, f"pipeline parallel generation is greedy; got {k}={kwargs[k]}")

@@ -37,7 +37,8 @@ if __name__ == "__main__":
     g = torch.Generator().manual_seed(dist.get_rank())
     for step in range(args.steps):
         ids = torch.randint(0, vocab, (args.micro_batch, args.seq_len), generator=g).cuda()   # synthetic batch
-        loss = model(input_ids=ids, labels=ids).loss
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = model(input_ids=ids, labels=ids).loss
         loss.backward()
         opt.step()
         if dist.get_rank() == 0:

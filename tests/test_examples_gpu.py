@@ -37,7 +37,19 @@ def ckpt(tmp_path_factory):
     alpaca = d / "alpaca.json"
     alpaca.write_text(json.dumps([{"instruction": f"w{i} w{i + 1}", "input": "", "output": f"w{i + 2} w{i + 3}"}
                                   for i in range(16)]))
+    (d / "pairs.jsonl").write_text("\n".join(json.dumps({"prompt": f"w{i} w{i + 1}", "chosen": f"w{i + 2} w{i + 3}",
+                                                          "rejected": f"w{i + 9} w{i + 5}"}) for i in range(8)))
+    (d / "lines.txt").write_text("\n".join(" ".join(f"w{(3 * i + j) % 300}" for j in range(12)) for i in range(32)))
     return d
+
+
+def _torchrun(script, *args, timeout=300):
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1",
+                        "--nproc-per-node", "1", os.path.join(ROOT, "examples", "GPU", script), *map(str, args)], env=env,
+                       capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, f"{script} failed:\n{r.stdout[-2000:]}\n{r.stderr[-3000:]}"
+    return r.stdout
 
 
 def _run(script, *args, timeout=240):
@@ -78,3 +90,32 @@ def test_qlora_finetuning_example(ckpt, tmp_path):
 def test_graph_mode_example():
     out = _run("GraphMode/graph_decode.py", "--n-predict", 16)
     assert "ms" in out
+
+
+def test_more_finetuning_examples(ckpt, tmp_path):
+    _run("LLM-Finetuning/DPO/dpo_finetuning.py", "--repo-id-or-model-path", ckpt, "--dataset", ckpt / "pairs.jsonl",
+         "--output-path", tmp_path / "dpo", "--micro-batch", 2, "--grad-accum", 1, "--max-steps", 2)
+    _run("LLM-Finetuning/GaLore/galore_finetuning.py", "--repo-id-or-model-path", ckpt, "--data-path", ckpt / "alpaca.json",
+         "--output-dir", tmp_path / "galore", "--rank", 8, "--max-steps", 3, "--cutoff-len", 32)
+    _run("LLM-Finetuning/LISA/lisa_finetuning.py", "--base_model", ckpt, "--text_file", ckpt / "lines.txt", "--steps", 4,
+         "--lisa_interval_steps", 2)
+    _torchrun("LLM-Finetuning/ZeRO/qlora_zero.py", "--base", ckpt, "--stage", 3, "--steps", 2, "--micro-batch", 2,
+              "--seq-len", 16)
+
+
+def test_parallel_examples_with_one_rank(ckpt):
+    """world size 1: the sharding / staging code paths run, the collectives are no-ops"""
+    out = _torchrun("Tensor-Parallel/generate.py", "--repo-id-or-model-path", ckpt, "--prompt", "w1 w2 w3", "--n-predict", 8)
+    assert out.strip()
+    out = _torchrun("Pipeline-Parallel-Inference/generate.py", "--repo-id-or-model-path", ckpt, "--prompt", "w1 w2 w3",
+                    "--n-predict", 8, "--gpu-num", 1)
+    assert out.strip()
+
+
+def test_unmodified_hf_peft_script(ckpt, tmp_path):
+    """llm_patch(train=True) + a stock transformers / peft training script (200 optimizer steps on the tiny model)"""
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "GPU", "LLM-Finetuning", "HF-PEFT",
+                                                     "alpaca_lora_unmodified.py"), str(ckpt), str(ckpt / "lines.txt")],
+                       env=env, capture_output=True, text=True, timeout=500, cwd=str(tmp_path))
+    assert r.returncode == 0, f"{r.stdout[-1500:]}\n{r.stderr[-3000:]}"

@@ -46,3 +46,28 @@ def test_benchmark_config_schema():
               "test_api", "cpu_embedding", "streaming"):
         assert k in conf
     assert "1024-128" in conf["in_out_pairs"]
+
+
+def test_llm_patch_rebinds_names_for_unmodified_scripts():
+    """After llm_patch(train=True) a stock script's ``from transformers import AutoModelForCausalLM`` and
+    ``from peft import LoraConfig, get_peft_model`` resolve to this library (PEFT itself is optional)."""
+    import subprocess
+    import sys
+    code = (
+        "from ipex_llm import llm_patch\n"
+        "llm_patch(train=True)\n"
+        "import transformers\n"
+        "from transformers import AutoModelForCausalLM, TrainingArguments\n"
+        "from peft import LoraConfig, get_peft_model, prepare_model_for_kbit_training\n"
+        "assert AutoModelForCausalLM.__module__.startswith('bigdl_amd'), AutoModelForCausalLM\n"
+        "assert TrainingArguments.__module__.startswith('bigdl_amd'), TrainingArguments\n"
+        "assert get_peft_model.__module__.startswith('bigdl_amd')\n"
+        "from ipex_llm.llm_patching import llm_unpatch\n"
+        "llm_unpatch()\n"
+        "assert transformers.AutoModelForCausalLM.__module__.startswith('transformers')\n"
+        "print('ok')\n")
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, PYTHONPATH=root))
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]

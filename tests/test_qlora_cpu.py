@@ -155,3 +155,24 @@ def test_data_parallel_matches_full_batch():
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     mp.spawn(_dp_worker, args=(port,), nprocs=2, join=True)
+
+
+def test_training_forward_keeps_all_positions_through_a_converted_lm_head():
+    """The last-token lm_head shortcut is an inference optimisation: a training step with labels on a sequence longer
+    than 10 tokens needs logits for every position."""
+    import torch
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from bigdl_amd import optimize_model
+    torch.manual_seed(0)
+    cfg = LlamaConfig(vocab_size=64, hidden_size=64, intermediate_size=128, num_hidden_layers=1, num_attention_heads=4,
+                      num_key_value_heads=4, max_position_embeddings=64)
+    m = optimize_model(LlamaForCausalLM(cfg), low_bit="bf16")
+    ids = torch.randint(0, 64, (2, 14))
+    m.eval()
+    with torch.no_grad():
+        assert m(input_ids=ids).logits.shape[1] == 1
+    m.train()
+    for p in m.parameters():
+        p.requires_grad_(p.is_floating_point())
+    out = m(input_ids=ids, labels=ids)
+    assert out.logits.shape[1] == 14 and torch.isfinite(out.loss)
