@@ -119,3 +119,69 @@ def test_unmodified_hf_peft_script(ckpt, tmp_path):
                                                      "alpaca_lora_unmodified.py"), str(ckpt), str(ckpt / "lines.txt")],
                        env=env, capture_output=True, text=True, timeout=500, cwd=str(tmp_path))
     assert r.returncode == 0, f"{r.stdout[-1500:]}\n{r.stderr[-3000:]}"
+
+
+@pytest.fixture(scope="module")
+def moe_ckpt(ckpt, tmp_path_factory):
+    import shutil
+    from transformers import MixtralConfig, MixtralForCausalLM
+    d = tmp_path_factory.mktemp("tiny_mixtral")
+    torch.manual_seed(0)
+    cfg = MixtralConfig(vocab_size=320, hidden_size=256, intermediate_size=256, num_hidden_layers=2, num_attention_heads=4,
+                        num_key_value_heads=2, num_local_experts=4, num_experts_per_tok=2, max_position_embeddings=512)
+    model = MixtralForCausalLM(cfg).eval()
+    model.generation_config.eos_token_id = None
+    model.save_pretrained(str(d), safe_serialization=True)
+    for f in os.listdir(ckpt):
+        if "token" in f:
+            shutil.copy(os.path.join(ckpt, f), os.path.join(d, f))
+    return d
+
+
+def test_moe_examples(moe_ckpt):
+    _run("CPU-GPU-Hybrid/generate.py", "--repo-id-or-model-path", moe_ckpt, "--prompt", "w1 w2 w3", "--n-predict", 6,
+         "--gpu-layers", 1)
+    for mode in ("a2a", "allreduce"):
+        out = _torchrun("MoE/mixtral_expert_parallel.py", "--repo-id-or-model-path", moe_ckpt, "--mode", mode,
+                        "--n-predict", 8)
+        assert out.strip()
+
+
+def _serve_and_query(script, *args, port):
+    """start a server example, wait for /health, stream one request, stop the exact process that was started"""
+    import json as js
+    import time
+    import urllib.request
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, "examples", "GPU", script), *map(str, args), "--port", str(port)],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    try:
+        deadline = time.time() + 120
+        while True:
+            assert p.poll() is None, "server exited:\n" + p.stdout.read()[-3000:]
+            try:
+                urllib.request.urlopen(f"http://127.0.0.1:{port}/health", timeout=2).read()
+                break
+            except Exception:
+                assert time.time() < deadline, "server did not come up"
+                time.sleep(1.0)
+        body = js.dumps({"inputs": "w1 w2 w3 w4", "parameters": {"max_new_tokens": 8}}).encode()
+        req = urllib.request.Request(f"http://127.0.0.1:{port}/generate", data=body, headers={"Content-Type": "application/json"})
+        out = js.loads(urllib.request.urlopen(req, timeout=60).read())
+        assert out["generate_tokens"] >= 1
+        body = js.dumps({"model": "m", "prompt": "w5 w6", "max_tokens": 6}).encode()
+        req = urllib.request.Request(f"http://127.0.0.1:{port}/v1/completions", data=body, headers={"Content-Type": "application/json"})
+        out = js.loads(urllib.request.urlopen(req, timeout=60).read())
+        assert out["choices"][0]["text"] is not None
+    finally:
+        p.terminate()
+        try:
+            p.wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            p.kill()
+
+
+def test_serving_examples(ckpt):
+    _serve_and_query("Lightweight-Serving/lightweight_serving.py", "--repo-id-or-model-path", ckpt, port=18431)
+    _serve_and_query("Continuous-Batching/serve.py", "--repo-id-or-model-path", ckpt, "--max-num-seqs", 4, "--max-seq-len", 256,
+                     port=18432)
