@@ -185,3 +185,14 @@ def test_serving_examples(ckpt):
     _serve_and_query("Lightweight-Serving/lightweight_serving.py", "--repo-id-or-model-path", ckpt, port=18431)
     _serve_and_query("Continuous-Batching/serve.py", "--repo-id-or-model-path", ckpt, "--max-num-seqs", 4, "--max-seq-len", 256,
                      port=18432)
+
+
+def test_gguf_example(tmp_path):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gguf_helpers", os.path.join(ROOT, "tests", "test_gguf_cpu.py"))
+    H = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(H)
+    path = str(tmp_path / "tiny.gguf")
+    H._write_llama(H._tiny_llama(), path, H.G.GGML_Q4_0)
+    out = _run("GGUF/generate.py", "--model", path, "--prompt", "hello", "--n-predict", 6)
+    assert out.strip()
