@@ -444,6 +444,7 @@ extern "C" int bigdl_attn_prefill(const void* q, const void* k, const void* v, v
   a.scale = scale; a.softcap = softcap; a.causal = causal; a.window = window; a.v_transposed = v_transposed;
   switch (D) {
     case 64: return launch_pf<64>(a, st);
+    case 96: return launch_pf<96>(a, st);
     case 128: return launch_pf<128>(a, st);
     default: return -2;
   }

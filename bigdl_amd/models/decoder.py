@@ -529,12 +529,12 @@ class NativeDecoder:
     def _sdpa(self, q, k, vt, past, window):
         """q [B,Hq,S,D], k [B,Hkv,past+S,D], vt = V^T [B,Hkv,D,past+S] -> [B, S, Hq*D]"""
         cfg = self.cfg
-        if cfg.head_dim in (64, 128) and vt.stride(2) % 8 == 0 and vt.data_ptr() % 16 == 0:
+        if cfg.head_dim in (64, 96, 128) and vt.stride(2) % 8 == 0 and vt.data_ptr() % 16 == 0:
             from ..ops import hip
             return hip.attn_prefill(q, k, vt, scale=self.attn_scale, causal=True, softcap=cfg.attn_softcap, window=window,
                                     v_transposed=True, alibi=self.alibi)
         if self.alibi is not None:
-            raise NotImplementedError("ALiBi attention needs head_dim 64 or 128")
+            raise NotImplementedError("ALiBi attention needs head_dim 64, 96 or 128")
         return self._sdpa_torch(q, k, vt.transpose(-1, -2), past, window).transpose(1, 2).reshape(q.shape[0], q.shape[2], -1)
 
     def _sdpa_torch(self, q, k, v, past, window):

@@ -694,6 +694,9 @@ def attn_decode(qkv, k_cache, v_cache, past_len, out, ws, counters, *, n_heads, 
     return out
 
 
+PREFILL_HEAD_DIMS = (64, 96, 128)
+
+
 def _check_alibi(alibi, n_heads):
     if alibi is not None and (alibi.dtype != torch.float32 or alibi.numel() != n_heads or not alibi.is_contiguous()
                               or alibi.device.type != "cuda"):
@@ -709,8 +712,8 @@ def attn_prefill(q, k, v, *, scale, causal=True, mask=None, softcap=0.0, window=
     _need_cuda(q, k, v, mask, out)
     b, hq, sq, d = q.shape
     hkv, lk = k.shape[1], k.shape[2]
-    if d not in (64, 128):
-        raise ValueError("attn_prefill supports head_dim 64 and 128")
+    if d not in PREFILL_HEAD_DIMS:
+        raise ValueError("attn_prefill supports head_dim 64, 96 and 128")
     for t in (q, k, v):
         if t.dtype != torch.float16 or t.stride(-1) != 1:
             raise ValueError("q / k / v must be fp16 with a contiguous last dim")
