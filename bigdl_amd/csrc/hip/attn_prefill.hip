@@ -38,8 +38,10 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(PrefillArgs a) {
   constexpr int KS = D + 8;          // halves per K row in LDS (16 B pad)
   constexpr int VS = PF_BN + 8;      // halves per V^T row
   constexpr int DB = D / 16, STEPS = D / 32, CH = D / 8;
-  __shared__ __attribute__((aligned(16))) _Float16 Ks[PF_BN * KS];
-  __shared__ __attribute__((aligned(16))) _Float16 Vt[D * VS];
+  // dynamic LDS: head_dim 256 needs 69 KiB (above the 64 KiB a kernel gets without asking)
+  extern __shared__ __attribute__((aligned(16))) _Float16 pf_smem[];
+  _Float16* Ks = pf_smem;                    // [PF_BN][KS]
+  _Float16* Vt = pf_smem + PF_BN * KS;       // [D][VS]
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, g = lane >> 4;
@@ -402,17 +404,25 @@ extern "C" int bigdl_prefill_rope_append(void* qkv, void* kc, void* vc, void* vt
   return HIP_CHECK_LAUNCH();
 }
 
+template <int D, bool HAS_MASK, bool VT, int QB>
+static int launch_pf_one(const PrefillArgs& a, hipStream_t st) {
+  const dim3 grid((a.Sq + 64 * QB - 1) / (64 * QB), a.Hq, a.B), block(256);
+  constexpr size_t lds = ((size_t)PF_BN * (D + 8) + (size_t)D * (PF_BN + 8)) * 2;
+  static bool attr = false;
+  if (!attr && lds > 65536) {
+    if (hipFuncSetAttribute((const void*)attn_prefill_kernel<D, HAS_MASK, VT, QB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+      return -5;
+    attr = true;
+  }
+  hipLaunchKernelGGL((attn_prefill_kernel<D, HAS_MASK, VT, QB>), grid, block, lds, st, a);
+  return HIP_CHECK_LAUNCH();
+}
+
 template <int D, int QB>
 static int launch_pf_qb(const PrefillArgs& a, hipStream_t st) {
-  const dim3 grid((a.Sq + 64 * QB - 1) / (64 * QB), a.Hq, a.B), block(256);
-  if (a.mask) {
-    if (a.v_transposed) hipLaunchKernelGGL((attn_prefill_kernel<D, true, true, QB>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((attn_prefill_kernel<D, true, false, QB>), grid, block, 0, st, a);
-  } else {
-    if (a.v_transposed) hipLaunchKernelGGL((attn_prefill_kernel<D, false, true, QB>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((attn_prefill_kernel<D, false, false, QB>), grid, block, 0, st, a);
-  }
-  return HIP_CHECK_LAUNCH();
+  if (a.mask) return a.v_transposed ? launch_pf_one<D, true, true, QB>(a, st) : launch_pf_one<D, true, false, QB>(a, st);
+  return a.v_transposed ? launch_pf_one<D, false, true, QB>(a, st) : launch_pf_one<D, false, false, QB>(a, st);
 }
 
 template <int D>
@@ -446,6 +456,7 @@ extern "C" int bigdl_attn_prefill(const void* q, const void* k, const void* v, v
     case 64: return launch_pf<64>(a, st);
     case 96: return launch_pf<96>(a, st);
     case 128: return launch_pf<128>(a, st);
+    case 256: return launch_pf<256>(a, st);
     default: return -2;
   }
 }

@@ -529,7 +529,7 @@ class NativeDecoder:
     def _sdpa(self, q, k, vt, past, window):
         """q [B,Hq,S,D], k [B,Hkv,past+S,D], vt = V^T [B,Hkv,D,past+S] -> [B, S, Hq*D]"""
         cfg = self.cfg
-        if cfg.head_dim in (64, 96, 128) and vt.stride(2) % 8 == 0 and vt.data_ptr() % 16 == 0:
+        if cfg.head_dim in (64, 96, 128, 256) and vt.stride(2) % 8 == 0 and vt.data_ptr() % 16 == 0:
             from ..ops import hip
             return hip.attn_prefill(q, k, vt, scale=self.attn_scale, causal=True, softcap=cfg.attn_softcap, window=window,
                                     v_transposed=True, alibi=self.alibi)

@@ -694,7 +694,7 @@ def attn_decode(qkv, k_cache, v_cache, past_len, out, ws, counters, *, n_heads, 
     return out
 
 
-PREFILL_HEAD_DIMS = (64, 96, 128)
+PREFILL_HEAD_DIMS = (64, 96, 128, 256)
 
 
 def _check_alibi(alibi, n_heads):
@@ -713,7 +713,7 @@ def attn_prefill(q, k, v, *, scale, causal=True, mask=None, softcap=0.0, window=
     b, hq, sq, d = q.shape
     hkv, lk = k.shape[1], k.shape[2]
     if d not in PREFILL_HEAD_DIMS:
-        raise ValueError("attn_prefill supports head_dim 64, 96 and 128")
+        raise ValueError("attn_prefill supports head_dim 64, 96, 128 and 256")
     for t in (q, k, v):
         if t.dtype != torch.float16 or t.stride(-1) != 1:
             raise ValueError("q / k / v must be fp16 with a contiguous last dim")

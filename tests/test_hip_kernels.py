@@ -496,7 +496,8 @@ def _sdpa_ref(q, k, v, scale, causal, mask=None, softcap=0.0, window=0):
 
 @pytest.mark.parametrize("cfg", [(1, 8, 8, 128, 200, 200, True), (2, 8, 2, 64, 77, 77, True), (1, 4, 4, 128, 64, 300, True),
                                  (1, 4, 2, 128, 130, 130, False), (2, 4, 1, 64, 33, 90, False),
-                                 (1, 6, 6, 96, 150, 150, True), (2, 4, 2, 96, 70, 133, True), (1, 4, 4, 96, 65, 65, False)])
+                                 (1, 6, 6, 96, 150, 150, True), (2, 4, 2, 96, 70, 133, True), (1, 4, 4, 96, 65, 65, False),
+                                 (1, 4, 2, 256, 140, 140, True), (2, 2, 1, 256, 33, 100, False)])
 def test_attn_prefill_matches_reference(hip, cfg):
     b, hq, hkv, d, sq, lk, causal = cfg
     torch.manual_seed(30)
