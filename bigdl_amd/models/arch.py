@@ -567,6 +567,41 @@ def convert_gptj(cfg: dict, sd: StateDict):
     return dc, out
 
 
+ENGINE_HEAD_DIMS = (64, 96, 128, 256)
+
+
+def pad_head_dim(dc: DecoderConfig, sd: StateDict):
+    """Bring an odd head_dim (80: phi-2 / stablelm-3b, 72, 112, 160, 192) to the next size the attention kernels are
+    built for by zero-padding every head: extra q / k channels add 0 to the scores, extra v channels produce zeros
+    that the zero columns of o_proj ignore.  The softmax scale and the rotary dimension keep their original values
+    (reference: models/common.py:55-115 padding helpers, models/minicpm3.py ``padding_v_head_dim``)."""
+    d = dc.head_dim
+    if d in ENGINE_HEAD_DIMS or d > max(ENGINE_HEAD_DIMS):
+        return dc, sd
+    import dataclasses
+    nd = min(x for x in ENGINE_HEAD_DIMS if x > d)
+    hq, hkv = dc.num_heads, dc.num_kv_heads
+    out = dict(sd)
+
+    def pad_rows(t, heads):          # [heads * d, ...] -> [heads * nd, ...]
+        t = t.reshape(heads, d, *t.shape[1:])
+        z = torch.zeros(heads, nd - d, *t.shape[2:], dtype=t.dtype)
+        return torch.cat([t, z], 1).reshape(heads * nd, *t.shape[2:])
+
+    for i in range(dc.num_layers if sd else 0):
+        for key in (f"L{i}.qkv", f"L{i}.qkv.bias"):
+            if key in sd:
+                t = sd[key]
+                q, k, v = t[: hq * d], t[hq * d:(hq + hkv) * d], t[(hq + hkv) * d:]
+                out[key] = torch.cat([pad_rows(q, hq), pad_rows(k, hkv), pad_rows(v, hkv)], 0)
+        o = sd[f"L{i}.o"]                                              # [hidden, hq * d]
+        o = o.reshape(o.shape[0], hq, d)
+        out[f"L{i}.o"] = torch.cat([o, torch.zeros(o.shape[0], hq, nd - d, dtype=o.dtype)], 2).reshape(o.shape[0], hq * nd)
+    ndc = dataclasses.replace(dc, head_dim=nd, rot_dim=dc.rot_dim or d,
+                              attn_scale=dc.attn_scale if dc.attn_scale is not None else 1.0 / math.sqrt(d))
+    return ndc, out
+
+
 LN_CONVERTERS = {"gpt_neox": convert_gpt_neox, "bloom": convert_bloom, "mpt": convert_mpt, "falcon": convert_falcon,
                  "gpt2": convert_gpt2, "gpt_bigcode": convert_gpt_bigcode, "opt": convert_opt, "phi": convert_phi,
                  "starcoder2": convert_starcoder2, "stablelm": convert_stablelm, "gptj": convert_gptj}
@@ -739,7 +774,7 @@ class NativeCausalLM:
         mt = cfg.get("model_type")
         if mt not in ARCH_CONVERTERS:
             raise ValueError(f"no native weight map for model_type {mt!r}")
-        dc, canon = ARCH_CONVERTERS[mt](cfg, sd)
+        dc, canon = pad_head_dim(*ARCH_CONVERTERS[mt](cfg, sd))
         return cls(dc, quantize_canonical(canon, Q.ggml_tensor_qtype[low_bit]), low_bit, cfg)
 
     @classmethod
@@ -832,7 +867,7 @@ class NativeCausalLM:
         meta = cfg.pop("bigdl_native_arch")["quantized"]
         low_bit = cfg.pop("bigdl_transformers_low_bit")
         tensors = torch.load(os.path.join(path, "pytorch_model.bin"), weights_only=True)
-        dc = arch_config_only(cfg)
+        dc = arch_config_only(cfg, padded=True)
         qsd = {}
         for name, t in tensors.items():
             if name in meta:
@@ -843,8 +878,11 @@ class NativeCausalLM:
         return cls(dc, qsd, low_bit, cfg)
 
 
-def arch_config_only(cfg: dict) -> DecoderConfig:
-    """DecoderConfig of a family from its config dict alone (the converters only read shapes from the tensors)."""
+def arch_config_only(cfg: dict, padded: bool = False) -> DecoderConfig:
+    """DecoderConfig of a family from its config dict alone (the converters only read shapes from the tensors);
+    ``padded``: as ``NativeCausalLM`` holds it, with an odd head_dim brought to a kernel size."""
+    if padded:
+        return pad_head_dim(arch_config_only(cfg), {})[0] if _needs_pad(arch_config_only(cfg)) else arch_config_only(cfg)
     mt = cfg.get("model_type")
     probe = {"chatglm": _probe_chatglm, "minicpm": _probe_minicpm}.get(mt)
     if probe is not None:
@@ -857,6 +895,10 @@ def arch_config_only(cfg: dict) -> DecoderConfig:
         return _base_config(cfg, "qwen", intermediate_size=cfg["intermediate_size"] // 2,
                             head_dim=_get(cfg, "kv_channels", default=cfg["hidden_size"] // cfg["num_attention_heads"]))
     return _base_config(cfg, mt)
+
+
+def _needs_pad(dc):
+    return dc.head_dim not in ENGINE_HEAD_DIMS and dc.head_dim < max(ENGINE_HEAD_DIMS)
 
 
 def _probe_chatglm(cfg):

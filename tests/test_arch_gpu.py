@@ -67,3 +67,26 @@ def test_layernorm_family_engine_matches_cpu_forward(family):
     # batched decode rows agree with the single-sequence run
     out2 = model.generate(ids.repeat(2, 1).cuda(), max_new_tokens=6)
     assert torch.equal(out2[0], out2[1])
+
+
+def test_padded_head_dim_engine_matches_cpu_forward():
+    """head_dim 80 (phi-2 class) runs on the engine as zero-padded 96-wide heads"""
+    import json
+    import transformers as T
+    from bigdl_amd.models import arch
+    torch.manual_seed(0)
+    cfg = T.PhiConfig(vocab_size=96, hidden_size=320, num_hidden_layers=2, intermediate_size=512, num_attention_heads=4,
+                      partial_rotary_factor=0.4, max_position_embeddings=128)
+    hf = T.PhiForCausalLM(cfg).eval().float()
+    cd = json.loads(cfg.to_json_string())
+    model = arch.NativeCausalLM.from_state_dict(cd, {k: v.detach() for k, v in hf.state_dict().items()}, low_bit="sym_int8")
+    assert model.dc.head_dim == 96
+    ids = torch.randint(0, 96, (1, 21))
+    want, _ = model(ids)
+    ref_tokens = model.generate(ids, max_new_tokens=6)
+    model.to("cuda")
+    got, _ = model(ids.cuda())
+    rel = ((got.float().cpu() - want).abs().mean() / want.abs().mean()).item()
+    assert rel < 0.03, rel
+    out = model.generate(ids.cuda(), max_new_tokens=6)
+    assert (out.cpu() == ref_tokens).float().mean() > 0.9

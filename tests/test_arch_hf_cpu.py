@@ -109,3 +109,23 @@ def test_from_pretrained_native_engine_opt_in(tmp_path):
     again = AutoModelForCausalLM.load_low_bit(str(tmp_path / "lb"))
     assert again.dc == native.dc
     assert torch.equal(again.generate(ids, max_new_tokens=3), native.generate(ids, max_new_tokens=3))
+
+
+def test_odd_head_dim_is_padded_to_a_kernel_size():
+    """phi-2 class head_dim 80 -> 96 by zero-padding heads: same logits, original softmax scale and rotary dim."""
+    torch.manual_seed(0)
+    cfg, model = _mk(T.PhiConfig, T.PhiForCausalLM, vocab_size=V, hidden_size=320, num_hidden_layers=2, intermediate_size=256,
+                     num_attention_heads=4, partial_rotary_factor=0.4, max_position_embeddings=64)
+    ids = torch.randint(0, V, (2, 12))
+    with torch.no_grad():
+        want = model(ids).logits.float()
+    cd = json.loads(cfg.to_json_string())
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    dc, canon = arch.ARCH_CONVERTERS["phi"](cd, sd)
+    assert dc.head_dim == 80
+    pdc, pcanon = arch.pad_head_dim(dc, canon)
+    assert pdc.head_dim == 96 and pdc.rot_dim == 32 and abs(pdc.attn_scale - 80 ** -0.5) < 1e-9
+    assert pcanon["L0.qkv"].shape[0] == 3 * 4 * 96 and pcanon["L0.o"].shape[1] == 4 * 96
+    got, _ = arch.reference_forward(pdc, pcanon, ids)
+    torch.testing.assert_close(got, want, rtol=2e-4, atol=2e-4)
+    assert arch.arch_config_only(cd, padded=True) == pdc
