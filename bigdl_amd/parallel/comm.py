@@ -59,6 +59,18 @@ def init_distributed(backend: Optional[str] = None, timeout_s: int = 1800):
     return dist.get_rank(), dist.get_world_size(), device
 
 
+def staggered_wait(local_rank: Optional[int] = None):
+    """``RANK_WAIT_TIME`` seconds (default 0) times the local rank before a rank starts loading its copy of the
+    checkpoint, so that the ranks of one host do not hold full-precision state dicts in host memory at the same time
+    (reference: example/GPU/Deepspeed-AutoTP/deepspeed_autotp.py:69-73)."""
+    import time
+    wait = float(os.environ.get("RANK_WAIT_TIME", 0))
+    if wait > 0:
+        if local_rank is None:
+            local_rank = get_rank_world_from_env()[2]
+        time.sleep(wait * local_rank)
+
+
 def rank() -> int:
     return dist.get_rank() if dist.is_initialized() else 0
 

@@ -7,6 +7,7 @@ assembly from chat messages, background ``process_requests`` loop started at app
 from __future__ import annotations
 
 import asyncio
+import os
 import json
 import uuid
 from typing import List, Optional
@@ -97,6 +98,7 @@ class FastApp:
         self.processor = myprocessor
         self.name = served_model_name
         self.default_max = max_new_tokens_default
+        self.token_timeout = float(os.environ.get("IPEX_LLM_FASTAPI_TIMEOUT", 60))
         self.app = FastAPI(title="bigdl_amd lightweight serving")
         self._task = None
         self._routes()
@@ -122,7 +124,13 @@ class FastApp:
         text = ""
         try:
             while True:
-                delta, done = await q.get()
+                try:
+                    # IPEX_LLM_FASTAPI_TIMEOUT (seconds, default 60): a request whose worker stops producing tokens
+                    # ends with what it has instead of holding the connection (reference api_server.py:114-116)
+                    delta, done = await asyncio.wait_for(q.get(), timeout=self.token_timeout)
+                except asyncio.TimeoutError:
+                    yield "", True
+                    return
                 text += delta
                 cut = min((text.find(s) for s in req.stop if s and s in text), default=-1)
                 if cut >= 0:

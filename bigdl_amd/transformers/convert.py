@@ -78,9 +78,9 @@ def is_linear_module(module):
     if cls == "Conv1D" and hasattr(module, "nf") and getattr(module, "weight", None) is not None and module.weight.dim() == 2:
         # GPT-2 style transposed linear: weight [in, out]
         return True, (module.weight.shape[0], module.weight.shape[1], None)
-    if cls in ("ColumnParallelLinear", "RowParallelLinear", "QKVParallelLinear", "MergedColumnParallelLinear",
-               "ParallelLMHead"):
-        # vLLM tensor-parallel linears: per-partition sizes, TP group only for row-parallel outputs
+    if os.environ.get("IPEX_LLM_NOT_USE_VLLM") is None and cls in (
+            "ColumnParallelLinear", "RowParallelLinear", "QKVParallelLinear", "MergedColumnParallelLinear", "ParallelLMHead"):
+        # vLLM tensor-parallel linears (IPEX_LLM_NOT_USE_VLLM set: never treat modules as vLLM's, reference convert.py:73): per-partition sizes, TP group only for row-parallel outputs
         if cls == "ParallelLMHead":
             return True, (module.embedding_dim, module.num_embeddings_per_partition, None)
         in_features = getattr(module, "input_size_per_partition", getattr(module, "input_size", None))

@@ -7,6 +7,7 @@ import torch
 from transformers import AutoTokenizer
 
 from bigdl_amd.parallel import init_distributed
+from bigdl_amd.parallel.comm import staggered_wait
 from bigdl_amd.parallel.tensor_parallel import tensor_parallel
 from ipex_llm.transformers import AutoModelForCausalLM
 
@@ -18,6 +19,7 @@ if __name__ == "__main__":
     ap.add_argument("--low-bit", default="sym_int4")
     a = ap.parse_args()
     rank, world, device = init_distributed()
+    staggered_wait()                                         # RANK_WAIT_TIME=<s>: ranks load one after another
     model = AutoModelForCausalLM.from_pretrained(a.repo_id_or_model_path, load_in_low_bit=a.low_bit, optimize_model=True,
                                                  torch_dtype=torch.float16)
     model = tensor_parallel(model).half().to(device)        # shard on the host, then move this rank's shard
