@@ -71,11 +71,30 @@ def run_native_engine_gpu(repo_id, local_model_hub, in_out_pairs, warm_up, num_t
     return rows
 
 
-def _load_hf(repo_id, hub, low_bit, conf, device, **extra):
+def _load_hf(repo_id, hub, low_bit, conf, device, plain=False, tensor_parallel=False, **extra):
     from transformers import AutoTokenizer
     from bigdl_amd.transformers import AutoModelForCausalLM
     path = os.path.join(hub, os.path.basename(repo_id)) if hub else repo_id
     dt = torch.float16 if conf.get("use_fp16_torch_dtype", True) and device != "cpu" else "auto"
+    if plain:
+        # unconverted HuggingFace model: the fp16 / bf16 baselines of the reference (ipex_fp16_gpu, pytorch_autocast_bf16)
+        import transformers
+        model = transformers.AutoModelForCausalLM.from_pretrained(path, torch_dtype=torch.float16 if device != "cpu" else torch.bfloat16)
+        tok = AutoTokenizer.from_pretrained(path) if os.path.exists(os.path.join(path, "tokenizer_config.json")) else None
+        return model.to(device).eval(), tok
+    if tensor_parallel:
+        # the reference's deepspeed_optimize_model_gpu / deepspeed_transformer_int4_cpu: one model sharded over the
+        # ranks of the job (torchrun --nproc-per-node N), all-reduce after the row-parallel linears
+        from bigdl_amd.parallel import init_distributed
+        from bigdl_amd.parallel.tensor_parallel import tensor_parallel as shard
+        _, _, dev = init_distributed(backend=None if device != "cpu" else "gloo")
+        model = AutoModelForCausalLM.from_pretrained(path, load_in_low_bit=low_bit, torch_dtype=dt, use_cache=True)
+        model = shard(model)
+        model = model.half().to(dev) if device != "cpu" else model
+        if hasattr(model, "_hf_generate"):
+            model.generate = model._hf_generate          # the sharded modules run through the HF loop, not the engine
+        tok = AutoTokenizer.from_pretrained(path) if os.path.exists(os.path.join(path, "tokenizer_config.json")) else None
+        return model.eval(), tok
     if os.path.exists(os.path.join(path, "bigdl_config.json")) or _is_low_bit_dir(path):
         model = AutoModelForCausalLM.load_low_bit(path, torch_dtype=dt, **extra)
     else:
@@ -110,7 +129,7 @@ def _run_hf_generate(repo_id, hub, in_out_pairs, warm_up, num_trials, low_bit, b
     rows = []
     for pair in in_out_pairs:
         i, o = (int(x) for x in pair.split("-"))
-        ids = _prompt_ids(tok, i, model.config.vocab_size, batch_size).to(device)
+        ids = _prompt_ids(tok, i, model.config.vocab_size, batch_size).to(next(model.parameters()).device)
         firsts, rests = [], []
         for t in range(warm_up + num_trials):
             out = wrapped.generate(ids, max_new_tokens=o, min_new_tokens=o, do_sample=False, **(gen_kwargs or {}))
@@ -145,6 +164,10 @@ def run_model(repo_id, test_api, in_out_pairs, local_model_hub, warm_up, num_tri
         "speculative_gpu": dict(**gpu, load_kwargs=dict(speculative=True)),
         "speculative_cpu": dict(device="cpu", load_kwargs=dict(speculative=True)),
         "pipeline_parallel_gpu": dict(**gpu, load_kwargs=dict(pipeline_parallel_stages=int(os.environ.get("WORLD_SIZE", 1)))),
+        "ipex_fp16_gpu": dict(**gpu, load_kwargs=dict(plain=True)),
+        "pytorch_autocast_bf16": dict(device="cpu", load_kwargs=dict(plain=True)),
+        "deepspeed_optimize_model_gpu": dict(**gpu, load_kwargs=dict(tensor_parallel=True)),
+        "deepspeed_transformer_int4_cpu": dict(device="cpu", load_kwargs=dict(tensor_parallel=True)),
     }
     if test_api in table:
         kw = table[test_api]

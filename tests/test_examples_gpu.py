@@ -203,7 +203,7 @@ def test_all_in_one_benchmark_harness(ckpt, tmp_path):
     import csv
     import yaml
     apis = ["transformer_int4_gpu", "transformer_int4_fp16_gpu", "optimize_model_gpu", "bigdl_fp16_gpu", "lookup_gpu",
-            "speculative_gpu"]
+            "speculative_gpu", "ipex_fp16_gpu"]
     conf = dict(repo_id=[os.path.basename(str(ckpt))], local_model_hub=os.path.dirname(str(ckpt)), warm_up=1, num_trials=2,
                 num_beams=1, low_bit="sym_int4", batch_size=1, in_out_pairs=["32-8"], test_api=apis, cpu_embedding=False,
                 streaming=False, use_fp16_torch_dtype=True, quantize_kv_cache=False, task="continuation")
@@ -218,3 +218,19 @@ def test_all_in_one_benchmark_harness(ckpt, tmp_path):
     for f in files:
         rows = list(csv.DictReader(open(tmp_path / f)))
         assert len(rows) == 1 and float(rows[0]["1st token avg latency (ms)"]) > 0 and float(rows[0]["2+ avg latency (ms/token)"]) > 0
+
+
+def test_all_in_one_tensor_parallel_mode(ckpt, tmp_path):
+    """the reference's deepspeed_optimize_model_gpu mode: here this library's own sharder under torchrun"""
+    import yaml
+    conf = dict(repo_id=[os.path.basename(str(ckpt))], local_model_hub=os.path.dirname(str(ckpt)), warm_up=1, num_trials=1,
+                num_beams=1, low_bit="sym_int4", batch_size=1, in_out_pairs=["32-8"], test_api=["deepspeed_optimize_model_gpu"],
+                cpu_embedding=False, streaming=False, use_fp16_torch_dtype=True, quantize_kv_cache=False, task="continuation")
+    cfg = tmp_path / "config.yaml"
+    cfg.write_text(yaml.safe_dump(conf))
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1",
+                        "--nproc-per-node", "1", os.path.join(ROOT, "benchmark", "all_in_one", "run.py"), "-c", str(cfg), "-o",
+                        str(tmp_path)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, f"{r.stdout[-2000:]}\n{r.stderr[-3000:]}"
+    assert any(f.startswith("deepspeed_optimize_model_gpu-results") for f in os.listdir(tmp_path))
