@@ -10,7 +10,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 from transformers import LlamaConfig, LlamaForCausalLM
 
-WORLD = 2
+WORLD = int(os.environ.get("BIGDL_TEST_WORLD", "2"))      # rehearse more ranks with BIGDL_TEST_WORLD=4
 
 
 def _free_port():
@@ -22,7 +22,8 @@ def _free_port():
 def _tiny(layers=4, hidden=128, inter=256):
     torch.manual_seed(0)
     cfg = LlamaConfig(vocab_size=320, hidden_size=hidden, intermediate_size=inter, num_hidden_layers=layers,
-                      num_attention_heads=4, num_key_value_heads=2, max_position_embeddings=256,
+                      num_attention_heads=2 * max(2, WORLD), num_key_value_heads=max(2, WORLD),
+                      max_position_embeddings=256,
                       tie_word_embeddings=False)
     m = LlamaForCausalLM(cfg).eval()
     m.generation_config.eos_token_id = None
@@ -48,14 +49,14 @@ def _tp_worker(rank, port, low_bit, tmp):
     _boot(rank, port)
     from bigdl_amd.optimize import optimize_model
     from bigdl_amd.parallel.tensor_parallel import tensor_parallel
-    full = optimize_model(_tiny(2, 512, 1024), low_bit=low_bit)       # k-quant blocks need 256-wide column shards
+    full = optimize_model(_tiny(2, 256 * WORLD, 512 * WORLD), low_bit=low_bit)     # k-quant blocks need 256-wide column shards
     ids = torch.load(os.path.join(tmp, "ids.pt"))
     with torch.no_grad():
         ref = full(ids).logits
     sharded = tensor_parallel(copy.deepcopy(full))
     att = sharded.model.layers[0].self_attn
     assert att.qkv_proj.out_len == full.model.layers[0].self_attn.qkv_proj.out_len // WORLD
-    assert sharded.model.layers[0].mlp.down_proj.in_len == 1024 // WORLD
+    assert sharded.model.layers[0].mlp.down_proj.in_len == 512
     with torch.no_grad():
         out = sharded(ids).logits
         gen = sharded.generate(ids, max_new_tokens=6, do_sample=False)
@@ -80,7 +81,7 @@ def _pp_worker(rank, port, tmp):
     _boot(rank, port)
     from bigdl_amd.optimize import optimize_model
     from bigdl_amd.transformers.pipeline_parallel import pipeline_parallel
-    full = optimize_model(_tiny(4), low_bit="sym_int8")
+    full = optimize_model(_tiny(2 * WORLD), low_bit="sym_int8")
     ids = torch.load(os.path.join(tmp, "ids.pt"))
     ref = full.generate(ids, max_new_tokens=8, do_sample=False)
     long_ids = ids.repeat(1, 3)                                   # > 10 tokens: lm_head keeps the last position only
@@ -127,11 +128,12 @@ def _comm_worker(rank, port):
     _boot(rank, port)
     from bigdl_amd.parallel import all_reduce_coalesced_, new_groups
     g = new_groups(tp=2, pp=1)
-    assert g["coords"] == (0, 0, rank)
+    assert g["coords"] == (rank // 2, 0, rank % 2)          # data-parallel index, stage, tensor-parallel index
     ts = [torch.full((3, 5), float(rank + 1)), torch.full((7,), float(rank + 1)), torch.ones(4, dtype=torch.float64) * rank]
     all_reduce_coalesced_(ts, bucket_mb=1, average=True)
-    assert torch.allclose(ts[0], torch.full((3, 5), 1.5)) and torch.allclose(ts[1], torch.full((7,), 1.5))
-    assert torch.allclose(ts[2], torch.full((4,), 0.5, dtype=torch.float64))
+    mean = (WORLD + 1) / 2                                   # mean of rank + 1 over the world
+    assert torch.allclose(ts[0], torch.full((3, 5), mean)) and torch.allclose(ts[1], torch.full((7,), mean))
+    assert torch.allclose(ts[2], torch.full((4,), mean - 1, dtype=torch.float64))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -230,8 +232,8 @@ def _cp_worker(rank, port):
     torch.manual_seed(5)
     b, hkv, d, n = 1, 2, 8, 3
     total = 2 * WORLD * n
-    full_k = torch.randn(b, hkv, 16, d)
-    full_v = torch.randn(b, hkv, d, 16)
+    full_k = torch.randn(b, hkv, total + 4, d)
+    full_v = torch.randn(b, hkv, d, total + 4)
     for dtype in (torch.float32, torch.uint8):
         fk = full_k if dtype == torch.float32 else (full_k * 40).to(torch.uint8)
         fv = full_v if dtype == torch.float32 else (full_v * 40).to(torch.uint8)
