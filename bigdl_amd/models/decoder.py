@@ -369,10 +369,19 @@ class NativeDecoder:
         return self._tp_reduce(self._linear_dense(g, lw.down))
 
     @torch.no_grad()
-    def prefill(self, input_ids: torch.Tensor, last_only: bool = True, slot: Optional[int] = None):
+    def prefill(self, input_ids: torch.Tensor, last_only: bool = True, slot: Optional[int] = None,
+                with_decode: bool = False):
         """input_ids [B, S] (device).  Fills the cache from position past_len and returns logits
         ([B, 1, V] if last_only else [B, S, V]).  With ``slot`` (continuous batching) input_ids is one sequence
-        [1, S] that is appended to cache row ``slot`` only."""
+        [1, S] that is appended to cache row ``slot`` only.
+
+        ``with_decode`` (slot mode): the pass also carries one decode row per cache slot, the chained token of the
+        running sequences, so that the prompt's GEMMs and the decode step share one read of the weights (what the
+        reference's serving loop gets from vLLM's chunked prefill,
+        python/llm/src/ipex_llm/vllm/xpu/engine/engine.py:40-246).  Linears, norms and the MLP run over the
+        S + slots rows together; attention runs per kind (flash kernel for the prompt, split-KV decode kernel for the
+        slots).  Returns (prompt logits, decode logits [slots, V], next tokens [slots]) and advances every active
+        slot by one token exactly like ``decode(None, 1, chain=True)``."""
         from ..ops import hip
         cfg, cache = self.cfg, self.cache
         b, s = input_ids.shape
@@ -382,16 +391,33 @@ class NativeDecoder:
         else:
             past = cache.host_len
         assert past + s <= cache.capacity, "KV cache capacity exceeded"
+        nd, st = 0, None
+        if with_decode:
+            assert slot is not None and last_only and not cache.active_host[slot], \
+                "the mixed pass appends a new sequence to an idle slot"
+            assert max(cache.slot_len) + 1 <= cache.capacity, "KV cache capacity exceeded"
+            nd = cache.batch
+            st = self._get_graph(nd, 1, True)[1]         # the decode step's static buffers: tokens, workspace
         h = F.embedding(input_ids, self.embed).to(torch.float16)
         if cfg.embed_scale != 1.0:
             h = h * cfg.embed_scale
         h = h.reshape(b * s, cfg.hidden_size)
         pos = torch.arange(past, past + s, device=self.device)[None].expand(b, s)
+        if nd:
+            hd = F.embedding(st["tokens"].view(-1), self.embed).to(torch.float16)
+            h = torch.cat([h, hd * cfg.embed_scale if cfg.embed_scale != 1.0 else hd])
+            pos = torch.cat([pos.reshape(-1), cache.past_len.to(torch.int64)])
         h = self._embed_extras(h, pos.reshape(-1))
         hq, hkv, d = cfg.num_heads, cfg.num_kv_heads, cfg.head_dim
         for li, lw in enumerate(self.layers):
             x = self._norm(h, lw.input_norm, lw.input_norm_b)
-            qkv = self._linear_dense(x, lw.qkv).view(b, s, (hq + 2 * hkv) * d)
+            qkv = self._linear_dense(x, lw.qkv)
+            if nd:
+                # decode rows first: the idle slot's row appends a throw-away key at position 0 of the cache row
+                # that the prompt's keys are written to right after
+                attn_d = self._decode_attention(qkv[s:], li, lw, st, nd)
+                qkv = qkv[:s]
+            qkv = qkv.view(b, s, (hq + 2 * hkv) * d)
             q = qkv[..., : hq * d].view(b, s, hq, d).transpose(1, 2)
             k = qkv[..., hq * d: (hq + hkv) * d].view(b, s, hkv, d).transpose(1, 2)
             kc, vc = cache.k[li], cache.v[li]
@@ -410,6 +436,8 @@ class NativeDecoder:
             else:
                 kk, vt = self._read_cache(li, past + s, slot)
             attn = self._sdpa(q, kk, vt, past, lw.window).reshape(b * s, hq * d)
+            if nd:
+                attn = torch.cat([attn, attn_d])
             o = self._tp_reduce(self._linear_dense(attn, lw.o))
             if lw.post_attn_out_norm is not None:
                 o = self._norm(o, lw.post_attn_out_norm)
@@ -432,12 +460,39 @@ class NativeDecoder:
         else:
             cache.past_len.add_(s)
             cache.host_len += s
+        if nd:
+            x = self._norm(h[s - 1:], self.final_norm, self.final_norm_b)            # last prompt token + the decode rows
+            logits = self._finish_logits(self._linear_dense(x, self.lm_head).float())
+            st["logits"].copy_(logits[1:])
+            hip.argmax(st["logits"], out=st["tokens"].view(-1))                      # chained like the graph's step
+            cache.past_len.add_(cache.active)
+            cache.slot_len = [n + a for n, a in zip(cache.slot_len, cache.active_host)]
+            return logits[:1].view(1, 1, cfg.vocab_size), st["logits"], st["tokens"].view(-1)
         h = h.view(b, s, -1)
         if last_only:
             h = h[:, -1:, :]
         x = self._norm(h.reshape(-1, cfg.hidden_size), self.final_norm, self.final_norm_b)
         logits = self._linear_dense(x, self.lm_head).float().view(b, -1, cfg.vocab_size)
         return self._finish_logits(logits)
+
+    def _decode_attention(self, qkv, li, lw, st, batch):
+        """split-KV decode attention (+ RoPE and cache append) of one token per slot, outside the graph; qkv
+        [batch, q + 2 kv] rows of a larger pass.  Returns [batch, q_size]."""
+        from ..ops import hip
+        cfg, cache = self.cfg, self.cache
+        qkv = qkv.contiguous()
+        out = torch.empty(batch, cfg.q_size, dtype=torch.float16, device=self.device)
+        if not self.fused_rope:
+            hip.rope_append(qkv, cache.k[li], cache.v[li], cache.past_len, self.inv_freq, n_heads=cfg.num_heads,
+                            n_kv_heads=cfg.num_kv_heads, head_dim=cfg.head_dim, q_len=1, batch=batch,
+                            rot_dim=cfg.rot_dim or cfg.head_dim, interleaved=cfg.rope_interleaved,
+                            attn_scaling=self.rope_scaling_factor)
+        hip.attn_decode(qkv, cache.k[li], cache.v[li], cache.past_len, out, st["ws"], st["counters"],
+                        n_heads=cfg.num_heads, n_kv_heads=cfg.num_kv_heads, head_dim=cfg.head_dim, q_len=1,
+                        batch=batch, scale=self.attn_scale, splits=st["splits"], softcap=cfg.attn_softcap,
+                        window=lw.window, rope_table=self.rope_table if self.fused_rope and not self.no_rope else None,
+                        append=self.no_rope, alibi=self.alibi, interleaved=cfg.rope_interleaved, defer_combine=False)
+        return out
 
     @torch.no_grad()
     def prefill_context_parallel(self, input_ids: torch.Tensor, group=None):
@@ -830,6 +885,11 @@ class NativeDecoder:
         self.rest_cost_mean = sum(times[1:]) / max(1, len(times) - 1)
         self.peak_memory = torch.cuda.max_memory_reserved() / (1024 ** 3)
         return torch.cat(out, 1)
+
+    def dense_copy_bytes(self):
+        """HBM an fp16 copy of every fused linear takes (what ``Lin.cache_dense`` keeps resident for the prompt GEMMs)"""
+        lins = [self.lm_head] + [lin for lw in self.layers for lin in (lw.qkv, lw.o, lw.gate, lw.up, lw.down)]
+        return sum(2 * lin.n * lin.k for lin in lins if lin is not None and lin.fused)
 
     def weight_bytes(self):
         tot = self.embed.numel() * self.embed.element_size() + self.lm_head.nbytes

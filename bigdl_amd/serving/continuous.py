@@ -11,11 +11,14 @@ model), the same graph at 32 slots costs little more, so throughput scales with 
 
 ``ContinuousBatcher`` is the scheduler: ``submit`` queues a request, ``step`` admits waiting requests into free
 slots (at most ``max_prefill_per_step`` per step, the reference's ``max_prefilled_seqs``), runs one decode step over
-all slots and returns the new token of every running request.
+all slots and returns the new token of every running request.  When sequences are running while a prompt is
+admitted, both go through one pass (``NativeDecoder.prefill(with_decode=True)``): the decode rows are appended to the
+prompt's rows, so the step costs one read of the weights instead of two.
 """
 from __future__ import annotations
 
 import collections
+import os
 import time
 from dataclasses import dataclass, field
 from typing import Callable, Dict, List, Optional
@@ -48,7 +51,8 @@ class ContinuousBatcher:
     """Iteration-level scheduler over ``max_num_seqs`` cache slots of one ``NativeDecoder``."""
 
     def __init__(self, engine, max_num_seqs: int = 8, max_seq_len: int = 4096, kv_fp8: bool = False,
-                 max_prefill_per_step: int = 1, on_token: Optional[Callable[[SeqRequest, int], None]] = None):
+                 max_prefill_per_step: int = 1, on_token: Optional[Callable[[SeqRequest, int], None]] = None,
+                 piggyback: Optional[bool] = None, dense_prefill_cache: Optional[bool] = None):
         self.engine = engine
         self.max_num_seqs = max_num_seqs
         self.max_seq_len = max_seq_len
@@ -60,9 +64,20 @@ class ContinuousBatcher:
         cache = engine.ensure_cache(max_num_seqs, max_seq_len, fp8=kv_fp8)
         cache.enable_slots()
         self.cache = cache
+        # a serving loop runs prompt passes all the time: keep fp16 copies of the weights for their GEMMs when that
+        # fits in a quarter of the HBM left after the KV cache (decode keeps streaming the low-bit tiles)
+        if dense_prefill_cache is None and hasattr(engine, "dense_copy_bytes") and torch.cuda.is_available() \
+                and os.environ.get("BIGDL_PREFILL_DENSE_CACHE") != "0":
+            dense_prefill_cache = engine.dense_copy_bytes() <= torch.cuda.mem_get_info()[0] // 4
+        if dense_prefill_cache:
+            from ..models.decoder import Lin
+            Lin.cache_dense = True
         self._tokens = None      # the engine's static [B, 1] token buffer (input of the next decode step)
         self.steps = 0
         self.generated = 0
+        # decode rows ride on the prompt pass of a newly admitted request (BIGDL_SERVING_PIGGYBACK=0 turns it off)
+        self.piggyback = os.environ.get("BIGDL_SERVING_PIGGYBACK", "1") != "0" if piggyback is None else piggyback
+        self.mixed_steps = 0
 
     # ------------------------------------------------------------------ queue
     def submit(self, req: SeqRequest) -> SeqRequest:
@@ -109,36 +124,55 @@ class ContinuousBatcher:
             self.running.pop(req.slot, None)
             self.free_slots.append(req.slot)
 
+    def _admit(self, req: SeqRequest):
+        slot = self.free_slots.pop()
+        req.slot = slot
+        self.cache.set_active(slot, False)            # clears the slot's length counters
+        return slot, torch.tensor([req.input_ids], dtype=torch.int64, device=self.engine.device)
+
+    def _started(self, req: SeqRequest, logits_row, tokens, out):
+        tok = self._pick(req, logits_row)
+        tokens[req.slot, 0] = tok
+        self.cache.set_active(req.slot, True)
+        self.running[req.slot] = req
+        self._emit(req, tok, time.perf_counter(), out)
+
+    def _advance(self, logits, nxt, tokens, out, skip=-1):
+        host = nxt.tolist()                           # one device sync per iteration
+        now = time.perf_counter()
+        for slot, req in list(self.running.items()):
+            if slot == skip:
+                continue
+            tok = host[slot]
+            if req.do_sample:
+                tok = self._pick(req, logits[slot])
+                tokens[slot, 0] = tok
+            self._emit(req, tok, now, out)
+
     def step(self) -> Dict[str, int]:
         """Admit, decode once, return {request_id: new token}."""
         eng, out = self.engine, {}
         tokens = self._token_buffer()
-        # decode first: the sequences that are already running advance by one token
-        if self.running:
-            logits, nxt = eng.decode(None, 1, chain=True)
-            host = nxt.tolist()                       # one device sync per iteration
-            now = time.perf_counter()
-            for slot, req in list(self.running.items()):
-                tok = host[slot]
-                if req.do_sample:
-                    tok = self._pick(req, logits[slot])
-                    tokens[slot, 0] = tok
-                self._emit(req, tok, now, out)
-        # then admit: prefill writes the prompt into the slot's cache rows and yields the slot's first token
         admitted = 0
+        if self.running and self.waiting and self.free_slots and self.piggyback:
+            # one pass for both: the running sequences' next token rides on the new prompt's GEMMs
+            req = self.waiting.popleft()
+            slot, ids = self._admit(req)
+            first, logits, nxt = eng.prefill(ids, last_only=True, slot=slot, with_decode=True)
+            self._advance(logits, nxt, tokens, out)
+            self._started(req, first[0, -1], tokens, out)
+            admitted = 1
+            self.mixed_steps += 1
+        elif self.running:
+            # the sequences that are already running advance by one token
+            logits, nxt = eng.decode(None, 1, chain=True)
+            self._advance(logits, nxt, tokens, out)
+        # then admit: prefill writes the prompt into the slot's cache rows and yields the slot's first token
         while self.waiting and self.free_slots and admitted < self.max_prefill_per_step:
             req = self.waiting.popleft()
-            slot = self.free_slots.pop()
-            req.slot = slot
-            self.cache.set_active(slot, False)        # clears the slot's length counters
-            ids = torch.tensor([req.input_ids], dtype=torch.int64, device=eng.device)
-            logits = eng.prefill(ids, last_only=True, slot=slot)[0, -1]
-            tok = self._pick(req, logits)
-            tokens[slot, 0] = tok
-            self.cache.set_active(slot, True)
-            self.running[slot] = req
+            slot, ids = self._admit(req)
+            self._started(req, eng.prefill(ids, last_only=True, slot=slot)[0, -1], tokens, out)
             admitted += 1
-            self._emit(req, tok, time.perf_counter(), out)
         self.steps += 1
         return out
 

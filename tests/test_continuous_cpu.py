@@ -40,11 +40,17 @@ class _FakeEngine:
         lg[sum(hist) % self.vocab] = 1.0
         return lg
 
-    def prefill(self, ids, last_only=True, slot=None):
-        assert self.cache.slot_len[slot] == 0
+    mixed = 0
+
+    def prefill(self, ids, last_only=True, slot=None, with_decode=False):
+        assert self.cache.slot_len[slot] == 0 and not self.cache.active_host[slot]
         self.hist[slot] = ids[0].tolist()
         self.cache.slot_len[slot] += ids.shape[1]
-        return self._logits(self.hist[slot])[None, None]
+        first = self._logits(self.hist[slot])[None, None]
+        if with_decode:                               # the running slots advance in the same pass
+            self.mixed += 1
+            return (first,) + self.decode(None, 1, chain=True)
+        return first
 
     def decode(self, tokens, q_len=1, chain=False):
         lg = torch.zeros(self.cache.batch, self.vocab)
@@ -72,6 +78,19 @@ def test_more_requests_than_slots_all_finish_with_their_own_history():
     outs = generate_batch(_FakeEngine(), prompts, max_new_tokens=6, max_num_seqs=3)
     for p, o in zip(prompts, outs):
         assert o == _expected(p, 6)
+
+
+def test_piggyback_and_separate_passes_give_the_same_tokens():
+    prompts = [[i + 1, 2 * i + 3, 5] + [7] * i for i in range(9)]
+    outs = {}
+    for on in (True, False):
+        eng = _FakeEngine()
+        cb = ContinuousBatcher(eng, max_num_seqs=3, max_seq_len=64, piggyback=on)
+        reqs = [cb.submit(SeqRequest(str(i), list(p), max_new_tokens=3 + i % 4)) for i, p in enumerate(prompts)]
+        cb.run_until_done()
+        outs[on] = [r.output_ids for r in reqs]
+        assert (eng.mixed > 0) == on and cb.mixed_steps == eng.mixed
+    assert outs[True] == outs[False] == [_expected(p, 3 + i % 4) for i, p in enumerate(prompts)]
 
 
 def test_eos_frees_the_slot_and_callbacks_fire():

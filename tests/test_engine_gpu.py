@@ -138,6 +138,47 @@ def test_continuous_batching_matches_per_request_generation():
 
 
 @pytest.mark.parametrize("fp8", [False, True])
+def test_mixed_prompt_and_decode_pass_matches_separate_passes(fp8):
+    """prefill(with_decode=True) = one decode step of the running slots + the prompt pass of a new one: same logits,
+    same cache contents and counters as the two separate calls from the same state."""
+    from bigdl_amd.models import decoder as D
+    cfg = D.DecoderConfig(vocab_size=512, hidden_size=256, intermediate_size=512, num_layers=3, num_heads=4, num_kv_heads=2,
+                          head_dim=64, max_position=1024)
+    eng = D.build_random_decoder(cfg, device="cuda", seed=3)
+    g = torch.Generator().manual_seed(0)
+    p0, p1, new = (torch.randint(3, 512, (1, n), generator=g).cuda() for n in (40, 19, 300))
+    res = {}
+    for mixed in (False, True):
+        cache = eng.ensure_cache(4, 512, fp8=fp8)
+        cache.reset()
+        cache.enable_slots()
+        tokens = eng._get_graph(4, 1, True)[1]["tokens"]
+        for slot, p in ((0, p0), (2, p1)):
+            tokens[slot, 0] = eng.prefill(p, slot=slot)[0, -1].argmax()
+            cache.set_active(slot, True)
+        eng.decode(None, 1, chain=True)                       # one ordinary step first
+        if mixed:
+            first, lg, nxt = eng.prefill(new, slot=1, with_decode=True)
+        else:
+            lg, nxt = eng.decode(None, 1, chain=True)
+            lg, nxt = lg.clone(), nxt.clone()
+            first = eng.prefill(new, slot=1)
+        res[mixed] = (first.clone(), lg[[0, 2]].clone(), nxt[[0, 2]].clone(), cache.past_len.clone(), list(cache.slot_len),
+                      cache.k[1][[0, 2], :, :45].float().clone(), cache.k[1][1, :, :300].float().clone())
+    a, b = res[False], res[True]
+    tol = 0.06 if fp8 else 1e-2
+    for i in (0, 1):
+        rel = ((a[i] - b[i]).abs().mean() / a[i].abs().mean()).item()
+        assert rel < tol, (i, rel)
+    assert torch.equal(a[3], b[3]) and a[4] == b[4] == [42, 300, 21, 0]
+    for i in (5, 6):
+        if fp8:                                               # e5m2 codes: a rounding flip here and there
+            assert (a[i] != b[i]).float().mean().item() < 0.03
+        else:
+            torch.testing.assert_close(a[i], b[i], rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("fp8", [False, True])
 def test_context_parallel_prefill_matches_plain_prefill(fp8):
     """One rank, two zigzag chunks: chunked RoPE positions, cache writes at chunk offsets and per-chunk causal
     attention reproduce the plain prompt pass; decoding continues from the cache it leaves."""
