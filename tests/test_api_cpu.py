@@ -289,3 +289,28 @@ def test_other_families_convert_and_run():
         assert _rel(got, ref) < 0.05, m_cls.__name__
         out = q.generate(ids, max_new_tokens=4, do_sample=False)
         assert out.shape == (1, 11)
+
+
+def test_npu_model_import_path_takes_the_npu_keywords(tiny_llama, tmp_path):
+    """A script written against ipex_llm.transformers.npu_model runs unchanged: NPU keywords are accepted, *_rtn
+    qtypes land on the block formats, save_directory receives a low-bit checkpoint that load_low_bit reads back."""
+    from ipex_llm.transformers.npu_model import AutoModelForCausalLM
+    from ipex_llm.transformers.low_bit_linear import LowBitLinear
+    d, ref_model = tiny_llama
+    ids = torch.randint(0, 320, (1, 9))
+    out = str(tmp_path / "npu_out")
+    m = AutoModelForCausalLM.from_pretrained(d, load_in_low_bit="sym_int4_rtn", optimize_model=True, pipeline=True,
+                                             max_context_len=512, max_prompt_len=128, quantization_group_size=64,
+                                             transpose_value_cache=True, mixed_precision=False, device="cpu",
+                                             save_directory=out, torch_dtype=torch.float16, attn_implementation="eager")
+    assert m.max_context_len == 511 and m.max_prompt_len == 128
+    assert isinstance(m.model.layers[0].mlp.up_proj, LowBitLinear) and m.config.bigdl_transformers_low_bit == "sym_int4"
+    with torch.no_grad():
+        want = m(ids).logits.float()
+        assert _rel(want, ref_model(ids).logits) < 0.3
+    back = AutoModelForCausalLM.load_low_bit(out, max_context_len=512, max_prompt_len=128, device="cpu")
+    with torch.no_grad():
+        torch.testing.assert_close(back(ids).logits.float(), want, rtol=1e-3, atol=1e-3)
+    conv = AutoModelForCausalLM.optimize_npu_model(model=LlamaForCausalLM.from_pretrained(d), qtype="sym_int8_rtn",
+                                                   max_context_len=256, device="cpu")
+    assert conv.model.layers[0].mlp.up_proj.qtype == Q.SYM_INT8
