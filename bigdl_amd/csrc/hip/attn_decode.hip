@@ -14,6 +14,12 @@
 // per-lane 16-byte (8-byte for fp8) loads and the softmax probabilities never leave registers:
 //   S^T[key][row] = K . Q^T      (A = K rows, B = Q^T)
 //   O^T[d][row]  += V^T . P^T    (A = V^T rows, B = P^T taken straight from the S^T accumulators)
+// int4 caches (I4): K [B, Hkv, Lmax, D/2] bytes with one fp16 scale per key and 32 channels (ks [B, Hkv, Lmax, D/32]):
+// the 8 channels 8i .. 8i+7 of a key form one 32-bit word, channel j in nibble (j >> 1) + 4 (j & 1), value
+// (nibble - 8) * scale.  V^T [B, Hkv, D/2, Lmax] bytes: row 16m + r holds channel 32m + r (low nibble) and 32m + 16 + r
+// (high nibble) of every key, scales vs [B, Hkv, D/32, Lmax] per key and 32 channels.  Appending a token writes whole
+// bytes in both caches; the V scale is applied to the probabilities (once per 32-channel group), the K scale to the
+// dequantized fragment.
 // In both products the query row is the MFMA column (= lane & 15), so the online-softmax
 // statistics and the O rescale are lane-local.  A 32-key step feeds the two 16-key S^T tiles
 // with keys {8g+q} and {8g+4+q} so that lane group g ends up owning 8 consecutive keys, which
@@ -35,6 +41,8 @@ struct AttnArgs {
   const float* rope;     // fused RoPE: table [max_pos][rot/2][2] (cos, sin) or null (q/k already rotated+appended)
   const int* position_ids;  // optional [B*q_total] rope positions (default: cache position)
   const float* alibi;       // optional [Hq] ALiBi slopes: score += slope[head] * (key - query position)
+  _Float16* ks;             // int4 caches: K scales [B, Hkv, Lmax, D/32]
+  _Float16* vs;             // int4 caches: V scales [B, Hkv, D/32, Lmax]
   int mask_ld;
   float scale;           // softmax scale
   float softcap;         // gemma2 logit soft-capping (0 = off)
@@ -59,13 +67,31 @@ __device__ __forceinline__ half8 load_kv8(const void* base, int64_t elem_off) {
   }
 }
 
+// 8 int4 values of one cache word -> fp16 (nibble k -> element 2k, nibble k + 4 -> element 2k + 1), minus the zero
+// point 8, times `sc`.  0x6400 | n is the fp16 number 1024 + n.
+__device__ __forceinline__ half8 dq_i4(uint32_t w, _Float16 sc) {
+  H8 r;
+  const half2v off = {(_Float16)1032.0f, (_Float16)1032.0f}, s2 = {sc, sc};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t t = ((w >> (4 * k)) & 0x000F000Fu) | 0x64006400u;
+    r.h2[k] = (__builtin_bit_cast(half2v, t) - off) * s2;
+  }
+  return r.v;
+}
+
+// symmetric int4 code of x for the scale 1 / inv
+__device__ __forceinline__ uint32_t q_i4(float x, float inv) {
+  return (uint32_t)(int)fminf(fmaxf(rintf(x * inv) + 8.0f, 0.0f), 15.0f);
+}
+
 // D = head dim (multiple of 32), RT = number of 16-row tiles, KW = keys per wavefront per iteration.
 // KW = 64 (e5m2 caches, D % 128 == 0): every lane loads 16 bytes of a key row / of a V^T channel row instead of 8, i.e.
 // half as many load instructions and 64-byte instead of 32-byte contiguous pieces per 4 lanes.  With 8-byte pieces the
 // e5m2 path is bound by the number of memory instructions, not by bytes (batch 64, 1024 keys: 184 us per layer where
 // the fp16 cache needs 258 us for twice the bytes).  The MFMA k index <-> head channel assignment is free as long as
 // Q and K agree, so lane group g takes channels [16 (g + 4 c2), +16) of a row for the k-steps 2 c2 and 2 c2 + 1.
-template <int D, bool FP8, int RT, int KW>
+template <int D, bool FP8, int RT, int KW, bool I4>
 __global__ __launch_bounds__(ATT_NW * 64) void attn_decode_kernel(AttnArgs a) {
   constexpr int DC = D / 32;   // QK k-steps
   constexpr int DT = D / 16;   // O^T d-tiles
@@ -75,8 +101,12 @@ __global__ __launch_bounds__(ATT_NW * 64) void attn_decode_kernel(AttnArgs a) {
   constexpr int KL = KW / 4;           // consecutive keys per lane
   constexpr bool WIDE = KW == 64;
   static_assert(!WIDE || (FP8 && D % 128 == 0), "16-byte fragments: e5m2 cache, rotate-half partner in k-step c + DC/2");
-  // first head channel of this lane's 8 values in k-step c
-  auto chan = [](int c, int g) { return WIDE ? 64 * (c >> 1) + 16 * g + 8 * (c & 1) : 32 * c + 8 * g; };
+  static_assert(!I4 || (!FP8 && KW == 32), "int4 caches: 32 keys per wavefront");
+  // first head channel of this lane's 8 values in k-step c.  int4: lane group g owns the D/4 contiguous channels
+  // (D/4) g .. of a key, one load of D/8 bytes
+  auto chan = [](int c, int g) {
+    return I4 ? (D / 4) * g + 8 * c : WIDE ? 64 * (c >> 1) + 16 * g + 8 * (c & 1) : 32 * c + 8 * g;
+  };
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int rr = lane & 15, g = lane >> 4;
@@ -101,8 +131,10 @@ __global__ __launch_bounds__(ATT_NW * 64) void attn_decode_kernel(AttnArgs a) {
   const int blk0 = split * per, blk1 = min(nblk, blk0 + per);
 
   const int64_t kbase = ((int64_t)b * a.Hkv + hkv) * (int64_t)a.Lmax * D;
-  char* kc = (char*)a.kc + (FP8 ? kbase : kbase * 2);
-  char* vc = (char*)a.vc + (FP8 ? kbase : kbase * 2);
+  char* kc = (char*)a.kc + (I4 ? kbase / 2 : FP8 ? kbase : kbase * 2);
+  char* vc = (char*)a.vc + (I4 ? kbase / 2 : FP8 ? kbase : kbase * 2);
+  _Float16* ks = I4 ? a.ks + kbase / 32 : nullptr;
+  _Float16* vs = I4 ? a.vs + kbase / 32 : nullptr;
   const int half_rot = a.rot >> 1;
 
   // ---- fused RoPE(k) + KV append for the new tokens that fall into this workgroup's key range ----
@@ -116,6 +148,7 @@ __global__ __launch_bounds__(ATT_NW * 64) void attn_decode_kernel(AttnArgs a) {
         const int pos = a.position_ids ? a.position_ids[tokidx] : p;
         const _Float16* krow = a.qkv + (int64_t)tokidx * a.ld + (int64_t)(a.Hq + hkv) * D;
         const _Float16* vrow = krow + (int64_t)a.Hkv * D;
+        _Float16* stage = (_Float16*)s_o + wave * D;     // int4: the rotated key, quantized below
         for (int i = lane; i < D / 2; i += 64) {
           int i0, i1;
           const bool rot = i < half_rot;
@@ -133,13 +166,58 @@ __global__ __launch_bounds__(ATT_NW * 64) void attn_decode_kernel(AttnArgs a) {
             x0 = y0;
             x1 = y1;
           }
-          if constexpr (FP8) {
+          if constexpr (I4) {
+            stage[i0] = (_Float16)x0;
+            stage[i1] = (_Float16)x1;
+          } else if constexpr (FP8) {
             ((uint8_t*)kc)[(int64_t)p * D + i0] = f16_to_e5m2((_Float16)x0);
             ((uint8_t*)kc)[(int64_t)p * D + i1] = f16_to_e5m2((_Float16)x1);
           } else {
             ((_Float16*)kc)[(int64_t)p * D + i0] = (_Float16)x0;
             ((_Float16*)kc)[(int64_t)p * D + i1] = (_Float16)x1;
           }
+        }
+        if constexpr (I4) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+          __builtin_amdgcn_wave_barrier();
+          // K: lane l < D/8 packs channels 8l .. 8l+7; the four lanes of a 32-channel group share the scale
+          {
+            const bool on = lane < D / 8;
+            half8 kv8 = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (on) kv8 = *(const half8*)(stage + 8 * lane);
+            float am = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) am = fmaxf(am, fabsf((float)kv8[j]));
+            am = fmaxf(am, __shfl_xor(am, 1));
+            am = fmaxf(am, __shfl_xor(am, 2));
+            const _Float16 sc = (_Float16)(am * (1.0f / 7.0f));
+            const float inv = (float)sc > 0.0f ? 1.0f / (float)sc : 0.0f;
+            uint32_t w = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w |= q_i4((float)kv8[j], inv) << (4 * ((j >> 1) + 4 * (j & 1)));
+            if (on) {
+              *(uint32_t*)(kc + (int64_t)p * (D / 2) + 4 * lane) = w;
+              if ((lane & 3) == 0) ks[(int64_t)p * (D / 32) + (lane >> 2)] = sc;
+            }
+          }
+          // V: lane r < D/2 writes the byte of V^T row r = 16m + rr: channels 32m + rr and 32m + 16 + rr
+#pragma unroll
+          for (int r0 = 0; r0 < D / 2; r0 += 64) {
+            const int r = r0 + lane;
+            const bool on = r < D / 2;
+            const int m = r >> 4, c0 = 32 * m + (r & 15);
+            const float lo = on ? (float)vrow[c0] : 0.0f, hi = on ? (float)vrow[c0 + 16] : 0.0f;
+            float am = fmaxf(fabsf(lo), fabsf(hi));
+#pragma unroll
+            for (int x = 1; x < 16; x <<= 1) am = fmaxf(am, __shfl_xor(am, x));
+            const _Float16 sc = (_Float16)(am * (1.0f / 7.0f));
+            const float inv = (float)sc > 0.0f ? 1.0f / (float)sc : 0.0f;
+            if (on) {
+              ((uint8_t*)vc)[(int64_t)r * a.Lmax + p] = (uint8_t)(q_i4(lo, inv) | (q_i4(hi, inv) << 4));
+              if ((r & 15) == 0) vs[(int64_t)m * a.Lmax + p] = sc;
+            }
+          }
+          continue;
         }
         for (int d = lane; d < D; d += 64) {
           if constexpr (FP8) ((uint8_t*)vc)[(int64_t)d * a.Lmax + p] = f16_to_e5m2(vrow[d]);
@@ -192,6 +270,9 @@ __global__ __launch_bounds__(ATT_NW * 64) void attn_decode_kernel(AttnArgs a) {
             }
           }
         }
+      } else if constexpr (I4) {
+        // rotate-half pairs (d, d + D/2) with the int4 channel order: the partner of lane group g is group g ^ 2
+        // (lane ^ 32), same k-step.  Invalid rows take part in the shuffles below with zeros.
       } else {
         // rotate-half pairs (d, d + D/2): the host only enables the fused path for full rotary
         // (rot == D), so the partner lives in chunk c + DC/2 of the same lane
@@ -204,6 +285,23 @@ __global__ __launch_bounds__(ATT_NW * 64) void attn_decode_kernel(AttnArgs a) {
             const float x0 = qv[c][j], x1 = qv[c + DC / 2][j];
             qv[c][j] = x0 * cs.x - x1 * cs.y;
             qv[c + DC / 2][j] = x1 * cs.x + x0 * cs.y;
+          }
+        }
+      }
+    }
+    if constexpr (I4) {
+      if (a.rope != nullptr && !a.interleaved) {
+        const int pos = min(a.position_ids ? a.position_ids[valid ? tokidx : 0] : past + tok, a.rope_max_pos - 1);
+        const float* tab = a.rope + (int64_t)max(pos, 0) * half_rot * 2;
+        const float sgn = g < 2 ? -1.0f : 1.0f;
+#pragma unroll
+        for (int c = 0; c < DC; ++c) {
+          const int d0 = chan(c, g) & (D / 2 - 1);       // index of the pair in the table
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float other = __shfl_xor(qv[c][j], 32);
+            const float2 cs = *(const float2*)(tab + (d0 + j) * 2);
+            qv[c][j] = qv[c][j] * cs.x + sgn * other * cs.y;
           }
         }
       }
@@ -236,7 +334,31 @@ __global__ __launch_bounds__(ATT_NW * 64) void attn_decode_kernel(AttnArgs a) {
     // keys kb + KL*g .. of every query row
     const int key0 = kb + KL * (rr >> 2) + (rr & 3);
     half8 kf[NU][DC];
-    if constexpr (WIDE) {
+    if constexpr (I4) {
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const int64_t key = key0 + 4 * u;
+        uint32_t w[DC];
+        const uint8_t* src = (const uint8_t*)kc + key * (D / 2) + (D / 8) * g;
+        if constexpr (DC == 2) {
+          const uint2v t = *(const uint2v*)src;
+          w[0] = t.x; w[1] = t.y;
+        } else {
+#pragma unroll
+          for (int c4 = 0; c4 < DC / 4; ++c4) {
+            const uint4v t = *(const uint4v*)(src + 16 * c4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[4 * c4 + e] = t[e];
+          }
+        }
+        constexpr int SPL = D >= 128 ? D / 128 : 1;       // scales per lane (32 channels each)
+        _Float16 sc[SPL];
+#pragma unroll
+        for (int e = 0; e < SPL; ++e) sc[e] = ks[key * (D / 32) + ((D / 4) * g) / 32 + e];
+#pragma unroll
+        for (int c = 0; c < DC; ++c) kf[u][c] = dq_i4(w[c], sc[SPL > 1 ? c / 4 : 0]);
+      }
+    } else if constexpr (WIDE) {
 #pragma unroll
       for (int u = 0; u < NU; ++u)
 #pragma unroll
@@ -253,7 +375,29 @@ __global__ __launch_bounds__(ATT_NW * 64) void attn_decode_kernel(AttnArgs a) {
     }
     // V^T fragments: lane (d_local, g) holds keys kb + KL*g .. of channel 16*dt + d_local (KL/8 k-steps)
     half8 vf[DT][KL / 8];
-    if constexpr (WIDE) {
+    half8 vsc[I4 ? DT / 2 : 1];     // int4: V scales of this lane's 8 keys, per 32-channel group
+    if constexpr (I4) {
+      const _Float16 one = (_Float16)1.0f;
+      const half2v off = {(_Float16)1032.0f, (_Float16)1032.0f};
+#pragma unroll
+      for (int m = 0; m < DT / 2; ++m) {
+        const uint2v t = *(const uint2v*)((const uint8_t*)vc + (int64_t)(16 * m + rr) * a.Lmax + kb + 8 * g);
+        vsc[m] = *(const half8*)(vs + (int64_t)m * a.Lmax + kb + 8 * g);
+        H8 lo, hi;
+        // byte q of the pair of words is key q: pairs come out as keys (0,2) (1,3) (4,6) (5,7)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const uint32_t w = e ? t.y : t.x;
+          lo.h2[2 * e] = __builtin_bit_cast(half2v, (w & 0x000F000Fu) | 0x64006400u) - off;
+          hi.h2[2 * e] = __builtin_bit_cast(half2v, ((w >> 4) & 0x000F000Fu) | 0x64006400u) - off;
+          lo.h2[2 * e + 1] = __builtin_bit_cast(half2v, ((w >> 8) & 0x000F000Fu) | 0x64006400u) - off;
+          hi.h2[2 * e + 1] = __builtin_bit_cast(half2v, ((w >> 12) & 0x000F000Fu) | 0x64006400u) - off;
+        }
+        vf[2 * m][0] = lo.v;
+        vf[2 * m + 1][0] = hi.v;
+      }
+      (void)one;
+    } else if constexpr (WIDE) {
 #pragma unroll
       for (int d = 0; d < DT; ++d) {
         const uint4v w = *(const uint4v*)((const uint8_t*)vc + (int64_t)(16 * d + rr) * a.Lmax + kb + 16 * g);
@@ -322,6 +466,26 @@ __global__ __launch_bounds__(ATT_NW * 64) void attn_decode_kernel(AttnArgs a) {
       if (__any(alpha != 1.0f)) {
 #pragma unroll
         for (int d = 0; d < DT; ++d) o[t][d] *= alpha;
+      }
+      if constexpr (I4) {
+        // probabilities in the key order of the V^T fragments, times the V scale of each 32-channel group
+        const half8 p8 = pf[0].v;
+        H8 pp;
+        pp.h2[0] = half2v{p8[0], p8[2]};
+        pp.h2[1] = half2v{p8[1], p8[3]};
+        pp.h2[2] = half2v{p8[4], p8[6]};
+        pp.h2[3] = half2v{p8[5], p8[7]};
+#pragma unroll
+        for (int m = 0; m < DT / 2; ++m) {
+          H8 pm;
+          pm.h2[0] = pp.h2[0] * half2v{vsc[m][0], vsc[m][2]};
+          pm.h2[1] = pp.h2[1] * half2v{vsc[m][1], vsc[m][3]};
+          pm.h2[2] = pp.h2[2] * half2v{vsc[m][4], vsc[m][6]};
+          pm.h2[3] = pp.h2[3] * half2v{vsc[m][5], vsc[m][7]};
+          o[t][2 * m] = mfma16(vf[2 * m][0], pm.v, o[t][2 * m]);
+          o[t][2 * m + 1] = mfma16(vf[2 * m + 1][0], pm.v, o[t][2 * m + 1]);
+        }
+        continue;
       }
 #pragma unroll
       for (int h = 0; h < KL / 8; ++h)
@@ -418,26 +582,31 @@ __global__ __launch_bounds__(ATT_NW * 64) void attn_decode_kernel(AttnArgs a) {
   }
 }
 
-template <int D, bool FP8, int RT, int KW>
+template <int D, bool FP8, int RT, int KW, bool I4 = false>
 static int launch_one(const AttnArgs& a, size_t smem, hipStream_t st) {
   const dim3 grid(a.splits, a.Hkv * a.nchunk, a.B), block(ATT_NW * 64);
   // more than 64 KiB of dynamic LDS has to be requested explicitly (once per kernel)
   static bool attr = false;
   if (!attr && smem > 65536) {
-    if (hipFuncSetAttribute((const void*)attn_decode_kernel<D, FP8, RT, KW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void*)attn_decode_kernel<D, FP8, RT, KW, I4>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess)
       return -5;
     attr = true;
   }
-  hipLaunchKernelGGL((attn_decode_kernel<D, FP8, RT, KW>), grid, block, smem, st, a);
+  hipLaunchKernelGGL((attn_decode_kernel<D, FP8, RT, KW, I4>), grid, block, smem, st, a);
   return HIP_CHECK_LAUNCH();
 }
 
-template <int D, bool FP8>
+template <int D, bool FP8, bool I4 = false>
 static int launch_rt(const AttnArgs& a, hipStream_t st) {
   const int rows = a.gchunk * a.q_cnt;
   const int rt = (rows + 15) / 16;
   const size_t smem = (size_t)(ATT_NW * rt * 16 * 2 + ATT_NW * rows * D) * 4 + 16;
+  if constexpr (I4) {
+    if (rt == 1) return launch_one<D, false, 1, 32, true>(a, smem, st);
+    if (rt == 2) return launch_one<D, false, 2, 32, true>(a, smem, st);
+    return -4;
+  }
   if (rt == 1) {
     // 64 keys per wavefront (16-byte fragments) once every workgroup has several iterations of work anyway: one KV
     // split (enough (batch, head) pairs to fill the GPU) or a long cache.  Latency-bound launches with few keys per
@@ -537,7 +706,7 @@ extern "C" int bigdl_attn_decode(void* qkv, void* kc, void* vc, void* out, float
                                  const float* rope, const int* position_ids, int rope_max_pos, int rot, int interleaved, float scale,
                                  float softcap, int B, int Hq, int Hkv, int q_total, int q_off, int q_cnt, int ld,
                                  int Lmax, int D, int splits, int window, int fp8, int append, int defer_combine,
-                                 hipStream_t stream) {
+                                 void* k_scale, void* v_scale, hipStream_t stream) {
   if (B <= 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv || q_cnt <= 0 || q_off < 0 || q_off + q_cnt > q_total || splits <= 0 ||
       (Lmax & 255) || (ld & 7)) return -1;
   if (((uintptr_t)qkv | (uintptr_t)kc | (uintptr_t)vc | (uintptr_t)ws | (uintptr_t)out) & 15) return -1;
@@ -557,6 +726,17 @@ extern "C" int bigdl_attn_decode(void* qkv, void* kc, void* vc, void* out, float
   a.B = B; a.Hq = Hq; a.Hkv = Hkv; a.ld = ld; a.Lmax = Lmax; a.splits = splits; a.window = window;
   a.q_total = q_total; a.q_off = q_off; a.q_cnt = q_cnt; a.defer_combine = defer_combine;
   a.nchunk = nchunk; a.gchunk = gchunk;
+  a.ks = (_Float16*)k_scale; a.vs = (_Float16*)v_scale;
+  if (k_scale != nullptr || v_scale != nullptr) {
+    // int4 caches: the kernel appends itself (quantization needs the whole rotated key), full rotary only
+    if (k_scale == nullptr || v_scale == nullptr || fp8 || a.rot < 0 || (((uintptr_t)k_scale | (uintptr_t)v_scale) & 15)) return -1;
+    switch (D) {
+      case 64: return launch_rt<64, false, true>(a, stream);
+      case 128: return launch_rt<128, false, true>(a, stream);
+      case 256: return launch_rt<256, false, true>(a, stream);
+      default: return -2;
+    }
+  }
 #define DISPATCH_D(DD)                                                   \
   case DD: return fp8 ? launch_rt<DD, true>(a, stream) : launch_rt<DD, false>(a, stream);
   switch (D) {

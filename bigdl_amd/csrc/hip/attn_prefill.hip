@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void prefill_rope_append_kernel(PrefillRopeArg
       _Float16* row = base + (int64_t)t * a.ld;
       const int64_t kdst = (((int64_t)b * a.Hkv + hk) * a.Lmax + a.past + t) * D;
       auto put_k = [&](int d, half8 v) {
-        if (!is_k) return;
+        if (!is_k || a.kc == nullptr) return;
         if (a.fp8) {
           uint2v pk;
           uint32_t w[2] = {0, 0};
@@ -360,6 +360,12 @@ __global__ __launch_bounds__(256) void prefill_rope_append_kernel(PrefillRopeArg
     const int64_t row = ((int64_t)b * a.Hkv + hv) * D + d;
     const int key = a.past + t0 + 8 * tc;
     const bool full = 8 * tc + 8 <= ntok;
+    if (a.vt_scratch) {
+      _Float16* sd = a.vt_scratch + row * a.vt_ld + t0 + 8 * tc;
+      if (full && (((uintptr_t)sd) & 15) == 0) *(half8*)sd = v;
+      else for (int e = 0; e < 8 && 8 * tc + e < ntok; ++e) sd[e] = v[e];
+    }
+    if (a.vc == nullptr) continue;
     if (a.fp8) {
       uint8_t* dst = (uint8_t*)a.vc + row * a.Lmax + key;
       if (full && (((uintptr_t)dst) & 7) == 0) {
@@ -371,11 +377,6 @@ __global__ __launch_bounds__(256) void prefill_rope_append_kernel(PrefillRopeArg
       } else {
         for (int e = 0; e < 8 && 8 * tc + e < ntok; ++e) dst[e] = f16_to_e5m2(v[e]);
       }
-      if (a.vt_scratch) {
-        _Float16* sd = a.vt_scratch + row * a.vt_ld + t0 + 8 * tc;
-        if (full && (((uintptr_t)sd) & 15) == 0) *(half8*)sd = v;
-        else for (int e = 0; e < 8 && 8 * tc + e < ntok; ++e) sd[e] = v[e];
-      }
     } else {
       _Float16* dst = (_Float16*)a.vc + row * a.Lmax + key;
       if (full && (((uintptr_t)dst) & 15) == 0) *(half8*)dst = v;
@@ -384,9 +385,83 @@ __global__ __launch_bounds__(256) void prefill_rope_append_kernel(PrefillRopeArg
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Prompt keys / values -> int4 caches (format: attn_decode.hip).  One thread per (token, kv head, 32-channel group):
+// consecutive threads take consecutive tokens, so the byte stores into the V^T rows are contiguous across a wavefront.
+// ---------------------------------------------------------------------------------------------
+struct KvInt4Args {
+  const _Float16* qkv; uint8_t* kc; uint8_t* vc; _Float16* ks; _Float16* vs;
+  int B, Hq, Hkv, S, D, past, Lmax;
+  int64_t ld;
+};
+
+__device__ __forceinline__ uint32_t pf_q_i4(float x, float inv) {
+  return (uint32_t)(int)fminf(fmaxf(rintf(x * inv) + 8.0f, 0.0f), 15.0f);
+}
+
+__global__ __launch_bounds__(256) void kv_int4_append_kernel(KvInt4Args a) {
+  const int NG = a.D / 32;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int t = (int)(idx % a.S);
+  const int m = (int)((idx / a.S) % NG);
+  const int hk = blockIdx.y, b = blockIdx.z;
+  if (idx >= (int64_t)a.S * NG) return;
+  const _Float16* krow = a.qkv + ((int64_t)b * a.S + t) * a.ld + (int64_t)(a.Hq + hk) * a.D + 32 * m;
+  const _Float16* vrow = krow + (int64_t)a.Hkv * a.D;
+  const int64_t bh = (int64_t)b * a.Hkv + hk;
+  const int p = a.past + t;
+  half8 x[4];
+  float am = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    x[i] = *(const half8*)(krow + 8 * i);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) am = fmaxf(am, fabsf((float)x[i][j]));
+  }
+  _Float16 sc = (_Float16)(am * (1.0f / 7.0f));
+  float inv = (float)sc > 0.0f ? 1.0f / (float)sc : 0.0f;
+  uint4v kw;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    uint32_t w = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w |= pf_q_i4((float)x[i][j], inv) << (4 * ((j >> 1) + 4 * (j & 1)));
+    kw[i] = w;
+  }
+  *(uint4v*)(a.kc + (bh * a.Lmax + p) * (a.D / 2) + 16 * m) = kw;
+  a.ks[(bh * a.Lmax + p) * NG + m] = sc;
+  am = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    x[i] = *(const half8*)(vrow + 8 * i);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) am = fmaxf(am, fabsf((float)x[i][j]));
+  }
+  sc = (_Float16)(am * (1.0f / 7.0f));
+  inv = (float)sc > 0.0f ? 1.0f / (float)sc : 0.0f;
+  uint8_t* vdst = a.vc + (bh * (a.D / 2) + 16 * m) * a.Lmax + p;
+#pragma unroll
+  for (int r = 0; r < 16; ++r)      // channels 32m + r (low nibble) and 32m + 16 + r (high nibble)
+    vdst[(int64_t)r * a.Lmax] = (uint8_t)(pf_q_i4((float)x[r >> 3][r & 7], inv) | (pf_q_i4((float)x[2 + (r >> 3)][r & 7], inv) << 4));
+  a.vs[(bh * NG + m) * a.Lmax + p] = sc;
+}
+
 }  // namespace bigdl
 
 using namespace bigdl;
+
+extern "C" int bigdl_kv_int4_append(const void* qkv, void* kc, void* vc, void* ks, void* vs, int B, int Hq, int Hkv, int S,
+                                    int D, int past, int Lmax, int64_t ld, hipStream_t st) {
+  if (B <= 0 || S <= 0 || Hkv <= 0 || (D != 64 && D != 128 && D != 256) || past < 0 || past + S > Lmax || (ld & 7)) return -1;
+  if (((uintptr_t)qkv | (uintptr_t)kc | (uintptr_t)vc | (uintptr_t)ks | (uintptr_t)vs) & 15) return -1;
+  if (kc == nullptr || vc == nullptr || ks == nullptr || vs == nullptr || B > 65535 || Hkv > 65535) return -1;
+  KvInt4Args a;
+  a.qkv = (const _Float16*)qkv; a.kc = (uint8_t*)kc; a.vc = (uint8_t*)vc; a.ks = (_Float16*)ks; a.vs = (_Float16*)vs;
+  a.B = B; a.Hq = Hq; a.Hkv = Hkv; a.S = S; a.D = D; a.past = past; a.Lmax = Lmax; a.ld = ld;
+  const int64_t items = (int64_t)S * (D / 32);
+  hipLaunchKernelGGL(kv_int4_append_kernel, dim3((unsigned)((items + 255) / 256), Hkv, B), dim3(256), 0, st, a);
+  return HIP_CHECK_LAUNCH();
+}
 
 // qkv [B, S, ld] fp16 (heads: Hq q, Hkv k, Hkv v; head h at column h*D).  past + S <= Lmax (validated here).
 extern "C" int bigdl_prefill_rope_append(void* qkv, void* kc, void* vc, void* vt_scratch, const float* table,

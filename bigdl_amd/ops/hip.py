@@ -38,7 +38,8 @@ def lib():
         vp, i64, ci, cf = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
         L.bigdl_gemv_lowbit.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, cf, cf, ci, ci, ci, ci, ci, ci, ci, ci, vp, ci, ci, ci, ci, ci, ci, vp]
         L.bigdl_gemv_lowbit_ln.argtypes = [vp] * 8 + [cf] + [ci] * 8 + [vp] * 5
-        L.bigdl_attn_decode.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, ci, ci, ci, cf, cf] + [ci] * 14 + [vp]
+        L.bigdl_attn_decode.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, ci, ci, ci, cf, cf] + [ci] * 14 + [vp, vp, vp]
+        L.bigdl_kv_int4_append.argtypes = [vp, vp, vp, vp, vp] + [ci] * 7 + [i64, vp]
         L.bigdl_attn_decode_ws_floats.argtypes = [ci] * 6
         L.bigdl_attn_decode_ws_floats.restype = i64
         L.bigdl_attn_decode_counters.argtypes = [ci] * 3
@@ -622,8 +623,11 @@ def rope_append(qkv, k_cache, v_cache, past_len, inv_freq, *, n_heads, n_kv_head
 
 def attn_decode(qkv, k_cache, v_cache, past_len, out, ws, counters, *, n_heads, n_kv_heads, head_dim, q_len, batch,
                 scale, splits, softcap=0.0, window=0, mask=None, rope_table=None, rot_dim=None, interleaved=False,
-                position_ids=None, append=False, defer_combine=False, alibi=None):
+                position_ids=None, append=False, defer_combine=False, alibi=None, k_scale=None, v_scale=None):
     """Split-KV decode attention over the fixed-capacity caches.
+
+    ``k_scale`` / ``v_scale``: int4 caches (``kv_int4_shapes``): K [B,Hkv,L,D/2] and V^T [B,Hkv,D/2,L] bytes with fp16
+    scales per key and 32 channels; the kernel always appends itself in that mode (``rope_table`` or ``append=True``).
 
     ``alibi``: optional fp32 [n_heads] slopes; the score of key position j for the query at position i gets the ALiBi
     bias ``slope * (j - i)`` added.
@@ -632,7 +636,7 @@ def attn_decode(qkv, k_cache, v_cache, past_len, out, ws, counters, *, n_heads, 
     rotates + appends the new k / v^T (one launch instead of rope_append + attention); ``append=True``
     without a table appends unrotated k/v.  Row counts above 32 are processed in token chunks.
     """
-    _need_cuda(qkv, k_cache, v_cache, past_len, out, ws, counters, mask, rope_table, position_ids)
+    _need_cuda(qkv, k_cache, v_cache, past_len, out, ws, counters, mask, rope_table, position_ids, k_scale, v_scale)
     lmax = k_cache.shape[2]
     if qkv.dtype != torch.float16 or out.dtype != torch.float16 or qkv.dim() != 2 or qkv.stride(1) != 1:
         raise ValueError("qkv/out must be fp16, qkv 2-D with contiguous rows")
@@ -640,14 +644,19 @@ def attn_decode(qkv, k_cache, v_cache, past_len, out, ws, counters, *, n_heads, 
         raise ValueError("qkv shape does not match batch/q_len/heads")
     if tuple(out.shape) != (batch * q_len, n_heads * head_dim) or not out.is_contiguous():
         raise ValueError("out must be contiguous [batch*q_len, n_heads*head_dim]")
-    if tuple(k_cache.shape) != (batch, n_kv_heads, lmax, head_dim) or tuple(v_cache.shape) != (batch, n_kv_heads, head_dim, lmax):
+    int4 = k_scale is not None
+    if int4:
+        _check_kv_int4(k_cache, v_cache, k_scale, v_scale, batch, n_kv_heads, head_dim)
+        if rope_table is None and not append:
+            raise ValueError("int4 caches are appended by the attention kernel (rope_table or append=True)")
+    elif tuple(k_cache.shape) != (batch, n_kv_heads, lmax, head_dim) or tuple(v_cache.shape) != (batch, n_kv_heads, head_dim, lmax):
         raise ValueError("cache shapes must be K [B,Hkv,L,D], V^T [B,Hkv,D,L]")
     if not (k_cache.is_contiguous() and v_cache.is_contiguous()) or k_cache.dtype != v_cache.dtype:
         raise ValueError("caches must be contiguous and of one dtype")
     if lmax % 256:
         raise ValueError("cache capacity must be a multiple of 256")
-    fp8 = k_cache.dtype == torch.uint8
-    if not fp8 and k_cache.dtype != torch.float16:
+    fp8 = k_cache.dtype == torch.uint8 and not int4
+    if not fp8 and not int4 and k_cache.dtype != torch.float16:
         raise ValueError("cache dtype must be float16 or uint8 (e5m2)")
     g = n_heads // n_kv_heads
     nchunk = (g + 31) // 32                      # groups above 32 query heads are split over workgroup columns
@@ -689,9 +698,69 @@ def attn_decode(qkv, k_cache, v_cache, past_len, out, ws, counters, *, n_heads, 
                                      _ptr(rope_table), _ptr(position_ids), rope_max, rot,
                                      int(bool(interleaved)), scale, softcap, batch, n_heads, n_kv_heads, q_len, off, cnt,
                                      qkv.stride(0), lmax, head_dim, splits, window, int(fp8), int(bool(do_append)),
-                                     int(bool(defer_combine)), _stream())
+                                     int(bool(defer_combine)), _ptr(k_scale), _ptr(v_scale), _stream())
         _check(rc, "attn_decode")
     return out
+
+
+KV_INT4_HEAD_DIMS = (64, 128, 256)
+
+
+def kv_int4_shapes(batch, n_kv_heads, capacity, head_dim):
+    """Shapes of the four tensors of one layer's int4 cache: K bytes, V^T bytes (uint8), K scales, V scales (fp16).
+    K: one 32-bit word per 8 channels of a key, channel j in nibble (j >> 1) + 4 (j & 1); V^T row 16m + r holds channels
+    32m + r (low nibble) and 32m + 16 + r (high nibble); value = (nibble - 8) * scale, one scale per key and 32 channels."""
+    d = head_dim
+    return ((batch, n_kv_heads, capacity, d // 2), (batch, n_kv_heads, d // 2, capacity),
+            (batch, n_kv_heads, capacity, d // 32), (batch, n_kv_heads, d // 32, capacity))
+
+
+def _check_kv_int4(k_cache, v_cache, k_scale, v_scale, batch, n_kv_heads, head_dim):
+    if head_dim not in KV_INT4_HEAD_DIMS:
+        raise ValueError(f"int4 caches need head_dim in {KV_INT4_HEAD_DIMS}")
+    if v_scale is None or k_scale is None:
+        raise ValueError("int4 caches need both scale tensors")
+    want = kv_int4_shapes(batch, n_kv_heads, k_cache.shape[2], head_dim)
+    got = tuple(tuple(t.shape) for t in (k_cache, v_cache, k_scale, v_scale))
+    if got != want:
+        raise ValueError(f"int4 cache shapes {got} != {want}")
+    if k_cache.dtype != torch.uint8 or v_cache.dtype != torch.uint8 or k_scale.dtype != torch.float16 or v_scale.dtype != torch.float16:
+        raise ValueError("int4 caches are uint8 with fp16 scales")
+    if not all(t.is_contiguous() for t in (k_cache, v_cache, k_scale, v_scale)):
+        raise ValueError("int4 caches must be contiguous")
+
+
+def kv_int4_append(qkv, k_cache, v_cache, k_scale, v_scale, *, n_heads, n_kv_heads, head_dim, past):
+    """Quantize the (already rotated) keys and the values of a prompt, qkv [B, S, (Hq + 2 Hkv) D] fp16, into the int4
+    caches at positions past .. past + S."""
+    _need_cuda(qkv, k_cache, v_cache, k_scale, v_scale)
+    if qkv.dtype != torch.float16 or qkv.dim() != 3 or qkv.stride(2) != 1 or qkv.shape[2] < (n_heads + 2 * n_kv_heads) * head_dim:
+        raise ValueError("qkv must be fp16 [B, S, (Hq + 2 Hkv) D]")
+    b, s = qkv.shape[:2]
+    if b > 1 and qkv.stride(0) != s * qkv.stride(1):
+        raise ValueError("qkv batch stride must be S rows")
+    _check_kv_int4(k_cache, v_cache, k_scale, v_scale, b, n_kv_heads, head_dim)
+    if past < 0 or past + s > k_cache.shape[2]:
+        raise ValueError("KV cache capacity exceeded")
+    rc = lib().bigdl_kv_int4_append(_ptr(qkv), _ptr(k_cache), _ptr(v_cache), _ptr(k_scale), _ptr(v_scale), b, n_heads,
+                                    n_kv_heads, s, head_dim, past, k_cache.shape[2], qkv.stride(1), _stream())
+    _check(rc, "kv_int4_append")
+
+
+def kv_int4_dequant(k_cache, v_cache, k_scale, v_scale, length):
+    """fp16 K [B,Hkv,length,D] and V^T [B,Hkv,D,length] of the first ``length`` positions of an int4 cache (prompt
+    passes over a non-empty cache, tests); plain tensor ops."""
+    b, h, _, d2 = k_cache.shape
+    d = 2 * d2
+    kb = k_cache[:, :, :length].reshape(b, h, length, d // 8, 4).to(torch.int32)
+    w = kb[..., 0] | (kb[..., 1] << 8) | (kb[..., 2] << 16) | (kb[..., 3] << 24)                  # one word per 8 channels
+    j = torch.arange(8, device=k_cache.device)
+    nib = (w[..., None] >> (4 * ((j >> 1) + 4 * (j & 1)))) & 15                                  # [.., D/8, 8]
+    k = (nib - 8).to(torch.float16).reshape(b, h, length, d // 32, 32) * k_scale[:, :, :length, :, None]
+    vb = v_cache[:, :, :, :length].reshape(b, h, d // 32, 16, length).to(torch.int32)
+    lo, hi = (vb & 15) - 8, (vb >> 4) - 8                                                         # channels 32m+r, 32m+16+r
+    v = torch.cat([lo, hi], 3).to(torch.float16) * v_scale[:, :, :, None, :length]                # [B,H,D/32,32,L]
+    return k.reshape(b, h, length, d), v.reshape(b, h, d, length)
 
 
 PREFILL_HEAD_DIMS = (64, 96, 128, 256)
@@ -752,19 +821,26 @@ def prefill_rope_append(qkv, k_cache, v_cache, rope_table, *, n_heads, n_kv_head
                         interleaved=False, position_ids=None, vt_scratch=None):
     """One launch per layer for a prompt: rotate q and k in place in ``qkv`` [B, S, (Hq+2Hkv)*D], copy k to the K
     cache [B, Hkv, Lmax, D] and v transposed to the V^T cache [B, Hkv, D, Lmax] (fp16 or e5m2 by the cache dtype);
-    ``vt_scratch`` [B, Hkv, D, S_alloc] fp16 additionally receives V^T unquantized (for e5m2 caches)."""
+    ``vt_scratch`` [B, Hkv, D, S_alloc] fp16 additionally receives V^T unquantized (for e5m2 caches).  Without caches
+    (both None) only the rotation and the scratch copy happen."""
     _need_cuda(qkv, k_cache, v_cache, rope_table, position_ids, vt_scratch)
     b, s, width = qkv.shape
     d = head_dim
     if qkv.dtype != torch.float16 or qkv.stride(2) != 1 or qkv.stride(0) != s * qkv.stride(1) or width != (n_heads + 2 * n_kv_heads) * d:
         raise ValueError("qkv must be fp16 [B, S, (Hq+2Hkv)*D] with uniform row stride")
-    fp8 = k_cache.dtype == torch.uint8
-    lmax = k_cache.shape[2]
-    if tuple(k_cache.shape) != (b, n_kv_heads, lmax, d) or tuple(v_cache.shape) != (b, n_kv_heads, d, lmax) \
-            or not k_cache.is_contiguous() or not v_cache.is_contiguous() or v_cache.dtype != k_cache.dtype:
-        raise ValueError("cache shapes do not match")
-    if past + s > lmax:
-        raise ValueError("KV cache capacity exceeded")
+    if k_cache is None:
+        # rotation only (int4 caches are filled by kv_int4_append from the rotated qkv); V^T goes to the scratch
+        if v_cache is not None:
+            raise ValueError("pass both caches or none")
+        fp8, lmax = True, past + s
+    else:
+        fp8 = k_cache.dtype == torch.uint8
+        lmax = k_cache.shape[2]
+        if tuple(k_cache.shape) != (b, n_kv_heads, lmax, d) or tuple(v_cache.shape) != (b, n_kv_heads, d, lmax) \
+                or not k_cache.is_contiguous() or not v_cache.is_contiguous() or v_cache.dtype != k_cache.dtype:
+            raise ValueError("cache shapes do not match")
+        if past + s > lmax:
+            raise ValueError("KV cache capacity exceeded")
     rot = d if rot_dim is None else rot_dim
     if rope_table.dtype != torch.float32 or not rope_table.is_contiguous() or (rot and rope_table.shape[1] != rot // 2):
         raise ValueError("rope table must be fp32 [max_pos, rot/2, 2]")

@@ -723,3 +723,75 @@ def test_gemv_layernorm_fold(hip, name, cfg):
     assert not hip.gemv_x_in_lds(16, 11008)
     with pytest.raises(ValueError):
         hip.gemv_lowbit_ln(torch.zeros(16, 11008, dtype=torch.float16, device="cuda"), w, qt, n, 11008, gamma.cuda(), ln)
+
+
+@pytest.mark.parametrize("interleaved", [False, True])
+@pytest.mark.parametrize("cfg", [(1, 32, 32, 128, 1, 1000), (2, 32, 8, 128, 1, 300), (1, 8, 2, 64, 5, 77),
+                                 (1, 4, 4, 256, 3, 513), (2, 48, 1, 128, 1, 130), (3, 8, 8, 128, 9, 40)])
+def test_int4_kv_cache_append_and_decode(hip, cfg, interleaved):
+    """int4 caches: the prompt-side quantizer and the in-kernel append agree with a plain per-32-channel symmetric
+    quantization, and the attention output equals fp32 attention over exactly the dequantized cache contents."""
+    torch.manual_seed(11)
+    b, hq, hkv, d, q_len, past = cfg
+    lmax = 1280
+    ld = (hq + 2 * hkv) * d
+    shapes = hip.kv_int4_shapes(b, hkv, lmax, d)
+    kc, vc = (torch.zeros(s, dtype=torch.uint8, device="cuda") for s in shapes[:2])
+    ks, vs = (torch.zeros(s, dtype=torch.float16, device="cuda") for s in shapes[2:])
+    inv_freq = 1.0 / (10000 ** (torch.arange(0, d, 2).float() / d))
+    ang = torch.arange(lmax)[:, None].float() * inv_freq[None]
+    table = torch.stack([ang.cos(), ang.sin()], -1).contiguous().cuda()
+
+    def rope(x, pos):  # x [B,H,S,D]
+        a = pos[None, None, :, None].float() * inv_freq
+        if interleaved:
+            x0, x1 = x[..., 0::2], x[..., 1::2]
+            return torch.stack([x0 * a.cos() - x1 * a.sin(), x1 * a.cos() + x0 * a.sin()], -1).flatten(-2)
+        x0, x1 = x[..., : d // 2], x[..., d // 2:]
+        return torch.cat([x0 * a.cos() - x1 * a.sin(), x1 * a.cos() + x0 * a.sin()], -1)
+
+    def fake_quant(t):  # [..., D] -> what an int4 cache with fp16 scales per 32 channels holds
+        g = t.half().float().reshape(*t.shape[:-1], d // 32, 32)
+        sc = (g.abs().amax(-1, keepdim=True) / 7).half().float()
+        q = torch.clamp(torch.round(g / sc.clamp_min(1e-30)), -8, 7)
+        return (q * sc).reshape(t.shape)
+
+    # the prompt: rotated keys (as prefill_rope_append leaves them in qkv) + values -> caches
+    prompt = (torch.randn(b, past, ld) * 0.5).half()
+    x = prompt.float().view(b, past, hq + 2 * hkv, d).transpose(1, 2)
+    k_prompt, v_prompt = x[:, hq:hq + hkv], x[:, hq + hkv:]
+    hip.kv_int4_append(prompt.cuda(), kc, vc, ks, vs, n_heads=hq, n_kv_heads=hkv, head_dim=d, past=0)
+    k_deq, v_deq = hip.kv_int4_dequant(kc, vc, ks, vs, past)
+    def flips(a, ref):      # x * (1 / scale) vs x / scale: a value on a rounding boundary may land one step off
+        return ((a - ref).abs() > 2e-3).float().mean().item()
+    assert flips(k_deq.float().cpu(), fake_quant(k_prompt)) < 1e-4
+    assert flips(v_deq.float().cpu().transpose(-1, -2), fake_quant(v_prompt)) < 1e-4
+
+    # one decode call with q_len new tokens: rotation + quantized append inside the attention kernel
+    qkv = (torch.randn(b * q_len, ld) * 0.5).half()
+    y = qkv.float().view(b, q_len, hq + 2 * hkv, d).transpose(1, 2)
+    pos = torch.arange(past, past + q_len)
+    q_rot, k_new, v_new = rope(y[:, :hq], pos), rope(y[:, hq:hq + hkv], pos), y[:, hq + hkv:]
+    past_len = torch.full((b,), past, dtype=torch.int32, device="cuda")
+    scale = 1.0 / math.sqrt(d)
+    for splits in (1, 3):
+        out = torch.empty(b * q_len, hq * d, dtype=torch.float16, device="cuda")
+        ws = torch.empty(hip.attn_decode_ws_floats(b, hq, hkv, q_len, d, splits) + 16, dtype=torch.float32, device="cuda")
+        counters = torch.zeros(hip.attn_decode_counters(b, hq, hkv), dtype=torch.int32, device="cuda")
+        hip.attn_decode(qkv.cuda(), kc, vc, past_len, out, ws, counters, n_heads=hq, n_kv_heads=hkv, head_dim=d,
+                        q_len=q_len, batch=b, scale=scale, splits=splits, rope_table=table, interleaved=interleaved,
+                        k_scale=ks, v_scale=vs)
+        k_all, v_all = hip.kv_int4_dequant(kc, vc, ks, vs, past + q_len)
+        k_all, v_all = k_all.float().cpu(), v_all.float().cpu().transpose(-1, -2)
+        # the appended tokens: within half a quantization step of the true rotated key / value
+        bad = ((k_all[:, :, past:] - fake_quant(k_new)).abs() > 2e-3).float().mean()
+        assert bad < 0.02, bad            # table cos/sin in fp32 vs torch: a rounding flips now and then
+        assert flips(v_all[:, :, past:], fake_quant(v_new)) < 1e-3
+        ref = _ref_attention(q_rot.half().float(), k_all, v_all, scale, past=past)
+        got = out.cpu().float().view(b, q_len, hq, d).transpose(1, 2)
+        torch.testing.assert_close(got, ref, rtol=1e-2, atol=1e-2)
+        assert int(counters.abs().sum()) == 0
+    # and against the unquantized values: int4 noise only
+    exact = _ref_attention(q_rot, torch.cat([k_prompt, k_new], 2), torch.cat([v_prompt, v_new], 2), scale, past=past)
+    rel = ((got - exact).abs().mean() / exact.abs().mean()).item()
+    assert rel < 0.25, rel
