@@ -28,7 +28,7 @@ def main():
     ap.add_argument("--in-len", type=int, default=1024)
     ap.add_argument("--out-len", type=int, default=128)
     ap.add_argument("--low-bit", default="sym_int4")
-    ap.add_argument("--kv", default="fp8", choices=["fp8", "fp16"])
+    ap.add_argument("--kv", default="fp8", choices=["fp8", "fp16", "int4"])
     ap.add_argument("--model", default="llama2-7b", choices=["llama2-7b", "tinyllama"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--parallelism", default="dp", choices=["dp", "tp"],
@@ -67,7 +67,7 @@ def main():
 
     def trial():
         out = model.generate(prompt, max_new_tokens=args.out_len, min_new_tokens=args.out_len, do_sample=False,
-                             kv_fp8=args.kv == "fp8")
+                             kv_fp8={"fp8": True, "fp16": False, "int4": "int4"}[args.kv])
         assert out.shape[1] == args.in_len + args.out_len
         return model.first_cost, model.rest_cost_mean, model.peak_memory
 

@@ -29,7 +29,7 @@ def main():
     g = torch.Generator().manual_seed(0)
     for slots in [int(s) for s in args.slots.split(",")]:
         n_req = slots * args.requests_per_slot
-        cb = ContinuousBatcher(eng, max_num_seqs=slots, max_seq_len=args.in_len + args.out_len + 1, kv_fp8=args.kv == "fp8",
+        cb = ContinuousBatcher(eng, max_num_seqs=slots, max_seq_len=args.in_len + args.out_len + 1, kv_fp8={"fp8": True, "fp16": False, "int4": "int4"}[args.kv],
                                max_prefill_per_step=1)
         # warm-up: graph capture + one short request
         cb.submit(SeqRequest("w", torch.randint(3, cfg.vocab_size, (64,), generator=g).tolist(), max_new_tokens=4))

@@ -822,9 +822,9 @@ class NativeCausalLM:
     @torch.no_grad()
     def generate(self, input_ids, max_new_tokens=32, do_sample=False, eos_token_id=None, **kw):
         if self.engine is not None:
-            from ..transformers.utils import use_quantize_kv_cache
+            from ..transformers.utils import engine_kv_mode
             out = self.engine.generate(input_ids, max_new_tokens=max_new_tokens, do_sample=do_sample,
-                                       eos_token_id=eos_token_id, kv_fp8=use_quantize_kv_cache(), **kw)
+                                       eos_token_id=eos_token_id, kv_fp8=engine_kv_mode(), **kw)
             self.first_cost, self.rest_cost_mean = self.engine.first_cost, self.engine.rest_cost_mean
             self.peak_memory = self.engine.peak_memory
             return out

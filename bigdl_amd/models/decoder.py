@@ -211,18 +211,33 @@ class LayerWeights:
 
 
 class KVCache:
-    """Fixed-capacity cache: K [L][B,Hkv,Lmax,D], V^T [L][B,Hkv,D,Lmax]; fp16 or e5m2 bytes."""
+    """Fixed-capacity cache: K [L][B,Hkv,Lmax,D], V^T [L][B,Hkv,D,Lmax]; fp16, e5m2 bytes (``fp8=True``) or int4 with
+    fp16 scales per key and 32 channels (``fp8="int4"``, layout in ops/hip.py::kv_int4_shapes)."""
 
-    def __init__(self, cfg: DecoderConfig, batch: int, capacity: int, fp8: bool, device):
+    def __init__(self, cfg: DecoderConfig, batch: int, capacity: int, fp8, device):
         capacity = (capacity + 255) // 256 * 256
-        dt = torch.uint8 if fp8 else torch.float16
-        self.fp8 = fp8
+        self.mode = fp8                      # what ensure_cache compares: False / True / "int4"
+        self.int4 = fp8 == "int4"
+        self.fp8 = bool(fp8) and not self.int4
+        self.quantized = self.fp8 or self.int4
         self.capacity = capacity
         self.batch = batch
-        self.k = [torch.zeros(batch, cfg.num_kv_heads, capacity, cfg.head_dim, dtype=dt, device=device)
-                  for _ in range(cfg.num_layers)]
-        self.v = [torch.zeros(batch, cfg.num_kv_heads, cfg.head_dim, capacity, dtype=dt, device=device)
-                  for _ in range(cfg.num_layers)]
+        self.k_scale = self.v_scale = None
+        if self.int4:
+            from ..ops import hip
+            if cfg.head_dim not in hip.KV_INT4_HEAD_DIMS:
+                raise ValueError(f"the int4 KV cache needs head_dim in {hip.KV_INT4_HEAD_DIMS}, got {cfg.head_dim}")
+            sk, sv, ssk, ssv = hip.kv_int4_shapes(batch, cfg.num_kv_heads, capacity, cfg.head_dim)
+            self.k = [torch.zeros(sk, dtype=torch.uint8, device=device) for _ in range(cfg.num_layers)]
+            self.v = [torch.zeros(sv, dtype=torch.uint8, device=device) for _ in range(cfg.num_layers)]
+            self.k_scale = [torch.zeros(ssk, dtype=torch.float16, device=device) for _ in range(cfg.num_layers)]
+            self.v_scale = [torch.zeros(ssv, dtype=torch.float16, device=device) for _ in range(cfg.num_layers)]
+        else:
+            dt = torch.uint8 if self.fp8 else torch.float16
+            self.k = [torch.zeros(batch, cfg.num_kv_heads, capacity, cfg.head_dim, dtype=dt, device=device)
+                      for _ in range(cfg.num_layers)]
+            self.v = [torch.zeros(batch, cfg.num_kv_heads, cfg.head_dim, capacity, dtype=dt, device=device)
+                      for _ in range(cfg.num_layers)]
         self.past_len = torch.zeros(batch, dtype=torch.int32, device=device)
         self.host_len = 0  # host mirror of past_len (uniform across the batch)
         # continuous batching: every batch row is a slot with its own length; rows whose `active` entry is 0 do not
@@ -259,7 +274,11 @@ class KVCache:
         self.host_len = length
 
     def nbytes(self):
-        return sum(t.numel() * t.element_size() for t in self.k + self.v)
+        return sum(t.numel() * t.element_size() for t in self.k + self.v + (self.k_scale or []) + (self.v_scale or []))
+
+    def scales(self, li):
+        """keyword arguments of ``hip.attn_decode`` for layer ``li`` (empty unless int4)"""
+        return dict(k_scale=self.k_scale[li], v_scale=self.v_scale[li]) if self.int4 else {}
 
 
 class NativeDecoder:
@@ -302,12 +321,15 @@ class NativeDecoder:
     # ------------------------------------------------------------------ cache
     def ensure_cache(self, batch: int, needed: int, fp8: bool = False):
         c = self.cache
-        if c is None or c.batch != batch or c.capacity < needed or c.fp8 != fp8:
+        if c is None or c.batch != batch or c.capacity < needed or c.mode != fp8:
             cap = max(needed, 256)
             self.cache = KVCache(self.cfg, batch, cap, fp8, self.device)
             self._graphs.clear()
             self._static.clear()
             self._build_rope_table(self.cache.capacity)
+            if self.cache.int4 and not self.fused_rope:
+                raise ValueError("the int4 KV cache needs the attention kernel's own RoPE + append (full or interleaved "
+                                 "rotary); this model rotates part of the head in rotate-half order")
         return self.cache
 
     def _build_rope_table(self, max_pos: int):
@@ -426,10 +448,19 @@ class NativeDecoder:
             # one launch: RoPE on q / k in place, K -> cache, V -> V^T cache (+ fp16 V^T scratch for e5m2 caches)
             rot = cfg.rot_dim or d
             scratch = None
-            if cache.fp8 and past == 0:
+            if cache.quantized and past == 0:
                 scratch = self._vt_scratch(b, hkv, d, s)
-            hip.prefill_rope_append(qkv, kc, vc, self.rope_table, n_heads=hq, n_kv_heads=hkv, head_dim=d, past=past,
-                                    rot_dim=rot, interleaved=cfg.rope_interleaved, vt_scratch=scratch)
+            if cache.int4:
+                # rotate in place, then quantize keys / values of the prompt into the int4 caches
+                ksc, vsc = cache.k_scale[li], cache.v_scale[li]
+                if slot is not None:
+                    ksc, vsc = ksc[slot:slot + 1], vsc[slot:slot + 1]
+                hip.prefill_rope_append(qkv, None, None, self.rope_table, n_heads=hq, n_kv_heads=hkv, head_dim=d,
+                                        past=past, rot_dim=rot, interleaved=cfg.rope_interleaved, vt_scratch=scratch)
+                hip.kv_int4_append(qkv, kc, vc, ksc, vsc, n_heads=hq, n_kv_heads=hkv, head_dim=d, past=past)
+            else:
+                hip.prefill_rope_append(qkv, kc, vc, self.rope_table, n_heads=hq, n_kv_heads=hkv, head_dim=d, past=past,
+                                        rot_dim=rot, interleaved=cfg.rope_interleaved, vt_scratch=scratch)
             vt = scratch[..., :s] if scratch is not None else vc[:, :, :, :s]
             if past == 0:
                 kk = k                       # attention reads the unquantized K / V^T of this call
@@ -491,7 +522,8 @@ class NativeDecoder:
                         n_heads=cfg.num_heads, n_kv_heads=cfg.num_kv_heads, head_dim=cfg.head_dim, q_len=1,
                         batch=batch, scale=self.attn_scale, splits=st["splits"], softcap=cfg.attn_softcap,
                         window=lw.window, rope_table=self.rope_table if self.fused_rope and not self.no_rope else None,
-                        append=self.no_rope, alibi=self.alibi, interleaved=cfg.rope_interleaved, defer_combine=False)
+                        append=self.no_rope, alibi=self.alibi, interleaved=cfg.rope_interleaved, defer_combine=False,
+                        **cache.scales(li))
         return out
 
     @torch.no_grad()
@@ -504,6 +536,7 @@ class NativeDecoder:
         from ..ops import hip
         from ..parallel import context_parallel as cp
         cfg, cache = self.cfg, self.cache
+        assert not cache.int4, "context-parallel prefill gathers fp16 / e5m2 caches"
         b, s = input_ids.shape
         assert b == 1 and cache.host_len == 0 and cache.slot_len is None, "context-parallel prefill: one sequence, empty cache"
         assert s <= cache.capacity, "KV cache capacity exceeded"
@@ -571,6 +604,8 @@ class NativeDecoder:
         from ..ops import hip
         c = self.cache
         rows = slice(None) if slot is None else slice(slot, slot + 1)
+        if c.int4:
+            return hip.kv_int4_dequant(c.k[li][rows], c.v[li][rows], c.k_scale[li][rows], c.v_scale[li][rows], length)
         k = c.k[li][rows, :, :length]
         vt = c.v[li][rows, :, :, :length]
         if c.fp8:
@@ -726,7 +761,7 @@ class NativeDecoder:
                             window=lw.window,
                             rope_table=self.rope_table if self.fused_rope and not self.no_rope else None,
                             append=self.no_rope, alibi=self.alibi,
-                            interleaved=cfg.rope_interleaved, defer_combine=st["defer"] and lw.o.fused)
+                            interleaved=cfg.rope_interleaved, defer_combine=st["defer"] and lw.o.fused, **cache.scales(li))
             att_partials = st["att_partials"] if st["defer"] and lw.o.fused else None
             if layer_norm and cfg.parallel_residual:
                 # the MLP reads the layer input: its first GEMV runs before o_proj adds the attention output to h

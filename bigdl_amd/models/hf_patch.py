@@ -521,7 +521,7 @@ def native_generate(self, inputs=None, **kwargs):
     if max_new is None:
         ml = kwargs.get("max_length", getattr(gc, "max_length", None) or 20)
         max_new = max(1, ml - input_ids.shape[1])
-    from ..transformers.utils import use_quantize_kv_cache
+    from ..transformers.utils import engine_kv_mode
     eng = get_native_engine(self)
     out = eng.generate(
         input_ids, max_new_tokens=max_new, min_new_tokens=kwargs.get("min_new_tokens", 0) or 0,
@@ -532,7 +532,7 @@ def native_generate(self, inputs=None, **kwargs):
         repetition_penalty=kwargs.get("repetition_penalty", getattr(gc, "repetition_penalty", 1.0)) or 1.0,
         eos_token_id=kwargs.get("eos_token_id", getattr(gc, "eos_token_id", None)),
         pad_token_id=kwargs.get("pad_token_id", getattr(gc, "pad_token_id", None)),
-        streamer=kwargs.get("streamer"), kv_fp8=use_quantize_kv_cache())
+        streamer=kwargs.get("streamer"), kv_fp8=engine_kv_mode())
     for attr in ("first_cost", "rest_cost_mean", "first_token_time", "last_token_time", "peak_memory"):
         object.__setattr__(self, attr, getattr(eng, attr))
     return out

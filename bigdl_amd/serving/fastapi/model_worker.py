@@ -164,12 +164,12 @@ class BatchedModelWorker(ModelWorker):
     def __init__(self, *args, max_num_seqs: int = 16, max_seq_len: int = 4096, max_prefilled_seqs: int = 1, **kw):
         super().__init__(*args, **kw)
         from ...models.hf_patch import get_native_engine, native_engine_supported
-        from ...transformers.utils import use_quantize_kv_cache
+        from ...transformers.utils import engine_kv_mode
         self.batcher = None
         if self.device != "cpu" and native_engine_supported(self.model):
             from ..continuous import ContinuousBatcher
             self.batcher = ContinuousBatcher(get_native_engine(self.model), max_num_seqs=max_num_seqs,
-                                             max_seq_len=max_seq_len, kv_fp8=use_quantize_kv_cache(),
+                                             max_seq_len=max_seq_len, kv_fp8=engine_kv_mode(),
                                              max_prefill_per_step=max_prefilled_seqs, on_token=self._on_token)
         self._loop = None
         self._text: Dict[str, _QueueStreamer] = {}

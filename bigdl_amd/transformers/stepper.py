@@ -102,8 +102,8 @@ class NativeStepper:
 def make_stepper(model, kv_fp8=None, capacity=None):
     """Native engine when the model has one and lives on the GPU, else the HF forward."""
     from ..models.hf_patch import get_native_engine, native_engine_supported
-    from .utils import use_quantize_kv_cache
+    from .utils import engine_kv_mode
     dev = next(model.parameters()).device
     if dev.type == "cuda" and native_engine_supported(model):
-        return NativeStepper(get_native_engine(model), use_quantize_kv_cache() if kv_fp8 is None else kv_fp8, capacity)
+        return NativeStepper(get_native_engine(model), engine_kv_mode() if kv_fp8 is None else kv_fp8, capacity)
     return HFStepper(model)

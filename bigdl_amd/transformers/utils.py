@@ -191,6 +191,16 @@ def use_quantize_kv_cache(linear=None, x=None, kv_group: int = 1) -> bool:
     return False
 
 
+def engine_kv_mode():
+    """KV precision of the native engine: False (fp16), True (e5m2) or "int4".  ``IPEX_LLM_QUANTIZE_KV_CACHE=int4``
+    (or ``BIGDL_KV_CACHE_INT4=1``) selects the int4 cache, which the reference does not have; everything else follows
+    ``use_quantize_kv_cache``."""
+    env = os.environ.get("IPEX_LLM_QUANTIZE_KV_CACHE", os.environ.get("BIGDL_QUANTIZE_KV_CACHE"))
+    if env == "int4" or os.environ.get("BIGDL_KV_CACHE_INT4") == "1":
+        return "int4"
+    return use_quantize_kv_cache()
+
+
 def should_use_compresskv(x=None, prompt_len: int = 0) -> bool:
     """SnapKV policy (reference models/utils.py:317-330): env override only; never in performance mode."""
     if os.environ.get("IPEX_LLM_PERFORMANCE_MODE") == "1":

@@ -137,6 +137,43 @@ def test_continuous_batching_matches_per_request_generation():
     assert agree >= 0.8 * total, (want, got)
 
 
+def test_int4_kv_cache_generation_tracks_fp16_cache():
+    """Engine on the int4 cache: prompt pass, decode steps, a second prompt pass over the non-empty cache and slot
+    mode all run; logits stay close to the fp16-cache engine and the cache takes a quarter of the memory + scales."""
+    from bigdl_amd.models import decoder as D
+    from bigdl_amd.serving.continuous import generate_batch
+    cfg = D.DecoderConfig(vocab_size=512, hidden_size=512, intermediate_size=512, num_layers=3, num_heads=4, num_kv_heads=2,
+                          head_dim=128, max_position=1024)
+    eng = D.build_random_decoder(cfg, device="cuda", seed=3)
+    torch.manual_seed(0)
+    ids = torch.randint(3, 512, (2, 150), device="cuda")
+    more = torch.randint(3, 512, (2, 20), device="cuda")
+    lg, size = {}, {}
+    for mode in (False, "int4"):
+        cache = eng.ensure_cache(2, 400, fp8=mode)
+        cache.reset()
+        assert cache.int4 == (mode == "int4")
+        size[mode] = cache.nbytes()
+        a = eng.prefill(ids)[:, -1].clone()
+        tok = a.argmax(-1).view(2, 1)
+        b = eng.decode(tok, 1)[0].clone()
+        c = eng.decode(tok, 1)[0].clone()
+        d = eng.prefill(more)[:, -1].clone()               # prompt pass over a non-empty cache (dequantized read)
+        lg[mode] = (a, b, c, d)
+        assert cache.host_len == 172
+    assert size["int4"] * 32 == size[False] * 9              # 4 bits + one fp16 scale per 32 values = 4.5 of 16 bits
+    for x, y in zip(lg[False], lg["int4"]):
+        rel = ((x - y).abs().mean() / x.abs().mean()).item()
+        assert rel < 0.12, rel
+    out = eng.generate(ids, max_new_tokens=8, kv_fp8="int4")
+    assert out.shape == (2, 158) and eng.cache.int4
+    prompts = [ids[0, :n].tolist() for n in (40, 90, 17)]
+    got = generate_batch(eng, prompts, max_new_tokens=6, max_num_seqs=2, kv_fp8="int4")
+    assert [len(g) for g in got] == [6, 6, 6]
+    want = eng.generate(ids[:1, :40], max_new_tokens=1, kv_fp8="int4")
+    assert got[0][0] == int(want[0, -1])
+
+
 @pytest.mark.parametrize("fp8", [False, True])
 def test_mixed_prompt_and_decode_pass_matches_separate_passes(fp8):
     """prefill(with_decode=True) = one decode step of the running slots + the prompt pass of a new one: same logits,
