@@ -188,6 +188,65 @@ def convert_minicpm(cfg: dict, sd: StateDict):
     return dc, _llama_keys(cfg, sd, dc, o_scale=rs, down_scale=rs)
 
 
+def _mla_layout(cfg: dict):
+    """(nope, rope, v, padded head_dim) of a latent-attention config"""
+    n, r, vd = cfg["qk_nope_head_dim"], cfg["qk_rope_head_dim"], cfg["v_head_dim"]
+    need = max(n + r, vd)
+    fits = [x for x in ENGINE_HEAD_DIMS if x >= need]
+    if not fits:
+        raise NotImplementedError(f"latent attention with {need} channels per head")
+    return n, r, vd, min(fits)
+
+
+def _mla_keys(cfg: dict, sd: StateDict, out: StateDict, i: int, o_scale: float = 1.0):
+    """Latent-attention projections of layer ``i`` in the engine's head layout (decoder.py::MLAWeights): q heads
+    [rotary | no-position | 0], K heads [0 (shared rotary key goes here) | no-position | 0], V heads [v | 0]."""
+    n, r, vd, d = _mla_layout(cfg)
+    heads = cfg["num_attention_heads"]
+    p = f"model.layers.{i}.self_attn."
+
+    def q_rows(w):                      # [heads * (n + r), in] -> [heads * d, in]
+        w = w.reshape(heads, n + r, -1)
+        z = torch.zeros(heads, d - n - r, w.shape[2], dtype=w.dtype)
+        return torch.cat([w[:, n:], w[:, :n], z], 1).reshape(heads * d, -1)
+
+    if cfg.get("q_lora_rank"):
+        out[f"L{i}.q_a"] = sd[p + "q_a_proj.weight"]
+        out[f"L{i}.q_a_norm"] = sd[p + "q_a_layernorm.weight"]
+        out[f"L{i}.q_b"] = q_rows(sd[p + "q_b_proj.weight"])
+    else:
+        out[f"L{i}.q"] = q_rows(sd[p + "q_proj.weight"])
+    out[f"L{i}.kv_a"] = sd[p + "kv_a_proj_with_mqa.weight"]
+    out[f"L{i}.kv_a_norm"] = sd[p + "kv_a_layernorm.weight"]
+    kvb = sd[p + "kv_b_proj.weight"].reshape(heads, n + vd, -1)
+    lora = kvb.shape[2]
+    k = torch.cat([torch.zeros(heads, r, lora, dtype=kvb.dtype), kvb[:, :n],
+                   torch.zeros(heads, d - r - n, lora, dtype=kvb.dtype)], 1)
+    v = torch.cat([kvb[:, n:], torch.zeros(heads, d - vd, lora, dtype=kvb.dtype)], 1)
+    out[f"L{i}.kv_b"] = torch.cat([k.reshape(heads * d, lora), v.reshape(heads * d, lora)], 0)
+    o = sd[p + "o_proj.weight"].reshape(-1, heads, vd) * o_scale
+    out[f"L{i}.o"] = torch.cat([o, torch.zeros(o.shape[0], heads, d - vd, dtype=o.dtype)], 2).reshape(o.shape[0], heads * d)
+
+
+def convert_minicpm3(cfg: dict, sd: StateDict):
+    """MiniCPM3-4B (reference models/minicpm3.py): MiniCPM's embedding / residual / logit scales plus multi-head
+    latent attention; rotate-half RoPE on the ``qk_rope_head_dim`` rotary channels, softmax scale
+    1 / sqrt(qk_nope + qk_rope)."""
+    dc = _probe_minicpm3(cfg)
+    rs = float(_get(cfg, "scale_depth", default=1.0)) / math.sqrt(dc.num_layers)
+    out = {"embed": sd["model.embed_tokens.weight"], "final_norm": sd["model.norm.weight"]}
+    out["lm_head"] = sd.get("lm_head.weight", out["embed"])
+    for i in range(dc.num_layers):
+        p = f"model.layers.{i}."
+        _mla_keys(cfg, sd, out, i, o_scale=rs)
+        out[f"L{i}.input_norm"] = sd[p + "input_layernorm.weight"]
+        out[f"L{i}.post_norm"] = sd[p + "post_attention_layernorm.weight"]
+        out[f"L{i}.gate"] = sd[p + "mlp.gate_proj.weight"]
+        out[f"L{i}.up"] = sd[p + "mlp.up_proj.weight"]
+        out[f"L{i}.down"] = sd[p + "mlp.down_proj.weight"] * rs
+    return dc, out
+
+
 def convert_llama_like(cfg: dict, sd: StateDict):
     """Aquila / Aquila2, Yi and other checkpoints that use llama's tensor names under another ``model_type``
     (reference models/aquila.py)."""
@@ -612,7 +671,7 @@ LN_CONFIGS = {"gpt_neox": _cfg_gpt_neox, "bloom": _cfg_bloom, "mpt": _cfg_mpt, "
 
 ARCH_CONVERTERS: Dict[str, Callable[[dict, StateDict], Tuple[DecoderConfig, StateDict]]] = {
     "chatglm": convert_chatglm, "baichuan": convert_baichuan, "qwen": convert_qwen, "internlm": convert_internlm,
-    "internlm2": convert_internlm2, "minicpm": convert_minicpm, "aquila": convert_llama_like, "yi": convert_llama_like,
+    "internlm2": convert_internlm2, "minicpm": convert_minicpm, "minicpm3": convert_minicpm3, "aquila": convert_llama_like, "yi": convert_llama_like,
     **LN_CONVERTERS,
 }
 
@@ -680,7 +739,17 @@ def reference_forward(dc: DecoderConfig, sd: StateDict, ids: torch.Tensor, past=
     new_past = []
     for i in range(dc.num_layers):
         x = norm(h, f"L{i}.input_norm")
-        qkv = lin(f"L{i}.qkv", x)
+        if dc.mla_kv_lora:
+            def rms(t, name):
+                return t * torch.rsqrt(t.pow(2).mean(-1, keepdim=True) + dc.rms_eps) * sd[name].float()
+            qh = lin(f"L{i}.q_b", rms(lin(f"L{i}.q_a", x), f"L{i}.q_a_norm")) if dc.mla_q_lora else lin(f"L{i}.q", x)
+            ckv = lin(f"L{i}.kv_a", x)
+            kvh = lin(f"L{i}.kv_b", rms(ckv[..., : dc.mla_kv_lora], f"L{i}.kv_a_norm"))
+            kh = kvh[..., : hq * d].reshape(b, s, hq, d).clone()
+            kh[..., :rot] = ckv[..., None, dc.mla_kv_lora:]          # the rotary key is shared by all heads
+            qkv = torch.cat([qh, kh.reshape(b, s, hq * d), kvh[..., hq * d:]], -1)
+        else:
+            qkv = lin(f"L{i}.qkv", x)
         q = qkv[..., : hq * d].view(b, s, hq, d).transpose(1, 2)
         k = qkv[..., hq * d:(hq + hkv) * d].view(b, s, hkv, d).transpose(1, 2)
         v = qkv[..., (hq + hkv) * d:].view(b, s, hkv, d).transpose(1, 2)
@@ -712,7 +781,7 @@ def reference_forward(dc: DecoderConfig, sd: StateDict, ids: torch.Tensor, past=
 # ------------------------------------------------------------------------------------------------
 # canonical form -> engine / CPU model
 # ------------------------------------------------------------------------------------------------
-LINEAR_SUFFIXES = (".qkv", ".o", ".gate", ".up", ".down")
+LINEAR_SUFFIXES = (".qkv", ".o", ".gate", ".up", ".down", ".q", ".q_a", ".q_b", ".kv_a", ".kv_b")
 
 
 def quantize_canonical(sd: StateDict, qtype: int, lm_head_qtype: Optional[int] = None):
@@ -746,7 +815,18 @@ def build_engine(dc: DecoderConfig, qsd: dict, device="cuda"):
     def vec(name):
         return qsd[name].to(dev, torch.float16).contiguous() if name in qsd else None
 
-    layers = [LayerWeights(input_norm=vec(f"L{i}.input_norm"), qkv=lin(f"L{i}.qkv"), o=lin(f"L{i}.o"),
+    def mla(i):
+        if not dc.mla_kv_lora:
+            return None
+        from .decoder import MLAWeights
+        has_a = f"L{i}.q_a" in qsd
+        return MLAWeights(kv_a=lin(f"L{i}.kv_a"), kv_a_norm=vec(f"L{i}.kv_a_norm"), kv_b=lin(f"L{i}.kv_b"),
+                          kv_lora=dc.mla_kv_lora, q=None if has_a else lin(f"L{i}.q"),
+                          q_a=lin(f"L{i}.q_a") if has_a else None, q_a_norm=vec(f"L{i}.q_a_norm"),
+                          q_b=lin(f"L{i}.q_b") if has_a else None)
+
+    layers = [LayerWeights(input_norm=vec(f"L{i}.input_norm"), qkv=None if dc.mla_kv_lora else lin(f"L{i}.qkv"),
+                           mla=mla(i), o=lin(f"L{i}.o"),
                            post_norm=vec(f"L{i}.post_norm"), gate=lin(f"L{i}.gate") if dc.gated_mlp else None,
                            up=lin(f"L{i}.up"), down=lin(f"L{i}.down"), input_norm_b=vec(f"L{i}.input_norm.bias"),
                            post_norm_b=vec(f"L{i}.post_norm.bias"), window=dc.sliding_window)
@@ -884,7 +964,7 @@ def arch_config_only(cfg: dict, padded: bool = False) -> DecoderConfig:
     if padded:
         return pad_head_dim(arch_config_only(cfg), {})[0] if _needs_pad(arch_config_only(cfg)) else arch_config_only(cfg)
     mt = cfg.get("model_type")
-    probe = {"chatglm": _probe_chatglm, "minicpm": _probe_minicpm}.get(mt)
+    probe = {"chatglm": _probe_chatglm, "minicpm": _probe_minicpm, "minicpm3": _probe_minicpm3}.get(mt)
     if probe is not None:
         return probe(cfg)
     if mt in LN_CONFIGS:
@@ -909,6 +989,17 @@ def _probe_chatglm(cfg):
                         head_dim=d, rot_dim=d // 2, rope_interleaved=True,
                         rope_theta=10000.0 * float(_get(cfg, "rope_ratio", default=1.0)),
                         intermediate_size=cfg["ffn_hidden_size"], vocab_size=_get(cfg, "padded_vocab_size", "vocab_size"))
+
+
+def _probe_minicpm3(cfg):
+    n, r, vd, d = _mla_layout(cfg)
+    heads = cfg["num_attention_heads"]
+    dc = _base_config(cfg, "minicpm3", tie_word_embeddings=True, num_kv_heads=heads, head_dim=d, rot_dim=r,
+                      attn_scale=1.0 / math.sqrt(n + r), mla_q_lora=int(cfg.get("q_lora_rank") or 0),
+                      mla_kv_lora=int(cfg["kv_lora_rank"]))
+    dc.embed_scale = float(_get(cfg, "scale_emb", default=1.0))
+    dc.logit_scale = float(_get(cfg, "dim_model_base", default=dc.hidden_size)) / dc.hidden_size
+    return dc
 
 
 def _probe_minicpm(cfg):

@@ -61,6 +61,9 @@ class DecoderConfig:
     pos_offset: int = 0               # opt: the position table starts at index 2
     post_norms: bool = False          # gemma2: extra norms after attention / mlp
     model_type: str = "llama"
+    # multi-head latent attention (MiniCPM3, DeepSeek-V2): kv_lora > 0 switches it on
+    mla_q_lora: int = 0               # 0: one q projection
+    mla_kv_lora: int = 0
     # MoE
     num_experts: int = 0
     top_k: int = 0
@@ -193,6 +196,26 @@ class Lin:
 
 
 @dataclass
+class MLAWeights:
+    """Projections of multi-head latent attention (reference models/minicpm3.py, deepseek.py): hidden -> q latent ->
+    q heads, hidden -> (kv latent | shared rotary key) -> k / v heads.  The engine expands the latent into ordinary
+    per-head K / V rows of ``head_dim`` channels laid out [rotary | no-position | zero padding] (values: [v | zero
+    padding]), so caches and attention kernels are the standard ones; ``q_b`` / ``kv_b`` rows are stored in that order
+    with zero rows at the padding and at the K rotary slots, which receive the shared rotary key."""
+    kv_a: "Lin"
+    kv_a_norm: torch.Tensor
+    kv_b: "Lin"
+    kv_lora: int
+    q: Optional["Lin"] = None
+    q_a: Optional["Lin"] = None
+    q_a_norm: Optional[torch.Tensor] = None
+    q_b: Optional["Lin"] = None
+
+    def lins(self):
+        return [l for l in (self.kv_a, self.kv_b, self.q, self.q_a, self.q_b) if l is not None]
+
+
+@dataclass
 class LayerWeights:
     input_norm: torch.Tensor
     qkv: Lin
@@ -208,6 +231,7 @@ class LayerWeights:
     window: int = 0
     input_norm_b: Optional[torch.Tensor] = None      # LayerNorm biases
     post_norm_b: Optional[torch.Tensor] = None
+    mla: Optional[MLAWeights] = None                 # latent attention: replaces qkv (which is then None)
 
 
 class KVCache:
@@ -433,7 +457,7 @@ class NativeDecoder:
         hq, hkv, d = cfg.num_heads, cfg.num_kv_heads, cfg.head_dim
         for li, lw in enumerate(self.layers):
             x = self._norm(h, lw.input_norm, lw.input_norm_b)
-            qkv = self._linear_dense(x, lw.qkv)
+            qkv = self._linear_dense(x, lw.qkv) if lw.mla is None else self._mla_qkv_dense(x, lw.mla)
             if nd:
                 # decode rows first: the idle slot's row appends a throw-away key at position 0 of the cache row
                 # that the prompt's keys are written to right after
@@ -506,6 +530,39 @@ class NativeDecoder:
         logits = self._linear_dense(x, self.lm_head).float().view(b, -1, cfg.vocab_size)
         return self._finish_logits(logits)
 
+    def _mla_qkv_dense(self, x, m: MLAWeights):
+        """prompt rows: normed hidden [rows, hidden] -> qkv [rows, 3 * heads * head_dim] (un-rotated)"""
+        from ..ops import hip
+        cfg = self.cfg
+        rows, qs, r = x.shape[0], cfg.q_size, cfg.rot_dim
+        qkv = torch.empty(rows, 3 * qs, dtype=torch.float16, device=self.device)
+        if m.q is not None:
+            qkv[:, :qs] = self._linear_dense(x, m.q)
+        else:
+            qa = hip.rms_norm(self._linear_dense(x, m.q_a), m.q_a_norm, cfg.rms_eps)
+            qkv[:, :qs] = self._linear_dense(qa, m.q_b)
+        ckv = self._linear_dense(x, m.kv_a)
+        kvn = hip.rms_norm(ckv[:, : m.kv_lora].contiguous(), m.kv_a_norm, cfg.rms_eps)
+        qkv[:, qs:] = self._linear_dense(kvn, m.kv_b)
+        # the rotary key is shared by all heads: it fills the first `rot_dim` channels of every K head
+        qkv[:, qs:2 * qs].view(rows, cfg.num_heads, cfg.head_dim)[:, :, :r] = ckv[:, None, m.kv_lora:]
+        return qkv
+
+    def _mla_qkv_decode(self, h, lw, st):
+        """the same inside the decode graph: four GEMVs (input norm and the latent norms folded into them) + the copy
+        of the shared rotary key"""
+        cfg, m = self.cfg, lw.mla
+        qkv, ckv, qs = st["qkv"], st["mla_ckv"], cfg.q_size
+        if m.q is not None:
+            self._gemv(h, m.q, qkv[:, :qs], gamma=lw.input_norm)
+        else:
+            self._gemv(h, m.q_a, st["mla_qa"], gamma=lw.input_norm)
+            self._gemv(st["mla_qa"], m.q_b, qkv[:, :qs], gamma=m.q_a_norm)
+        self._gemv(h, m.kv_a, ckv, gamma=lw.input_norm)
+        self._gemv(ckv[:, : m.kv_lora], m.kv_b, qkv[:, qs:], gamma=m.kv_a_norm)
+        qkv[:, qs:2 * qs].view(-1, cfg.num_heads, cfg.head_dim)[:, :, : cfg.rot_dim].copy_(
+            ckv[:, None, m.kv_lora:].expand(-1, cfg.num_heads, -1))
+
     def _decode_attention(self, qkv, li, lw, st, batch):
         """split-KV decode attention (+ RoPE and cache append) of one token per slot, outside the graph; qkv
         [batch, q + 2 kv] rows of a larger pass.  Returns [batch, q_size]."""
@@ -552,7 +609,7 @@ class NativeDecoder:
         rot = cfg.rot_dim or d
         for li, lw in enumerate(self.layers):
             x = self._norm(h, lw.input_norm, lw.input_norm_b)
-            qkv = self._linear_dense(x, lw.qkv).view(2, n, (hq + 2 * hkv) * d)
+            qkv = (self._linear_dense(x, lw.qkv) if lw.mla is None else self._mla_qkv_dense(x, lw.mla)).view(2, n, (hq + 2 * hkv) * d)
             kc, vc = cache.k[li], cache.v[li]
             for j, c in enumerate(chunks):      # RoPE at the chunk's global positions, K / V^T into the cache there
                 hip.prefill_rope_append(qkv[j:j + 1], kc, vc, self.rope_table, n_heads=hq, n_kv_heads=hkv, head_dim=d,
@@ -676,6 +733,9 @@ class NativeDecoder:
                                     device=dev),
             "splits": splits,
         }
+        if cfg.mla_kv_lora:
+            st["mla_ckv"] = torch.zeros(m, cfg.mla_kv_lora + cfg.rot_dim, dtype=torch.float16, device=dev)
+            st["mla_qa"] = torch.zeros(m, max(cfg.mla_q_lora, 8), dtype=torch.float16, device=dev)
         # with several KV splits the cross-split combine is folded into the o_proj GEMV's x staging
         g = cfg.num_heads // cfg.num_kv_heads
         rows = g * q_len
@@ -746,7 +806,9 @@ class NativeDecoder:
             pos = cache.past_len.to(torch.int64)[:, None] + torch.arange(q_len, device=self.device)[None]
             h.copy_(self._embed_extras(h, pos.reshape(-1)))
         for li, lw in enumerate(self.layers):
-            if layer_norm:
+            if lw.mla is not None:
+                self._mla_qkv_decode(h, lw, st)
+            elif layer_norm:
                 self._gemv(h, lw.qkv, qkv, gamma=lw.input_norm, beta=lw.input_norm_b)
             else:
                 self._gemv(h, lw.qkv, qkv, gamma=lw.input_norm)
@@ -924,6 +986,7 @@ class NativeDecoder:
     def dense_copy_bytes(self):
         """HBM an fp16 copy of every fused linear takes (what ``Lin.cache_dense`` keeps resident for the prompt GEMMs)"""
         lins = [self.lm_head] + [lin for lw in self.layers for lin in (lw.qkv, lw.o, lw.gate, lw.up, lw.down)]
+        lins += [lin for lw in self.layers if lw.mla is not None for lin in lw.mla.lins()]
         return sum(2 * lin.n * lin.k for lin in lins if lin is not None and lin.fused)
 
     def weight_bytes(self):
@@ -934,6 +997,8 @@ class NativeDecoder:
                     tot += lin.nbytes
             if lw.moe is not None:
                 tot += lw.moe.nbytes
+            if lw.mla is not None:
+                tot += sum(lin.nbytes for lin in lw.mla.lins())
         return tot
 
 

@@ -242,6 +242,8 @@ def shard_engine(engine, rank: int, world: int, group=None, fast_allreduce=None)
     assert cfg.num_heads % world == 0 and cfg.num_kv_heads % world == 0, "heads must divide the TP degree"
     q, kv = cfg.q_size, cfg.kv_size
     for lw in engine.layers:
+        if lw.mla is not None:
+            raise NotImplementedError("tensor-parallel sharding of latent-attention (MLA) layers")
         lw.qkv = _shard_lin(lw.qkv, rank, world, "column", parts=[q, kv, kv], unit=hd)
         lw.o = _shard_lin(lw.o, rank, world, "row")
         if lw.moe is not None:

@@ -62,6 +62,17 @@ FAMILIES = {
     "stablelm": lambda: _mk(T.StableLmConfig, T.StableLmForCausalLM, vocab_size=V, hidden_size=64, num_hidden_layers=2,
                             intermediate_size=128, num_attention_heads=4, num_key_value_heads=2, partial_rotary_factor=0.25,
                             max_position_embeddings=64, use_qkv_bias=True),
+    # multi-head latent attention (64 + 32 = 96 channels per head as in MiniCPM3-4B; without the q latent too)
+    "minicpm3": lambda: _mk(T.MiniCPM3Config, T.MiniCPM3ForCausalLM, vocab_size=V, hidden_size=64, num_hidden_layers=2,
+                            intermediate_size=128, num_attention_heads=4, num_key_value_heads=4, q_lora_rank=64,
+                            kv_lora_rank=64, qk_nope_head_dim=64, qk_rope_head_dim=32, v_head_dim=64,
+                            max_position_embeddings=64, scale_emb=3.0, scale_depth=1.4, dim_model_base=32,
+                            tie_word_embeddings=False),
+    "minicpm3_plain_q": lambda: _mk(T.MiniCPM3Config, T.MiniCPM3ForCausalLM, vocab_size=V, hidden_size=64,
+                                    num_hidden_layers=2, intermediate_size=128, num_attention_heads=4,
+                                    num_key_value_heads=4, q_lora_rank=None, kv_lora_rank=64, qk_nope_head_dim=32,
+                                    qk_rope_head_dim=16, v_head_dim=48, max_position_embeddings=64,
+                                    tie_word_embeddings=False),
     "gptj": lambda: _mk(T.GPTJConfig, T.GPTJForCausalLM, vocab_size=V, n_embd=64, n_layer=2, n_head=4, rotary_dim=8,
                         n_positions=64),
 }
