@@ -114,7 +114,10 @@ def layer_norm_forward(self, hidden_states):
             and self.weight is not None and hidden_states.dtype in (torch.float16, torch.bfloat16, torch.float32):
         from ..ops import hip
         return hip.layer_norm(hidden_states, self.weight, self.bias, self.eps)
-    return F.layer_norm(hidden_states, self.normalized_shape, self.weight, self.bias, self.eps)
+    w, b = self.weight, self.bias
+    if w is not None and w.dtype != hidden_states.dtype:       # half activations through a norm kept in fp32 (CPU)
+        w, b = w.to(hidden_states.dtype), None if b is None else b.to(hidden_states.dtype)
+    return F.layer_norm(hidden_states, self.normalized_shape, w, b, self.eps)
 
 
 def _act_name(mlp):

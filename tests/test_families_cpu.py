@@ -87,3 +87,35 @@ def test_bert_encoder_and_whisper_seq2seq():
         q = optimize_model(copy.deepcopy(wh), low_bit="sym_int8")
         out = q(input_features=feats, decoder_input_ids=dec).logits
     assert _rel(out, ref) < 0.05
+
+
+def test_vision_language_model_converts_every_tower():
+    """LLaVA-style wrapper (CLIP vision tower + projector + llama): the conversion reaches the language model through the
+    wrapper, quantizes tower and projector linears too, and image + text prompts give the logits of the fp32 model."""
+    from transformers import CLIPVisionConfig, LlamaConfig, LlavaConfig, LlavaForConditionalGeneration
+    from bigdl_amd.optimize import optimize_model
+    from bigdl_amd.transformers.low_bit_linear import LowBitLinear
+    torch.manual_seed(0)
+    vc = CLIPVisionConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4, image_size=28,
+                          patch_size=14, projection_dim=64)
+    tc = LlamaConfig(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=4,
+                     num_key_value_heads=2, max_position_embeddings=256)
+    cfg = LlavaConfig(vision_config=vc, text_config=tc, image_token_index=319, vision_feature_layer=-1,
+                      vision_feature_select_strategy="full")
+    m = LlavaForConditionalGeneration(cfg).eval()
+    n_img = (28 // 14) ** 2 + 1
+    ids = torch.cat([torch.tensor([[1, 5]]), torch.full((1, n_img), 319), torch.randint(2, 300, (1, 6))], 1)
+    px = torch.randn(1, 3, 28, 28)
+    with torch.no_grad():
+        want = m(input_ids=ids, pixel_values=px).logits[:, -1]
+    for low_bit, tol in (("sym_int8", 0.03), ("fp16", 0.01)):
+        import copy
+        q = optimize_model(copy.deepcopy(m), low_bit=low_bit)
+        parts = {".".join(n.split(".")[:2]) for n, mod in q.named_modules() if isinstance(mod, LowBitLinear) or
+                 type(mod).__name__ == "FP16Linear"}
+        assert {"lm_head", "model.language_model", "model.multi_modal_projector", "model.vision_tower"} <= parts, parts
+        with torch.no_grad():
+            got = q(input_ids=ids, pixel_values=px).logits[:, -1].float()      # the lm_head keeps the last position only
+        assert _rel(got, want) < tol, (low_bit, _rel(got, want))
+        out = q.generate(input_ids=ids, pixel_values=px, max_new_tokens=4, do_sample=False)
+        assert out.shape == (1, ids.shape[1] + 4)
