@@ -13,7 +13,10 @@ model), the same graph at 32 slots costs little more, so throughput scales with 
 slots (at most ``max_prefill_per_step`` per step, the reference's ``max_prefilled_seqs``), runs one decode step over
 all slots and returns the new token of every running request.  When sequences are running while a prompt is
 admitted, both go through one pass (``NativeDecoder.prefill(with_decode=True)``): the decode rows are appended to the
-prompt's rows, so the step costs one read of the weights instead of two.
+prompt's rows, so the step costs one read of the weights instead of two.  Prompts longer than ``max_prefill_tokens``
+are admitted in chunks of that many tokens, one chunk per step (the reference's partial prefill,
+python/llm/src/ipex_llm/transformers/pipeline_parallel.py:621-700), so a long prompt delays the running sequences by
+one chunk's time per token instead of stalling them for the whole prompt.
 """
 from __future__ import annotations
 
@@ -52,7 +55,8 @@ class ContinuousBatcher:
 
     def __init__(self, engine, max_num_seqs: int = 8, max_seq_len: int = 4096, kv_fp8: bool = False,
                  max_prefill_per_step: int = 1, on_token: Optional[Callable[[SeqRequest, int], None]] = None,
-                 piggyback: Optional[bool] = None, dense_prefill_cache: Optional[bool] = None):
+                 piggyback: Optional[bool] = None, dense_prefill_cache: Optional[bool] = None,
+                 max_prefill_tokens: Optional[int] = 4096):
         self.engine = engine
         self.max_num_seqs = max_num_seqs
         self.max_seq_len = max_seq_len
@@ -78,6 +82,10 @@ class ContinuousBatcher:
         # decode rows ride on the prompt pass of a newly admitted request (BIGDL_SERVING_PIGGYBACK=0 turns it off)
         self.piggyback = os.environ.get("BIGDL_SERVING_PIGGYBACK", "1") != "0" if piggyback is None else piggyback
         self.mixed_steps = 0
+        # prompts longer than this go through several passes (chunked prefill), so that the running sequences keep
+        # producing a token per pass instead of waiting for a whole long prompt; None / 0: one pass per prompt
+        self.max_prefill_tokens = max_prefill_tokens
+        self._prefilling = None                        # [request, tokens of its prompt already in the cache]
 
     # ------------------------------------------------------------------ queue
     def submit(self, req: SeqRequest) -> SeqRequest:
@@ -90,7 +98,7 @@ class ContinuousBatcher:
         return req
 
     def has_work(self) -> bool:
-        return bool(self.waiting or self.running)
+        return bool(self.waiting or self.running or self._prefilling)
 
     # ------------------------------------------------------------------ one iteration
     def _token_buffer(self):
@@ -128,7 +136,7 @@ class ContinuousBatcher:
         slot = self.free_slots.pop()
         req.slot = slot
         self.cache.set_active(slot, False)            # clears the slot's length counters
-        return slot, torch.tensor([req.input_ids], dtype=torch.int64, device=self.engine.device)
+        self._prefilling = [req, 0]
 
     def _started(self, req: SeqRequest, logits_row, tokens, out):
         tok = self._pick(req, logits_row)
@@ -137,42 +145,59 @@ class ContinuousBatcher:
         self.running[req.slot] = req
         self._emit(req, tok, time.perf_counter(), out)
 
-    def _advance(self, logits, nxt, tokens, out, skip=-1):
+    def _advance(self, logits, nxt, tokens, out):
         host = nxt.tolist()                           # one device sync per iteration
         now = time.perf_counter()
         for slot, req in list(self.running.items()):
-            if slot == skip:
-                continue
             tok = host[slot]
             if req.do_sample:
                 tok = self._pick(req, logits[slot])
                 tokens[slot, 0] = tok
             self._emit(req, tok, now, out)
 
+    def _prompt_pass(self, tokens, out, with_decode: bool) -> bool:
+        """The next chunk of the prompt being admitted (at most ``max_prefill_tokens`` tokens), optionally with the
+        decode rows of the running sequences on the same pass.  True when the prompt is complete."""
+        eng = self.engine
+        req, done = self._prefilling
+        n = len(req.input_ids) - done
+        if self.max_prefill_tokens:
+            n = min(n, self.max_prefill_tokens)
+        ids = torch.tensor([req.input_ids[done:done + n]], dtype=torch.int64, device=eng.device)
+        if with_decode:
+            first, logits, nxt = eng.prefill(ids, last_only=True, slot=req.slot, with_decode=True)
+            self._advance(logits, nxt, tokens, out)
+            self.mixed_steps += 1
+        else:
+            first = eng.prefill(ids, last_only=True, slot=req.slot)
+        self._prefilling[1] = done + n
+        if done + n < len(req.input_ids):
+            return False
+        self._prefilling = None
+        self._started(req, first[0, -1], tokens, out)
+        return True
+
     def step(self) -> Dict[str, int]:
         """Admit, decode once, return {request_id: new token}."""
         eng, out = self.engine, {}
         tokens = self._token_buffer()
         admitted = 0
-        if self.running and self.waiting and self.free_slots and self.piggyback:
-            # one pass for both: the running sequences' next token rides on the new prompt's GEMMs
-            req = self.waiting.popleft()
-            slot, ids = self._admit(req)
-            first, logits, nxt = eng.prefill(ids, last_only=True, slot=slot, with_decode=True)
-            self._advance(logits, nxt, tokens, out)
-            self._started(req, first[0, -1], tokens, out)
-            admitted = 1
-            self.mixed_steps += 1
-        elif self.running:
-            # the sequences that are already running advance by one token
-            logits, nxt = eng.decode(None, 1, chain=True)
-            self._advance(logits, nxt, tokens, out)
-        # then admit: prefill writes the prompt into the slot's cache rows and yields the slot's first token
-        while self.waiting and self.free_slots and admitted < self.max_prefill_per_step:
-            req = self.waiting.popleft()
-            slot, ids = self._admit(req)
-            self._started(req, eng.prefill(ids, last_only=True, slot=slot)[0, -1], tokens, out)
-            admitted += 1
+        if self._prefilling is None and self.waiting and self.free_slots:
+            self._admit(self.waiting.popleft())
+        if self._prefilling is not None and self.running and self.piggyback:
+            # one pass for both: the running sequences' next token rides on the prompt chunk's GEMMs
+            admitted += self._prompt_pass(tokens, out, with_decode=True)
+        else:
+            if self.running:
+                # the sequences that are already running advance by one token
+                logits, nxt = eng.decode(None, 1, chain=True)
+                self._advance(logits, nxt, tokens, out)
+            if self._prefilling is not None:
+                admitted += self._prompt_pass(tokens, out, with_decode=False)
+        # further admissions of this step: prompt passes of their own (whole prompts that fit one chunk)
+        while self._prefilling is None and self.waiting and self.free_slots and 0 < admitted < self.max_prefill_per_step:
+            self._admit(self.waiting.popleft())
+            admitted += self._prompt_pass(tokens, out, with_decode=False)
         self.steps += 1
         return out
 

@@ -41,10 +41,15 @@ class _FakeEngine:
         return lg
 
     mixed = 0
+    chunks = []
 
     def prefill(self, ids, last_only=True, slot=None, with_decode=False):
-        assert self.cache.slot_len[slot] == 0 and not self.cache.active_host[slot]
-        self.hist[slot] = ids[0].tolist()
+        assert not self.cache.active_host[slot]
+        if self.cache.slot_len[slot] == 0:
+            self.hist[slot] = []
+        assert len(self.hist[slot]) == self.cache.slot_len[slot]      # a later chunk continues where the last one ended
+        self.hist[slot] += ids[0].tolist()
+        self.chunks.append(ids.shape[1])
         self.cache.slot_len[slot] += ids.shape[1]
         first = self._logits(self.hist[slot])[None, None]
         if with_decode:                               # the running slots advance in the same pass
@@ -91,6 +96,19 @@ def test_piggyback_and_separate_passes_give_the_same_tokens():
         outs[on] = [r.output_ids for r in reqs]
         assert (eng.mixed > 0) == on and cb.mixed_steps == eng.mixed
     assert outs[True] == outs[False] == [_expected(p, 3 + i % 4) for i, p in enumerate(prompts)]
+
+
+def test_long_prompts_are_admitted_in_chunks():
+    prompts = [[i + 1, 2 * i + 3, 5] + [7] * (3 * i) for i in range(6)]      # 3 .. 18 tokens
+    for on in (True, False):
+        eng = _FakeEngine()
+        eng.chunks = []
+        cb = ContinuousBatcher(eng, max_num_seqs=3, max_seq_len=64, piggyback=on, max_prefill_tokens=4)
+        reqs = [cb.submit(SeqRequest(str(i), list(p), max_new_tokens=5)) for i, p in enumerate(prompts)]
+        cb.run_until_done()
+        assert [r.output_ids for r in reqs] == [_expected(p, 5) for p in prompts]
+        assert max(eng.chunks) == 4 and sum(eng.chunks) == sum(len(p) for p in prompts)
+        assert not cb.has_work() and sorted(cb.free_slots) == [0, 1, 2]
 
 
 def test_eos_frees_the_slot_and_callbacks_fire():

@@ -137,6 +137,30 @@ def test_continuous_batching_matches_per_request_generation():
     assert agree >= 0.8 * total, (want, got)
 
 
+def test_chunked_prompt_admission_matches_whole_prompt_admission():
+    """Prompts admitted 64 tokens per step (with the decode rows of the running slots on the same passes) end in the
+    same cache contents and first tokens as prompts admitted whole."""
+    from bigdl_amd.models import decoder as D
+    from bigdl_amd.serving.continuous import ContinuousBatcher, SeqRequest
+    cfg = D.DecoderConfig(vocab_size=512, hidden_size=256, intermediate_size=512, num_layers=3, num_heads=4, num_kv_heads=2,
+                          head_dim=64, max_position=1024)
+    eng = D.build_random_decoder(cfg, device="cuda", seed=3)
+    g = torch.Generator().manual_seed(0)
+    prompts = [torch.randint(3, 512, (n,), generator=g).tolist() for n in (200, 30, 333)]
+    res = {}
+    for chunk in (None, 64):
+        cb = ContinuousBatcher(eng, max_num_seqs=2, max_seq_len=512, max_prefill_tokens=chunk)
+        reqs = [cb.submit(SeqRequest(str(i), p, max_new_tokens=40 if i == 0 else 5)) for i, p in enumerate(prompts)]
+        cb.run_until_done()
+        res[chunk] = ([r.output_ids for r in reqs], cb.steps)
+        assert all(r.finish_reason == "length" for r in reqs)
+    assert res[64][1] > res[None][1]                          # more, shorter steps
+    whole, chunked = res[None][0], res[64][0]
+    assert [w[0] for w in whole] == [c[0] for c in chunked], (whole, chunked)
+    agree = sum(int(a == b) for w, c in zip(whole, chunked) for a, b in zip(w, c))
+    assert agree >= 0.8 * sum(len(w) for w in whole), (whole, chunked)      # fp16 summation order may flip a near-tie
+
+
 def test_int4_kv_cache_generation_tracks_fp16_cache():
     """Engine on the int4 cache: prompt pass, decode steps, a second prompt pass over the non-empty cache and slot
     mode all run; logits stay close to the fp16-cache engine and the cache takes a quarter of the memory + scales."""
