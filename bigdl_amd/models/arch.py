@@ -67,6 +67,11 @@ def _llama_keys(cfg: dict, sd: StateDict, dc: DecoderConfig, *, qkv: Optional[st
 def _base_config(cfg: dict, model_type: str, **over) -> DecoderConfig:
     heads = _get(cfg, "num_attention_heads", "n_head", "n_heads", default=over.get("num_heads"))
     hidden = _get(cfg, "hidden_size", "n_embd", "d_model", default=over.get("hidden_size"))
+    rp = cfg.get("rope_parameters") or {}          # transformers >= 5 writes theta / scaling into one dict
+    if rp and "rope_theta" not in cfg:
+        cfg = dict(cfg, rope_theta=rp.get("rope_theta", 10000.0))
+        if rp.get("rope_type", "default") != "default" and not cfg.get("rope_scaling"):
+            cfg["rope_scaling"] = {k: v for k, v in rp.items() if k != "rope_theta"}
     kw = dict(vocab_size=_get(cfg, "vocab_size", "padded_vocab_size"), hidden_size=hidden,
               intermediate_size=_get(cfg, "intermediate_size", "ffn_hidden_size", default=0),
               num_layers=_get(cfg, "num_hidden_layers", "num_layers", "n_layer"), num_heads=heads,
@@ -244,6 +249,59 @@ def convert_minicpm3(cfg: dict, sd: StateDict):
         out[f"L{i}.gate"] = sd[p + "mlp.gate_proj.weight"]
         out[f"L{i}.up"] = sd[p + "mlp.up_proj.weight"]
         out[f"L{i}.down"] = sd[p + "mlp.down_proj.weight"] * rs
+    return dc, out
+
+
+def _probe_deepseek_v2(cfg):
+    n, r, vd, d = _mla_layout(cfg)
+    heads = cfg["num_attention_heads"]
+    if _get(cfg, "topk_method", default="greedy") != "greedy" and (_get(cfg, "n_group", default=1) or 1) > 1:
+        raise NotImplementedError("group-limited expert routing (DeepSeek-V2 236B) has no engine map; use the module path")
+    scale = 1.0 / math.sqrt(n + r)
+    rs = _get(cfg, "rope_scaling") or cfg.get("rope_parameters") or {}
+    if rs.get("mscale_all_dim") and rs.get("factor", 1.0) > 1.0:      # yarn: the softmax scale carries mscale^2
+        ms = 0.1 * float(rs["mscale_all_dim"]) * math.log(float(rs["factor"])) + 1.0
+        scale *= ms * ms
+    return _base_config(cfg, "deepseek_v2", num_kv_heads=heads, head_dim=d, rot_dim=r, rope_interleaved=True,
+                        attn_scale=scale, mla_q_lora=int(cfg.get("q_lora_rank") or 0), mla_kv_lora=int(cfg["kv_lora_rank"]),
+                        num_experts=int(cfg["n_routed_experts"]), top_k=int(cfg["num_experts_per_tok"]),
+                        moe_intermediate_size=int(cfg["moe_intermediate_size"]), norm_topk_prob=False,
+                        shared_expert_intermediate_size=int(cfg["moe_intermediate_size"]) * int(cfg.get("n_shared_experts") or 0))
+
+
+def convert_deepseek_v2(cfg: dict, sd: StateDict):
+    """DeepSeek-V2-Lite class (reference models/deepseek.py ``deepseek_attention_forward`` / ``deepseek_moe_forward``):
+    latent attention with interleaved rotary pairs, dense MLP in the first ``first_k_dense_replace`` layers, then
+    routed experts (softmax scores, top-k without renormalization, ``routed_scaling_factor`` folded into the experts'
+    down projections) plus always-on shared experts.  Expert weights are taken stacked (``experts.gate_up_proj``) or
+    per expert (``experts.N.gate_proj``)."""
+    dc = _probe_deepseek_v2(cfg)
+    e, inter = dc.num_experts, dc.moe_intermediate_size
+    rsf = float(_get(cfg, "routed_scaling_factor", default=1.0))
+    out = {"embed": sd["model.embed_tokens.weight"], "final_norm": sd["model.norm.weight"]}
+    out["lm_head"] = sd.get("lm_head.weight", out["embed"])
+    for i in range(dc.num_layers):
+        p = f"model.layers.{i}."
+        _mla_keys(cfg, sd, out, i)
+        out[f"L{i}.input_norm"] = sd[p + "input_layernorm.weight"]
+        out[f"L{i}.post_norm"] = sd[p + "post_attention_layernorm.weight"]
+        if p + "mlp.gate.weight" not in sd:
+            for n in ("gate", "up", "down"):
+                out[f"L{i}.{n}"] = sd[p + f"mlp.{n}_proj.weight"]
+            continue
+        out[f"L{i}.router"] = sd[p + "mlp.gate.weight"]
+        if p + "mlp.experts.gate_up_proj" in sd:
+            gu = sd[p + "mlp.experts.gate_up_proj"]                     # [E, 2 I, H]
+            gate, up, down = gu[:, :inter], gu[:, inter:], sd[p + "mlp.experts.down_proj"]
+        else:
+            gate, up, down = (torch.stack([sd[p + f"mlp.experts.{j}.{n}_proj.weight"] for j in range(e)])
+                              for n in ("gate", "up", "down"))
+        out[f"L{i}.experts.gate"] = gate.reshape(e * inter, -1)
+        out[f"L{i}.experts.up"] = up.reshape(e * inter, -1)
+        out[f"L{i}.experts.down"] = (down * rsf).reshape(e * down.shape[1], -1)
+        if dc.shared_expert_intermediate_size:
+            for n in ("gate", "up", "down"):
+                out[f"L{i}.shared.{n}"] = sd[p + f"mlp.shared_experts.{n}_proj.weight"]
     return dc, out
 
 
@@ -671,7 +729,7 @@ LN_CONFIGS = {"gpt_neox": _cfg_gpt_neox, "bloom": _cfg_bloom, "mpt": _cfg_mpt, "
 
 ARCH_CONVERTERS: Dict[str, Callable[[dict, StateDict], Tuple[DecoderConfig, StateDict]]] = {
     "chatglm": convert_chatglm, "baichuan": convert_baichuan, "qwen": convert_qwen, "internlm": convert_internlm,
-    "internlm2": convert_internlm2, "minicpm": convert_minicpm, "minicpm3": convert_minicpm3, "aquila": convert_llama_like, "yi": convert_llama_like,
+    "internlm2": convert_internlm2, "minicpm": convert_minicpm, "minicpm3": convert_minicpm3, "deepseek_v2": convert_deepseek_v2, "aquila": convert_llama_like, "yi": convert_llama_like,
     **LN_CONVERTERS,
 }
 
@@ -702,10 +760,12 @@ _ACTS = {"silu": F.silu, "swish": F.silu, "gelu": F.gelu, "relu": F.relu,
 def reference_forward(dc: DecoderConfig, sd: StateDict, ids: torch.Tensor, past=None, linear=None):
     """Logits [B, S, V] (fp32) and the updated KV list.  ``linear(name, x)`` may replace the dense products (the CPU
     low-bit path plugs its quantized matmul in here); ``past`` is a list of (k, v) per layer."""
-    def lin(name, x):
+    def lin(name, x, rows=None):
+        """``rows`` = (first, count): the product with that row block of a stacked (per-expert) weight"""
         if linear is not None:
-            return linear(name, x)
-        y = x @ sd[name].float().t()
+            return linear(name, x) if rows is None else linear(name, x, rows)
+        w = sd[name] if rows is None else sd[name][rows[0]:rows[0] + rows[1]]
+        y = x @ w.float().t()
         b = sd.get(name + ".bias")
         return y if b is None else y + b.float()
 
@@ -716,6 +776,24 @@ def reference_forward(dc: DecoderConfig, sd: StateDict, ids: torch.Tensor, past=
         return x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + dc.rms_eps) * (w.float() + dc.norm_offset)
 
     def mlp(i, x):
+        if f"L{i}.router" in sd:
+            t = x.reshape(-1, x.shape[-1])
+            p = torch.softmax(t @ sd[f"L{i}.router"].float().t(), -1)
+            w, idx = torch.topk(p, dc.top_k, dim=-1)
+            if dc.norm_topk_prob:
+                w = w / w.sum(-1, keepdim=True)
+            e, inter, hd = dc.num_experts, dc.moe_intermediate_size, t.shape[-1]
+            y = torch.zeros_like(t)
+            for j in range(e):
+                tok, slot = torch.where(idx == j)
+                if tok.numel() == 0:
+                    continue
+                xe = t[tok]
+                a = act(lin(f"L{i}.experts.gate", xe, rows=(j * inter, inter))) * lin(f"L{i}.experts.up", xe, rows=(j * inter, inter))
+                y.index_add_(0, tok, lin(f"L{i}.experts.down", a, rows=(j * hd, hd)) * w[tok, slot, None])
+            if f"L{i}.shared.gate" in sd:
+                y = y + lin(f"L{i}.shared.down", act(lin(f"L{i}.shared.gate", t)) * lin(f"L{i}.shared.up", t))
+            return y.reshape(x.shape)
         if dc.gated_mlp:
             return lin(f"L{i}.down", act(lin(f"L{i}.gate", x)) * lin(f"L{i}.up", x))
         return lin(f"L{i}.down", act(lin(f"L{i}.up", x)))
@@ -825,10 +903,33 @@ def build_engine(dc: DecoderConfig, qsd: dict, device="cuda"):
                           q_a=lin(f"L{i}.q_a") if has_a else None, q_a_norm=vec(f"L{i}.q_a_norm"),
                           q_b=lin(f"L{i}.q_b") if has_a else None)
 
+    def moe(i):
+        if f"L{i}.router" not in qsd:
+            return None
+        from .moe import MoEWeights
+        e, inter, hid = dc.num_experts, dc.moe_intermediate_size, dc.hidden_size
+        ws, qt = [], None
+        for n, shape in (("gate", (e, inter, hid)), ("up", (e, inter, hid)), ("down", (e, hid, inter))):
+            w = qsd[f"L{i}.experts.{n}"]
+            if isinstance(w, FP4Params):
+                w = w.to(dev)
+                assert w.qlayout == "t16", "expert weights reach the device in the tiled layout"
+                ws.append(w.data)
+                qt = w.qtype
+            else:
+                ws.append(w.to(dev, torch.float16).view(shape).contiguous())
+                qt = Q.FP16
+        shared = tuple(lin(f"L{i}.shared.{n}") for n in ("gate", "up", "down")) if f"L{i}.shared.gate" in qsd else None
+        return MoEWeights(qsd[f"L{i}.router"].to(dev), ws[0], ws[1], ws[2], qt, e, dc.top_k, hid, inter, act=dc.act,
+                          normalize=dc.norm_topk_prob, shared=shared)
+
+    def opt_lin(name):
+        return lin(name) if name in qsd else None
+
     layers = [LayerWeights(input_norm=vec(f"L{i}.input_norm"), qkv=None if dc.mla_kv_lora else lin(f"L{i}.qkv"),
-                           mla=mla(i), o=lin(f"L{i}.o"),
-                           post_norm=vec(f"L{i}.post_norm"), gate=lin(f"L{i}.gate") if dc.gated_mlp else None,
-                           up=lin(f"L{i}.up"), down=lin(f"L{i}.down"), input_norm_b=vec(f"L{i}.input_norm.bias"),
+                           mla=mla(i), moe=moe(i), o=lin(f"L{i}.o"),
+                           post_norm=vec(f"L{i}.post_norm"), gate=opt_lin(f"L{i}.gate") if dc.gated_mlp else None,
+                           up=opt_lin(f"L{i}.up"), down=opt_lin(f"L{i}.down"), input_norm_b=vec(f"L{i}.input_norm.bias"),
                            post_norm_b=vec(f"L{i}.post_norm.bias"), window=dc.sliding_window)
               for i in range(dc.num_layers)]
     embed_norm = (vec("embed_norm"), vec("embed_norm.bias")) if "embed_norm" in qsd else None
@@ -879,9 +980,15 @@ class NativeCausalLM:
         return self
 
     # -- inference
-    def _cpu_linear(self, name, x):
+    def _cpu_linear(self, name, x, rows=None):
         from ..transformers.low_bit_linear import FP4Params, lowbit_matmul
         w = self.qsd[name]
+        if rows is not None:                               # one expert's block of a stacked weight
+            if isinstance(w, FP4Params):
+                from ..parallel.tensor_parallel import slice_param
+                w = slice_param(w, rows=(rows[0], rows[0] + rows[1]))
+            else:
+                w = w[rows[0]:rows[0] + rows[1]]
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])
         y = lowbit_matmul(x2, w, w._shape[0]) if isinstance(w, FP4Params) else x2 @ w.float().t()
@@ -964,7 +1071,7 @@ def arch_config_only(cfg: dict, padded: bool = False) -> DecoderConfig:
     if padded:
         return pad_head_dim(arch_config_only(cfg), {})[0] if _needs_pad(arch_config_only(cfg)) else arch_config_only(cfg)
     mt = cfg.get("model_type")
-    probe = {"chatglm": _probe_chatglm, "minicpm": _probe_minicpm, "minicpm3": _probe_minicpm3}.get(mt)
+    probe = {"chatglm": _probe_chatglm, "minicpm": _probe_minicpm, "minicpm3": _probe_minicpm3, "deepseek_v2": _probe_deepseek_v2}.get(mt)
     if probe is not None:
         return probe(cfg)
     if mt in LN_CONFIGS:

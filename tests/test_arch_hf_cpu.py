@@ -12,7 +12,8 @@ V = 96
 
 
 SCALE = 1      # the GPU test widens every family 4x (head_dim 64, which the attention kernels cover)
-_WIDTHS = ("hidden_size", "n_embd", "d_model", "intermediate_size", "ffn_dim", "word_embed_proj_dim", "rotary_dim")
+_WIDTHS = ("hidden_size", "n_embd", "d_model", "intermediate_size", "ffn_dim", "word_embed_proj_dim", "rotary_dim",
+           "moe_intermediate_size")
 
 
 def _mk(cfg_cls, model_cls, **kw):
@@ -73,6 +74,12 @@ FAMILIES = {
                                     num_key_value_heads=4, q_lora_rank=None, kv_lora_rank=64, qk_nope_head_dim=32,
                                     qk_rope_head_dim=16, v_head_dim=48, max_position_embeddings=64,
                                     tie_word_embeddings=False),
+    # latent attention with interleaved rotary pairs + routed / shared experts after one dense layer
+    "deepseek_v2": lambda: _mk(T.DeepseekV2Config, T.DeepseekV2ForCausalLM, vocab_size=V, hidden_size=64, num_hidden_layers=3,
+                               intermediate_size=128, moe_intermediate_size=64, num_attention_heads=4, num_key_value_heads=4,
+                               q_lora_rank=None, kv_lora_rank=64, qk_nope_head_dim=32, qk_rope_head_dim=32, v_head_dim=48,
+                               n_routed_experts=8, num_experts_per_tok=3, n_shared_experts=2, first_k_dense_replace=1,
+                               routed_scaling_factor=1.5, max_position_embeddings=64, tie_word_embeddings=False),
     "gptj": lambda: _mk(T.GPTJConfig, T.GPTJForCausalLM, vocab_size=V, n_embd=64, n_layer=2, n_head=4, rotary_dim=8,
                         n_positions=64),
 }
