@@ -147,3 +147,22 @@ def test_odd_head_dim_is_padded_to_a_kernel_size():
     got, _ = arch.reference_forward(pdc, pcanon, ids)
     torch.testing.assert_close(got, want, rtol=2e-4, atol=2e-4)
     assert arch.arch_config_only(cd, padded=True) == pdc
+
+
+def test_latent_attention_moe_checkpoint_round_trip(tmp_path):
+    """deepseek_v2 through the public API with the native map: low-bit conversion tracks the fp32 model, and the saved
+    low-bit checkpoint (latent projections, router, stacked experts, shared experts) loads back bit-identically."""
+    from ipex_llm.transformers import AutoModelForCausalLM
+    cfg, model = FAMILIES["deepseek_v2"]()
+    model.save_pretrained(str(tmp_path / "ckpt"), safe_serialization=True)
+    ids = torch.randint(0, V, (1, 9))
+    with torch.no_grad():
+        want = model(ids).logits
+    native = AutoModelForCausalLM.from_pretrained(str(tmp_path / "ckpt"), load_in_low_bit="sym_int8", native_engine=True)
+    assert isinstance(native, arch.NativeCausalLM) and native.dc.mla_kv_lora == 64 and native.dc.num_experts == 8
+    got, _ = native(ids)
+    assert ((got - want).abs().mean() / want.abs().mean()).item() < 0.05
+    native.save_low_bit(str(tmp_path / "lb"))
+    again = AutoModelForCausalLM.load_low_bit(str(tmp_path / "lb"))
+    assert again.dc == native.dc
+    assert torch.equal(again.generate(ids, max_new_tokens=3), native.generate(ids, max_new_tokens=3))
