@@ -216,12 +216,13 @@ def _mla_keys(cfg: dict, sd: StateDict, out: StateDict, i: int, o_scale: float =
         return torch.cat([w[:, n:], w[:, :n], z], 1).reshape(heads * d, -1)
 
     if cfg.get("q_lora_rank"):
-        out[f"L{i}.q_a"] = sd[p + "q_a_proj.weight"]
+        # both latent projections read the same rows: one stacked weight [q latent ; kv latent | rotary key]
+        out[f"L{i}.kv_a"] = torch.cat([sd[p + "q_a_proj.weight"], sd[p + "kv_a_proj_with_mqa.weight"]], 0)
         out[f"L{i}.q_a_norm"] = sd[p + "q_a_layernorm.weight"]
         out[f"L{i}.q_b"] = q_rows(sd[p + "q_b_proj.weight"])
     else:
         out[f"L{i}.q"] = q_rows(sd[p + "q_proj.weight"])
-    out[f"L{i}.kv_a"] = sd[p + "kv_a_proj_with_mqa.weight"]
+        out[f"L{i}.kv_a"] = sd[p + "kv_a_proj_with_mqa.weight"]
     out[f"L{i}.kv_a_norm"] = sd[p + "kv_a_layernorm.weight"]
     kvb = sd[p + "kv_b_proj.weight"].reshape(heads, n + vd, -1)
     lora = kvb.shape[2]
@@ -820,8 +821,12 @@ def reference_forward(dc: DecoderConfig, sd: StateDict, ids: torch.Tensor, past=
         if dc.mla_kv_lora:
             def rms(t, name):
                 return t * torch.rsqrt(t.pow(2).mean(-1, keepdim=True) + dc.rms_eps) * sd[name].float()
-            qh = lin(f"L{i}.q_b", rms(lin(f"L{i}.q_a", x), f"L{i}.q_a_norm")) if dc.mla_q_lora else lin(f"L{i}.q", x)
-            ckv = lin(f"L{i}.kv_a", x)
+            ckv = lin(f"L{i}.kv_a", x)                 # [q latent (if any) | kv latent | rotary key]
+            if dc.mla_q_lora:
+                qh = lin(f"L{i}.q_b", rms(ckv[..., : dc.mla_q_lora], f"L{i}.q_a_norm"))
+                ckv = ckv[..., dc.mla_q_lora:]
+            else:
+                qh = lin(f"L{i}.q", x)
             kvh = lin(f"L{i}.kv_b", rms(ckv[..., : dc.mla_kv_lora], f"L{i}.kv_a_norm"))
             kh = kvh[..., : hq * d].reshape(b, s, hq, d).clone()
             kh[..., :rot] = ckv[..., None, dc.mla_kv_lora:]          # the rotary key is shared by all heads
@@ -859,7 +864,7 @@ def reference_forward(dc: DecoderConfig, sd: StateDict, ids: torch.Tensor, past=
 # ------------------------------------------------------------------------------------------------
 # canonical form -> engine / CPU model
 # ------------------------------------------------------------------------------------------------
-LINEAR_SUFFIXES = (".qkv", ".o", ".gate", ".up", ".down", ".q", ".q_a", ".q_b", ".kv_a", ".kv_b")
+LINEAR_SUFFIXES = (".qkv", ".o", ".gate", ".up", ".down", ".q", ".q_b", ".kv_a", ".kv_b")
 
 
 def quantize_canonical(sd: StateDict, qtype: int, lm_head_qtype: Optional[int] = None):
@@ -897,11 +902,9 @@ def build_engine(dc: DecoderConfig, qsd: dict, device="cuda"):
         if not dc.mla_kv_lora:
             return None
         from .decoder import MLAWeights
-        has_a = f"L{i}.q_a" in qsd
-        return MLAWeights(kv_a=lin(f"L{i}.kv_a"), kv_a_norm=vec(f"L{i}.kv_a_norm"), kv_b=lin(f"L{i}.kv_b"),
-                          kv_lora=dc.mla_kv_lora, q=None if has_a else lin(f"L{i}.q"),
-                          q_a=lin(f"L{i}.q_a") if has_a else None, q_a_norm=vec(f"L{i}.q_a_norm"),
-                          q_b=lin(f"L{i}.q_b") if has_a else None)
+        return MLAWeights(a=lin(f"L{i}.kv_a"), kv_a_norm=vec(f"L{i}.kv_a_norm"), kv_b=lin(f"L{i}.kv_b"),
+                          kv_lora=dc.mla_kv_lora, q_lora=dc.mla_q_lora, q=None if dc.mla_q_lora else lin(f"L{i}.q"),
+                          q_a_norm=vec(f"L{i}.q_a_norm"), q_b=lin(f"L{i}.q_b") if dc.mla_q_lora else None)
 
     def moe(i):
         if f"L{i}.router" not in qsd:

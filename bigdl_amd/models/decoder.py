@@ -202,17 +202,17 @@ class MLAWeights:
     per-head K / V rows of ``head_dim`` channels laid out [rotary | no-position | zero padding] (values: [v | zero
     padding]), so caches and attention kernels are the standard ones; ``q_b`` / ``kv_b`` rows are stored in that order
     with zero rows at the padding and at the K rotary slots, which receive the shared rotary key."""
-    kv_a: "Lin"
+    a: "Lin"                 # hidden -> [q latent (q_lora, may be 0) | kv latent (kv_lora) | shared rotary key]: one GEMV
     kv_a_norm: torch.Tensor
     kv_b: "Lin"
     kv_lora: int
-    q: Optional["Lin"] = None
-    q_a: Optional["Lin"] = None
+    q_lora: int = 0
+    q: Optional["Lin"] = None            # without a q latent: hidden -> q heads
     q_a_norm: Optional[torch.Tensor] = None
     q_b: Optional["Lin"] = None
 
     def lins(self):
-        return [l for l in (self.kv_a, self.kv_b, self.q, self.q_a, self.q_b) if l is not None]
+        return [l for l in (self.a, self.kv_b, self.q, self.q_b) if l is not None]
 
 
 @dataclass
@@ -536,12 +536,12 @@ class NativeDecoder:
         cfg = self.cfg
         rows, qs, r = x.shape[0], cfg.q_size, cfg.rot_dim
         qkv = torch.empty(rows, 3 * qs, dtype=torch.float16, device=self.device)
+        lat = self._linear_dense(x, m.a)
+        ckv = lat[:, m.q_lora:]
         if m.q is not None:
             qkv[:, :qs] = self._linear_dense(x, m.q)
         else:
-            qa = hip.rms_norm(self._linear_dense(x, m.q_a), m.q_a_norm, cfg.rms_eps)
-            qkv[:, :qs] = self._linear_dense(qa, m.q_b)
-        ckv = self._linear_dense(x, m.kv_a)
+            qkv[:, :qs] = self._linear_dense(hip.rms_norm(lat[:, : m.q_lora].contiguous(), m.q_a_norm, cfg.rms_eps), m.q_b)
         kvn = hip.rms_norm(ckv[:, : m.kv_lora].contiguous(), m.kv_a_norm, cfg.rms_eps)
         qkv[:, qs:] = self._linear_dense(kvn, m.kv_b)
         # the rotary key is shared by all heads: it fills the first `rot_dim` channels of every K head
@@ -549,16 +549,16 @@ class NativeDecoder:
         return qkv
 
     def _mla_qkv_decode(self, h, lw, st):
-        """the same inside the decode graph: four GEMVs (input norm and the latent norms folded into them) + the copy
-        of the shared rotary key"""
+        """the same inside the decode graph: GEMVs (input norm and the latent norms folded into them) + the copy
+        of the shared rotary key (three GEMVs with a q latent: both latents come from one stacked weight)"""
         cfg, m = self.cfg, lw.mla
-        qkv, ckv, qs = st["qkv"], st["mla_ckv"], cfg.q_size
+        qkv, lat, qs = st["qkv"], st["mla_lat"], cfg.q_size
+        self._gemv(h, m.a, lat, gamma=lw.input_norm)
+        ckv = lat[:, m.q_lora:]
         if m.q is not None:
             self._gemv(h, m.q, qkv[:, :qs], gamma=lw.input_norm)
         else:
-            self._gemv(h, m.q_a, st["mla_qa"], gamma=lw.input_norm)
-            self._gemv(st["mla_qa"], m.q_b, qkv[:, :qs], gamma=m.q_a_norm)
-        self._gemv(h, m.kv_a, ckv, gamma=lw.input_norm)
+            self._gemv(lat[:, : m.q_lora], m.q_b, qkv[:, :qs], gamma=m.q_a_norm)
         self._gemv(ckv[:, : m.kv_lora], m.kv_b, qkv[:, qs:], gamma=m.kv_a_norm)
         qkv[:, qs:2 * qs].view(-1, cfg.num_heads, cfg.head_dim)[:, :, : cfg.rot_dim].copy_(
             ckv[:, None, m.kv_lora:].expand(-1, cfg.num_heads, -1))
@@ -734,8 +734,7 @@ class NativeDecoder:
             "splits": splits,
         }
         if cfg.mla_kv_lora:
-            st["mla_ckv"] = torch.zeros(m, cfg.mla_kv_lora + cfg.rot_dim, dtype=torch.float16, device=dev)
-            st["mla_qa"] = torch.zeros(m, max(cfg.mla_q_lora, 8), dtype=torch.float16, device=dev)
+            st["mla_lat"] = torch.zeros(m, cfg.mla_q_lora + cfg.mla_kv_lora + cfg.rot_dim, dtype=torch.float16, device=dev)
         # with several KV splits the cross-split combine is folded into the o_proj GEMV's x staging
         g = cfg.num_heads // cfg.num_kv_heads
         rows = g * q_len
@@ -1074,8 +1073,17 @@ def build_random_decoder(cfg: DecoderConfig, qtype: int = Q.SYM_INT4, device="cu
     embed = (torch.randn(cfg.vocab_size, h, device=dev, generator=gen) * 0.02).to(torch.float16)
     layers = []
     for _ in range(cfg.num_layers):
-        lw = LayerWeights(input_norm=norm(), qkv=blin(cfg.q_size + 2 * cfg.kv_size, h), o=blin(h, cfg.q_size),
-                          post_norm=norm(), input_norm_b=vec(h), post_norm_b=vec(h))
+        if cfg.mla_kv_lora:
+            # latent attention: the padding rows of q_b / kv_b are random here instead of zero (same cost, timing only)
+            lat, ql, r = cfg.mla_kv_lora, cfg.mla_q_lora, cfg.rot_dim
+            ones = lambda n: (1.0 + 0.02 * torch.randn(n, device=dev, generator=gen)).to(torch.float16)   # noqa: E731
+            mla = MLAWeights(a=lin(ql + lat + r, h), kv_a_norm=ones(lat), kv_b=lin(2 * cfg.q_size, lat), kv_lora=lat,
+                             q_lora=ql, q=None if ql else lin(cfg.q_size, h), q_a_norm=ones(ql) if ql else None,
+                             q_b=lin(cfg.q_size, ql) if ql else None)
+            lw = LayerWeights(input_norm=norm(), qkv=None, mla=mla, o=lin(h, cfg.q_size), post_norm=norm())
+        else:
+            lw = LayerWeights(input_norm=norm(), qkv=blin(cfg.q_size + 2 * cfg.kv_size, h), o=blin(h, cfg.q_size),
+                              post_norm=norm(), input_norm_b=vec(h), post_norm_b=vec(h))
         if layer_norm and not cfg.gated_mlp:
             lw.up, lw.down = blin(i, h), blin(h, i)
             layers.append(lw)
@@ -1089,13 +1097,15 @@ def build_random_decoder(cfg: DecoderConfig, qtype: int = Q.SYM_INT4, device="cu
             if cfg.shared_expert_intermediate_size:
                 si = cfg.shared_expert_intermediate_size
                 shared = (lin(si, h), lin(si, h), lin(h, si))
-                shared_router = torch.randn(1, h, device=dev, generator=gen) / math.sqrt(h)
+                if cfg.model_type != "deepseek_v2":          # qwen2-moe gates its shared expert, deepseek adds it as is
+                    shared_router = torch.randn(1, h, device=dev, generator=gen) / math.sqrt(h)
             lw.moe = MoEWeights(
                 torch.randn(e, h, device=dev, generator=gen) / math.sqrt(h),
                 _random_t16(e * mi, h, qtype, dev, gen, scale=1.0 / math.sqrt(h)).data,
                 _random_t16(e * mi, h, qtype, dev, gen, scale=1.0 / math.sqrt(h)).data,
                 _random_t16(e * h, mi, qtype, dev, gen, scale=1.0 / math.sqrt(mi)).data,
-                qtype, e, cfg.top_k, h, mi, act=cfg.act, shared=shared, shared_router=shared_router)
+                qtype, e, cfg.top_k, h, mi, act=cfg.act, normalize=cfg.norm_topk_prob, shared=shared,
+                shared_router=shared_router)
         else:
             lw.gate, lw.up, lw.down = lin(i, h), lin(i, h), lin(h, i)
         layers.append(lw)
@@ -1114,6 +1124,16 @@ LLAMA2_7B = dict(vocab_size=32000, hidden_size=4096, intermediate_size=11008, nu
                  num_kv_heads=32, head_dim=128, rms_eps=1e-5, max_position=4096, model_type="llama")
 TINY_LLAMA = dict(vocab_size=32000, hidden_size=2048, intermediate_size=5632, num_layers=22, num_heads=32,
                   num_kv_heads=4, head_dim=64, rms_eps=1e-5, max_position=2048, model_type="llama")
+# MiniCPM3-4B: latent attention, 64 + 32 = 96 channels per head, values 64 wide (padded to 96)
+MINICPM3_4B = dict(vocab_size=73448, hidden_size=2560, intermediate_size=6400, num_layers=62, num_heads=40, num_kv_heads=40,
+                   head_dim=96, rot_dim=32, rms_eps=1e-5, max_position=32768, model_type="minicpm3", mla_q_lora=768,
+                   mla_kv_lora=256, attn_scale=96 ** -0.5, embed_scale=12.0, logit_scale=256 / 2560,
+                   tie_word_embeddings=True)
+# DeepSeek-V2-Lite: latent attention (128 + 64 -> 256-channel heads) + 64 routed experts (top 6) + 2 shared
+DEEPSEEK_V2_LITE = dict(vocab_size=102400, hidden_size=2048, intermediate_size=10944, num_layers=27, num_heads=16,
+                        num_kv_heads=16, head_dim=256, rot_dim=64, rope_interleaved=True, rms_eps=1e-6, max_position=32768,
+                        model_type="deepseek_v2", mla_kv_lora=512, attn_scale=192 ** -0.5, num_experts=64, top_k=6,
+                        moe_intermediate_size=1408, shared_expert_intermediate_size=2816, norm_topk_prob=False)
 BLOOM_7B = dict(vocab_size=250880, hidden_size=4096, intermediate_size=16384, num_layers=30, num_heads=32, num_kv_heads=32,
                 head_dim=128, rms_eps=1e-5, max_position=2048, model_type="bloom", norm="layer", gated_mlp=False,
                 act="gelu_tanh", alibi=True, tie_word_embeddings=True)
