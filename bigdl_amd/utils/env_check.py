@@ -26,7 +26,10 @@ def collect() -> dict:
     info["hip_library"] = str(hip._LIB_PATH) if hip._LIB_PATH.exists() else "not built"
     info["hipcc"] = shutil.which("hipcc") or "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else None
     for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "MASTER_ADDR", "WORLD_SIZE", "IPEX_LLM_QUANTIZE_KV_CACHE",
-              "IPEX_LLM_COMPRESS_KV_CACHE", "IPEX_LLM_PERFORMANCE_MODE", "IPEX_LLM_LOW_MEM", "IPEX_LLM_LAST_LM_HEAD"):
+              "IPEX_LLM_COMPRESS_KV_CACHE", "IPEX_LLM_PERFORMANCE_MODE", "IPEX_LLM_LOW_MEM", "IPEX_LLM_LAST_LM_HEAD",
+              "IPEX_LLM_NOT_USE_VLLM", "IPEX_LLM_FASTAPI_TIMEOUT", "RANK_WAIT_TIME", "KV_CACHE_ALLOC_BLOCK_LENGTH",
+              "BIGDL_LLM_LINEAR_THRESHOLD", "BIGDL_NATIVE_ENGINE", "BIGDL_KV_CACHE_INT4", "BIGDL_PREFILL_DENSE_CACHE",
+              "BIGDL_SERVING_PIGGYBACK", "BIGDL_XGMI_ALLREDUCE", "BIGDL_HIP_ATTENTION", "BIGDL_MOE_GROUPED_GEMM"):
         if k in os.environ:
             info.setdefault("env", {})[k] = os.environ[k]
     if shutil.which("rocm-smi"):
