@@ -11,7 +11,8 @@ import time
 import torch
 
 from bigdl_amd import qtypes as Q
-from bigdl_amd.models.decoder import LLAMA2_7B, TINY_LLAMA, DecoderConfig, build_random_decoder
+from bigdl_amd.models import decoder as D
+from bigdl_amd.models.decoder import DecoderConfig, build_random_decoder
 from bigdl_amd.serving.continuous import ContinuousBatcher, SeqRequest
 
 
@@ -24,7 +25,8 @@ def main():
     ap.add_argument("--model", default="llama2-7b")
     ap.add_argument("--kv", default="fp8")
     args = ap.parse_args()
-    cfg = DecoderConfig(**(LLAMA2_7B if args.model == "llama2-7b" else TINY_LLAMA))
+    cfg = DecoderConfig(**getattr(D, {"llama2-7b": "LLAMA2_7B", "tinyllama": "TINY_LLAMA"}.get(args.model, args.model)))
+    # --model also takes the name of any shape constant of models/decoder.py (LLAMA3_8B, QWEN2_7B, ...)
     eng = build_random_decoder(cfg, Q.SYM_INT4, device="cuda", seed=1)
     g = torch.Generator().manual_seed(0)
     for slots in [int(s) for s in args.slots.split(",")]:

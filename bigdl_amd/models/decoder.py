@@ -1122,6 +1122,10 @@ MIXTRAL_8X7B = dict(vocab_size=32000, hidden_size=4096, intermediate_size=14336,
                     num_experts=8, top_k=2, moe_intermediate_size=14336)
 LLAMA2_7B = dict(vocab_size=32000, hidden_size=4096, intermediate_size=11008, num_layers=32, num_heads=32,
                  num_kv_heads=32, head_dim=128, rms_eps=1e-5, max_position=4096, model_type="llama")
+LLAMA3_8B = dict(vocab_size=128256, hidden_size=4096, intermediate_size=14336, num_layers=32, num_heads=32,
+                 num_kv_heads=8, head_dim=128, rms_eps=1e-5, max_position=8192, rope_theta=500000.0, model_type="llama")
+QWEN2_7B = dict(vocab_size=152064, hidden_size=3584, intermediate_size=18944, num_layers=28, num_heads=28,
+                num_kv_heads=4, head_dim=128, rms_eps=1e-6, max_position=32768, rope_theta=1e6, model_type="qwen2")
 TINY_LLAMA = dict(vocab_size=32000, hidden_size=2048, intermediate_size=5632, num_layers=22, num_heads=32,
                   num_kv_heads=4, head_dim=64, rms_eps=1e-5, max_position=2048, model_type="llama")
 # MiniCPM3-4B: latent attention, 64 + 32 = 96 channels per head, values 64 wide (padded to 96)
