@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--requests-per-slot", type=int, default=2)
     ap.add_argument("--model", default="llama2-7b")
     ap.add_argument("--kv", default="fp8")
+    ap.add_argument("--prefill-per-step", type=int, default=8, help="prompts admitted per step (packed into one pass)")
     args = ap.parse_args()
     cfg = DecoderConfig(**getattr(D, {"llama2-7b": "LLAMA2_7B", "tinyllama": "TINY_LLAMA"}.get(args.model, args.model)))
     # --model also takes the name of any shape constant of models/decoder.py (LLAMA3_8B, QWEN2_7B, ...)
@@ -32,7 +33,7 @@ def main():
     for slots in [int(s) for s in args.slots.split(",")]:
         n_req = slots * args.requests_per_slot
         cb = ContinuousBatcher(eng, max_num_seqs=slots, max_seq_len=args.in_len + args.out_len + 1, kv_fp8={"fp8": True, "fp16": False, "int4": "int4"}[args.kv],
-                               max_prefill_per_step=1)
+                               max_prefill_per_step=args.prefill_per_step)
         # warm-up: graph capture + one short request
         cb.submit(SeqRequest("w", torch.randint(3, cfg.vocab_size, (64,), generator=g).tolist(), max_new_tokens=4))
         cb.run_until_done()

@@ -530,6 +530,72 @@ class NativeDecoder:
         logits = self._linear_dense(x, self.lm_head).float().view(b, -1, cfg.vocab_size)
         return self._finish_logits(logits)
 
+    @torch.no_grad()
+    def prefill_packed(self, prompts, slots):
+        """Several whole prompts (lists of token ids) into empty cache slots in ONE pass: norms, projections and the MLP
+        run over the concatenated rows (one read of the weights for all prompts, what short chat prompts need: a
+        32-token prompt alone costs 6 ms on a 7B model, mostly weight traffic), attention and the cache append run per
+        prompt.  Returns the last-position logits [len(prompts), V].  The reference batches the prompt phase of
+        several requests the same way (``max_prefilled_seqs``,
+        python/llm/src/ipex_llm/transformers/pipeline_parallel.py:807-927)."""
+        from ..ops import hip
+        cfg, cache = self.cfg, self.cache
+        assert cache.slot_len is not None and len(prompts) == len(slots) > 0
+        lens = [len(p) for p in prompts]
+        assert all(cache.slot_len[sl] == 0 and not cache.active_host[sl] for sl in slots), "packed prompts go to empty slots"
+        assert max(lens) <= cache.capacity, "KV cache capacity exceeded"
+        offs = [0]
+        for n in lens:
+            offs.append(offs[-1] + n)
+        ids = torch.tensor([t for p in prompts for t in p], dtype=torch.int64, device=self.device)
+        h = F.embedding(ids, self.embed).to(torch.float16)
+        if cfg.embed_scale != 1.0:
+            h = h * cfg.embed_scale
+        pos = torch.cat([torch.arange(n, device=self.device) for n in lens])
+        h = self._embed_extras(h, pos)
+        hq, hkv, d = cfg.num_heads, cfg.num_kv_heads, cfg.head_dim
+        rot = cfg.rot_dim or d
+        for li, lw in enumerate(self.layers):
+            x = self._norm(h, lw.input_norm, lw.input_norm_b)
+            qkv_all = self._linear_dense(x, lw.qkv) if lw.mla is None else self._mla_qkv_dense(x, lw.mla)
+            parts = []
+            for j, slot in enumerate(slots):
+                s = lens[j]
+                qkv = qkv_all[offs[j]:offs[j + 1]].view(1, s, (hq + 2 * hkv) * d)
+                kc, vc = cache.k[li][slot:slot + 1], cache.v[li][slot:slot + 1]
+                scratch = self._vt_scratch(1, hkv, d, s) if cache.quantized else None
+                if cache.int4:
+                    hip.prefill_rope_append(qkv, None, None, self.rope_table, n_heads=hq, n_kv_heads=hkv, head_dim=d,
+                                            past=0, rot_dim=rot, interleaved=cfg.rope_interleaved, vt_scratch=scratch)
+                    hip.kv_int4_append(qkv, kc, vc, cache.k_scale[li][slot:slot + 1], cache.v_scale[li][slot:slot + 1],
+                                       n_heads=hq, n_kv_heads=hkv, head_dim=d, past=0)
+                else:
+                    hip.prefill_rope_append(qkv, kc, vc, self.rope_table, n_heads=hq, n_kv_heads=hkv, head_dim=d, past=0,
+                                            rot_dim=rot, interleaved=cfg.rope_interleaved, vt_scratch=scratch)
+                q = qkv[..., : hq * d].view(1, s, hq, d).transpose(1, 2)
+                k = qkv[..., hq * d: (hq + hkv) * d].view(1, s, hkv, d).transpose(1, 2)
+                vt = scratch[..., :s] if scratch is not None else vc[:, :, :, :s]
+                parts.append(self._sdpa(q, k, vt, 0, lw.window).reshape(s, hq * d))
+            o = self._tp_reduce(self._linear_dense(torch.cat(parts), lw.o))
+            if lw.post_attn_out_norm is not None:
+                o = self._norm(o, lw.post_attn_out_norm)
+            if cfg.parallel_residual:
+                x2 = x if lw.post_norm is None else self._norm(h, lw.post_norm, lw.post_norm_b)
+                h = h + o + self._mlp_dense(x2, lw)
+                continue
+            h = h + o
+            x = self._norm(h, lw.pre_ffn_norm if lw.pre_ffn_norm is not None else lw.post_norm, lw.post_norm_b)
+            m = lw.moe.forward_dense(x, self) if lw.moe is not None else self._mlp_dense(x, lw)
+            if lw.post_ffn_out_norm is not None:
+                m = self._norm(m, lw.post_ffn_out_norm)
+            h = h + m
+        for j, slot in enumerate(slots):
+            cache.past_len[slot] += lens[j]
+            cache.slot_len[slot] += lens[j]
+        last = torch.tensor([o - 1 for o in offs[1:]], device=self.device)
+        x = self._norm(h[last], self.final_norm, self.final_norm_b)
+        return self._finish_logits(self._linear_dense(x, self.lm_head).float())
+
     def _mla_qkv_dense(self, x, m: MLAWeights):
         """prompt rows: normed hidden [rows, hidden] -> qkv [rows, 3 * heads * head_dim] (un-rotated)"""
         from ..ops import hip

@@ -54,7 +54,7 @@ class ContinuousBatcher:
     """Iteration-level scheduler over ``max_num_seqs`` cache slots of one ``NativeDecoder``."""
 
     def __init__(self, engine, max_num_seqs: int = 8, max_seq_len: int = 4096, kv_fp8: bool = False,
-                 max_prefill_per_step: int = 1, on_token: Optional[Callable[[SeqRequest, int], None]] = None,
+                 max_prefill_per_step: int = 8, on_token: Optional[Callable[[SeqRequest, int], None]] = None,
                  piggyback: Optional[bool] = None, dense_prefill_cache: Optional[bool] = None,
                  max_prefill_tokens: Optional[int] = 4096):
         self.engine = engine
@@ -82,6 +82,7 @@ class ContinuousBatcher:
         # decode rows ride on the prompt pass of a newly admitted request (BIGDL_SERVING_PIGGYBACK=0 turns it off)
         self.piggyback = os.environ.get("BIGDL_SERVING_PIGGYBACK", "1") != "0" if piggyback is None else piggyback
         self.mixed_steps = 0
+        self.packed_prompts = 0
         # prompts longer than this go through several passes (chunked prefill), so that the running sequences keep
         # producing a token per pass instead of waiting for a whole long prompt; None / 0: one pass per prompt
         self.max_prefill_tokens = max_prefill_tokens
@@ -194,10 +195,28 @@ class ContinuousBatcher:
                 self._advance(logits, nxt, tokens, out)
             if self._prefilling is not None:
                 admitted += self._prompt_pass(tokens, out, with_decode=False)
-        # further admissions of this step: prompt passes of their own (whole prompts that fit one chunk)
-        while self._prefilling is None and self.waiting and self.free_slots and 0 < admitted < self.max_prefill_per_step:
-            self._admit(self.waiting.popleft())
+        # further admissions of this step: whole prompts, packed into one pass (one read of the weights for all of
+        # them) while they fit the token budget of a pass
+        batch, budget = [], self.max_prefill_tokens or (1 << 30)
+        while self._prefilling is None and self.waiting and len(self.free_slots) > len(batch) \
+                and 0 < admitted + len(batch) < self.max_prefill_per_step and hasattr(eng, "prefill_packed"):
+            n = len(self.waiting[0].input_ids)
+            if n > budget:
+                break
+            budget -= n
+            batch.append(self.waiting.popleft())
+        if len(batch) == 1:
+            self._admit(batch[0])
             admitted += self._prompt_pass(tokens, out, with_decode=False)
+        elif batch:
+            for req in batch:
+                req.slot = self.free_slots.pop()
+                self.cache.set_active(req.slot, False)
+            logits = eng.prefill_packed([r.input_ids for r in batch], [r.slot for r in batch])
+            for j, req in enumerate(batch):
+                self._started(req, logits[j], tokens, out)
+            admitted += len(batch)
+            self.packed_prompts += len(batch)
         self.steps += 1
         return out
 

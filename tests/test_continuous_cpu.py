@@ -57,6 +57,12 @@ class _FakeEngine:
             return (first,) + self.decode(None, 1, chain=True)
         return first
 
+    packed = 0
+
+    def prefill_packed(self, prompts, slots):
+        self.packed += len(prompts)
+        return torch.stack([self.prefill(torch.tensor([p]), slot=s)[0, 0] for p, s in zip(prompts, slots)])
+
     def decode(self, tokens, q_len=1, chain=False):
         lg = torch.zeros(self.cache.batch, self.vocab)
         for s in range(self.cache.batch):
@@ -96,6 +102,18 @@ def test_piggyback_and_separate_passes_give_the_same_tokens():
         outs[on] = [r.output_ids for r in reqs]
         assert (eng.mixed > 0) == on and cb.mixed_steps == eng.mixed
     assert outs[True] == outs[False] == [_expected(p, 3 + i % 4) for i, p in enumerate(prompts)]
+
+
+def test_waiting_prompts_are_packed_into_one_pass():
+    prompts = [[i + 1, 2 * i + 3, 5] + [7] * i for i in range(9)]
+    eng = _FakeEngine()
+    cb = ContinuousBatcher(eng, max_num_seqs=4, max_seq_len=64, max_prefill_per_step=4, max_prefill_tokens=16)
+    reqs = [cb.submit(SeqRequest(str(i), list(p), max_new_tokens=4)) for i, p in enumerate(prompts)]
+    cb.step()                                         # nothing runs yet: one prompt pass + a packed pass for the rest
+    assert len(cb.running) == 4 and eng.packed == 3 and cb.packed_prompts == 3
+    cb.run_until_done()
+    assert [r.output_ids for r in reqs] == [_expected(p, 4) for p in prompts]
+    assert not cb.has_work() and sorted(cb.free_slots) == [0, 1, 2, 3]
 
 
 def test_long_prompts_are_admitted_in_chunks():
