@@ -161,6 +161,35 @@ def test_chunked_prompt_admission_matches_whole_prompt_admission():
     assert agree >= 0.8 * sum(len(w) for w in whole), (whole, chunked)      # fp16 summation order may flip a near-tie
 
 
+@pytest.mark.parametrize("mode", [False, True, "int4"])
+def test_packed_prompt_pass_matches_one_prompt_per_pass(mode):
+    """prefill_packed: three prompts of different lengths in one pass give the logits and cache rows of three passes."""
+    from bigdl_amd.models import decoder as D
+    cfg = D.DecoderConfig(vocab_size=512, hidden_size=256, intermediate_size=512, num_layers=3, num_heads=4, num_kv_heads=2,
+                          head_dim=128 if mode == "int4" else 64, max_position=1024)
+    eng = D.build_random_decoder(cfg, device="cuda", seed=3)
+    g = torch.Generator().manual_seed(0)
+    prompts = [torch.randint(3, 512, (n,), generator=g).tolist() for n in (70, 9, 200)]
+    slots = [2, 0, 3]
+    cache = eng.ensure_cache(4, 512, fp8=mode)
+    cache.reset()
+    cache.enable_slots()
+    want = torch.cat([eng.prefill(torch.tensor([p]).cuda(), slot=s)[:, -1] for p, s in zip(prompts, slots)])
+    k_ref, lens_ref = cache.k[1].clone(), list(cache.slot_len)
+    cache.reset()
+    cache.enable_slots()
+    for t in cache.k + cache.v:
+        t.zero_()
+    got = eng.prefill_packed(prompts, slots)
+    rel = ((got - want).abs().mean() / want.abs().mean()).item()
+    assert rel < 5e-3, rel
+    assert list(cache.slot_len) == lens_ref == [9, 0, 70, 200] and cache.past_len.tolist() == lens_ref
+    if mode:          # quantized codes: a rounding flips here and there (the row count picks another GEMM kernel)
+        assert (cache.k[1] != k_ref).float().mean().item() < 0.03
+    else:
+        torch.testing.assert_close(cache.k[1].float(), k_ref.float(), rtol=2e-2, atol=2e-2)
+
+
 def test_int4_kv_cache_generation_tracks_fp16_cache():
     """Engine on the int4 cache: prompt pass, decode steps, a second prompt pass over the non-empty cache and slot
     mode all run; logits stay close to the fp16-cache engine and the cache takes a quarter of the memory + scales."""
