@@ -256,8 +256,7 @@ def convert_minicpm3(cfg: dict, sd: StateDict):
 def _probe_deepseek_v2(cfg):
     n, r, vd, d = _mla_layout(cfg)
     heads = cfg["num_attention_heads"]
-    if _get(cfg, "topk_method", default="greedy") != "greedy" and (_get(cfg, "n_group", default=1) or 1) > 1:
-        raise NotImplementedError("group-limited expert routing (DeepSeek-V2 236B) has no engine map; use the module path")
+    grouped = _get(cfg, "topk_method", default="greedy") == "group_limited_greedy" and (_get(cfg, "n_group", default=1) or 1) > 1
     scale = 1.0 / math.sqrt(n + r)
     rs = _get(cfg, "rope_scaling") or cfg.get("rope_parameters") or {}
     if rs.get("mscale_all_dim") and rs.get("factor", 1.0) > 1.0:      # yarn: the softmax scale carries mscale^2
@@ -267,13 +266,15 @@ def _probe_deepseek_v2(cfg):
                         attn_scale=scale, mla_q_lora=int(cfg.get("q_lora_rank") or 0), mla_kv_lora=int(cfg["kv_lora_rank"]),
                         num_experts=int(cfg["n_routed_experts"]), top_k=int(cfg["num_experts_per_tok"]),
                         moe_intermediate_size=int(cfg["moe_intermediate_size"]), norm_topk_prob=False,
+                        moe_n_group=int(cfg["n_group"]) if grouped else 1,
+                        moe_topk_group=int(cfg["topk_group"]) if grouped else 1,
                         shared_expert_intermediate_size=int(cfg["moe_intermediate_size"]) * int(cfg.get("n_shared_experts") or 0))
 
 
 def convert_deepseek_v2(cfg: dict, sd: StateDict):
-    """DeepSeek-V2-Lite class (reference models/deepseek.py ``deepseek_attention_forward`` / ``deepseek_moe_forward``):
+    """DeepSeek-V2 / V2-Lite (reference models/deepseek.py ``deepseek_attention_forward`` / ``deepseek_moe_forward``):
     latent attention with interleaved rotary pairs, dense MLP in the first ``first_k_dense_replace`` layers, then
-    routed experts (softmax scores, top-k without renormalization, ``routed_scaling_factor`` folded into the experts'
+    routed experts (softmax scores, plain or group-limited top-k without renormalization, ``routed_scaling_factor`` folded into the experts'
     down projections) plus always-on shared experts.  Expert weights are taken stacked (``experts.gate_up_proj``) or
     per expert (``experts.N.gate_proj``)."""
     dc = _probe_deepseek_v2(cfg)
@@ -780,6 +781,10 @@ def reference_forward(dc: DecoderConfig, sd: StateDict, ids: torch.Tensor, past=
         if f"L{i}.router" in sd:
             t = x.reshape(-1, x.shape[-1])
             p = torch.softmax(t @ sd[f"L{i}.router"].float().t(), -1)
+            if dc.moe_n_group > 1:                  # only the experts of the best groups compete
+                gs = p.view(p.shape[0], dc.moe_n_group, -1).amax(-1)
+                keep = torch.zeros_like(gs).scatter_(1, gs.topk(dc.moe_topk_group, dim=-1).indices, 1.0)
+                p = p * keep.repeat_interleave(dc.num_experts // dc.moe_n_group, 1)
             w, idx = torch.topk(p, dc.top_k, dim=-1)
             if dc.norm_topk_prob:
                 w = w / w.sum(-1, keepdim=True)
@@ -923,8 +928,10 @@ def build_engine(dc: DecoderConfig, qsd: dict, device="cuda"):
                 ws.append(w.to(dev, torch.float16).view(shape).contiguous())
                 qt = Q.FP16
         shared = tuple(lin(f"L{i}.shared.{n}") for n in ("gate", "up", "down")) if f"L{i}.shared.gate" in qsd else None
-        return MoEWeights(qsd[f"L{i}.router"].to(dev), ws[0], ws[1], ws[2], qt, e, dc.top_k, hid, inter, act=dc.act,
-                          normalize=dc.norm_topk_prob, shared=shared)
+        mw = MoEWeights(qsd[f"L{i}.router"].to(dev), ws[0], ws[1], ws[2], qt, e, dc.top_k, hid, inter, act=dc.act,
+                        normalize=dc.norm_topk_prob, shared=shared)
+        mw.n_group, mw.topk_group = dc.moe_n_group, dc.moe_topk_group
+        return mw
 
     def opt_lin(name):
         return lin(name) if name in qsd else None

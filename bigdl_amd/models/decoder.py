@@ -70,6 +70,8 @@ class DecoderConfig:
     moe_intermediate_size: int = 0
     shared_expert_intermediate_size: int = 0
     norm_topk_prob: bool = True
+    moe_n_group: int = 1              # DeepSeek-V2 group-limited routing: expert groups, and how many of them compete
+    moe_topk_group: int = 1
     logit_scale: float = 1.0
 
     @property

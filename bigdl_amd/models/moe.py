@@ -79,6 +79,8 @@ class MoEWeights:
         self.n_local = num_experts if expert_range is None else expert_range[1] - expert_range[0]
         self.ep_mode = "allreduce"              # "a2a": tokens are sharded over the expert-parallel ranks
         self.ep_rank, self.ep_world = 0, 1
+        # group-limited routing (DeepSeek-V2): experts in n_group groups, only the topk_group best groups compete
+        self.n_group, self.topk_group = 1, 1
 
     # ------------------------------------------------------------------ builders
     @classmethod
@@ -135,6 +137,22 @@ class MoEWeights:
         and local ones are rebased to this rank's slice."""
         logits = F.linear(x, self.router.to(x.dtype))
         rng = self.expert_range if local_only else None
+        if self.n_group > 1:
+            # softmax over all experts, experts outside the topk_group best groups (by their best expert) drop out,
+            # weights are the unrenormalized scores (reference models/deepseek.py ``moe_group_topk``); plain tensor ops,
+            # replayable inside the decode graph
+            p = torch.softmax(logits.float(), -1)
+            gs = p.view(p.shape[0], self.n_group, -1).amax(-1)
+            keep = torch.zeros_like(gs).scatter_(1, gs.topk(self.topk_group, dim=-1).indices, 1.0)
+            p = p * keep.repeat_interleave(self.num_experts // self.n_group, 1)
+            w, ids = torch.topk(p, self.top_k, dim=-1)
+            if self.normalize:
+                w = w / w.sum(-1, keepdim=True)
+            ids = ids.int()
+            if rng is not None:
+                inside = (ids >= rng[0]) & (ids < rng[1])
+                ids = torch.where(inside, ids - rng[0], torch.full_like(ids, -1))
+            return ids.contiguous(), w.contiguous()
         if x.device.type == "cuda":
             from ..ops import hip
             return hip.moe_route(logits, self.top_k, self.normalize, expert_range=rng)

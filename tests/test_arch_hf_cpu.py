@@ -80,6 +80,13 @@ FAMILIES = {
                                q_lora_rank=None, kv_lora_rank=64, qk_nope_head_dim=32, qk_rope_head_dim=32, v_head_dim=48,
                                n_routed_experts=8, num_experts_per_tok=3, n_shared_experts=2, first_k_dense_replace=1,
                                routed_scaling_factor=1.5, max_position_embeddings=64, tie_word_embeddings=False),
+    "deepseek_v2_grouped": lambda: _mk(T.DeepseekV2Config, T.DeepseekV2ForCausalLM, vocab_size=V, hidden_size=64,
+                                       num_hidden_layers=2, intermediate_size=128, moe_intermediate_size=64,
+                                       num_attention_heads=4, num_key_value_heads=4, q_lora_rank=64, kv_lora_rank=64,
+                                       qk_nope_head_dim=32, qk_rope_head_dim=32, v_head_dim=32, n_routed_experts=16,
+                                       num_experts_per_tok=4, n_shared_experts=1, first_k_dense_replace=0,
+                                       topk_method="group_limited_greedy", n_group=4, topk_group=2,
+                                       routed_scaling_factor=2.0, max_position_embeddings=64, tie_word_embeddings=False),
     "gptj": lambda: _mk(T.GPTJConfig, T.GPTJForCausalLM, vocab_size=V, n_embd=64, n_layer=2, n_head=4, rotary_dim=8,
                         n_positions=64),
 }
