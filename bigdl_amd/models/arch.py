@@ -203,26 +203,34 @@ def _mla_layout(cfg: dict):
     return n, r, vd, min(fits)
 
 
-def _mla_keys(cfg: dict, sd: StateDict, out: StateDict, i: int, o_scale: float = 1.0):
+def _mla_keys(cfg: dict, sd: StateDict, out: StateDict, i: int, o_scale: float = 1.0, pair_up: bool = False):
     """Latent-attention projections of layer ``i`` in the engine's head layout (decoder.py::MLAWeights): q heads
     [rotary | no-position | 0], K heads [0 (shared rotary key goes here) | no-position | 0], V heads [v | 0]."""
     n, r, vd, d = _mla_layout(cfg)
     heads = cfg["num_attention_heads"]
     p = f"model.layers.{i}.self_attn."
+    # pair_up: the checkpoint rotates channel pairs (j, j + r/2); the rotary channels are re-ordered so that the pairs
+    # sit side by side (2j, 2j + 1) in q and in the shared key alike (scores do not change), which is the order the
+    # attention kernel rotates and appends in by itself when only part of the head is rotary
+    order = torch.arange(r)
+    if pair_up:
+        order = torch.stack([order[: r // 2], order[r // 2:]], 1).reshape(-1)
 
     def q_rows(w):                      # [heads * (n + r), in] -> [heads * d, in]
         w = w.reshape(heads, n + r, -1)
         z = torch.zeros(heads, d - n - r, w.shape[2], dtype=w.dtype)
-        return torch.cat([w[:, n:], w[:, :n], z], 1).reshape(heads * d, -1)
+        return torch.cat([w[:, n:][:, order], w[:, :n], z], 1).reshape(heads * d, -1)
 
+    kv_a = sd[p + "kv_a_proj_with_mqa.weight"]
+    kv_a = torch.cat([kv_a[:-r], kv_a[-r:][order]], 0)
     if cfg.get("q_lora_rank"):
         # both latent projections read the same rows: one stacked weight [q latent ; kv latent | rotary key]
-        out[f"L{i}.kv_a"] = torch.cat([sd[p + "q_a_proj.weight"], sd[p + "kv_a_proj_with_mqa.weight"]], 0)
+        out[f"L{i}.kv_a"] = torch.cat([sd[p + "q_a_proj.weight"], kv_a], 0)
         out[f"L{i}.q_a_norm"] = sd[p + "q_a_layernorm.weight"]
         out[f"L{i}.q_b"] = q_rows(sd[p + "q_b_proj.weight"])
     else:
         out[f"L{i}.q"] = q_rows(sd[p + "q_proj.weight"])
-        out[f"L{i}.kv_a"] = sd[p + "kv_a_proj_with_mqa.weight"]
+        out[f"L{i}.kv_a"] = kv_a
     out[f"L{i}.kv_a_norm"] = sd[p + "kv_a_layernorm.weight"]
     kvb = sd[p + "kv_b_proj.weight"].reshape(heads, n + vd, -1)
     lora = kvb.shape[2]
@@ -236,7 +244,7 @@ def _mla_keys(cfg: dict, sd: StateDict, out: StateDict, i: int, o_scale: float =
 
 def convert_minicpm3(cfg: dict, sd: StateDict):
     """MiniCPM3-4B (reference models/minicpm3.py): MiniCPM's embedding / residual / logit scales plus multi-head
-    latent attention; rotate-half RoPE on the ``qk_rope_head_dim`` rotary channels, softmax scale
+    latent attention; rotate-half RoPE on the ``qk_rope_head_dim`` rotary channels (stored pair by pair here), softmax scale
     1 / sqrt(qk_nope + qk_rope)."""
     dc = _probe_minicpm3(cfg)
     rs = float(_get(cfg, "scale_depth", default=1.0)) / math.sqrt(dc.num_layers)
@@ -244,7 +252,7 @@ def convert_minicpm3(cfg: dict, sd: StateDict):
     out["lm_head"] = sd.get("lm_head.weight", out["embed"])
     for i in range(dc.num_layers):
         p = f"model.layers.{i}."
-        _mla_keys(cfg, sd, out, i, o_scale=rs)
+        _mla_keys(cfg, sd, out, i, o_scale=rs, pair_up=True)
         out[f"L{i}.input_norm"] = sd[p + "input_layernorm.weight"]
         out[f"L{i}.post_norm"] = sd[p + "post_attention_layernorm.weight"]
         out[f"L{i}.gate"] = sd[p + "mlp.gate_proj.weight"]
@@ -1112,6 +1120,7 @@ def _probe_minicpm3(cfg):
     n, r, vd, d = _mla_layout(cfg)
     heads = cfg["num_attention_heads"]
     dc = _base_config(cfg, "minicpm3", tie_word_embeddings=True, num_kv_heads=heads, head_dim=d, rot_dim=r,
+                      rope_interleaved=True,      # the weight map puts the rotate-half pairs side by side
                       attn_scale=1.0 / math.sqrt(n + r), mla_q_lora=int(cfg.get("q_lora_rank") or 0),
                       mla_kv_lora=int(cfg["kv_lora_rank"]))
     dc.embed_scale = float(_get(cfg, "scale_emb", default=1.0))

@@ -1198,7 +1198,8 @@ TINY_LLAMA = dict(vocab_size=32000, hidden_size=2048, intermediate_size=5632, nu
                   num_kv_heads=4, head_dim=64, rms_eps=1e-5, max_position=2048, model_type="llama")
 # MiniCPM3-4B: latent attention, 64 + 32 = 96 channels per head, values 64 wide (padded to 96)
 MINICPM3_4B = dict(vocab_size=73448, hidden_size=2560, intermediate_size=6400, num_layers=62, num_heads=40, num_kv_heads=40,
-                   head_dim=96, rot_dim=32, rms_eps=1e-5, max_position=32768, model_type="minicpm3", mla_q_lora=768,
+                   head_dim=96, rot_dim=32, rope_interleaved=True, rms_eps=1e-5, max_position=32768, model_type="minicpm3",
+                   mla_q_lora=768,
                    mla_kv_lora=256, attn_scale=96 ** -0.5, embed_scale=12.0, logit_scale=256 / 2560,
                    tie_word_embeddings=True)
 # DeepSeek-V2-Lite: latent attention (128 + 64 -> 256-channel heads) + 64 routed experts (top 6) + 2 shared
