@@ -27,6 +27,32 @@
 #ifndef GEMV_PROBE
 #define GEMV_PROBE 0
 #endif
+// Tuning knobs of benchmark/layer_probe.hip (the defaults are the production configuration):
+// GEMV_FORCE_OCC = 1 caps the single-tile 8-wavefront kernels at 80 VGPRs (6 wavefronts per SIMD);
+// GEMV_NW_MAIN = wavefronts per workgroup of the kernels whose x fits the LDS budget.
+// GEMV_STAMP = 1: diagnostic build, every wavefront writes 100 MHz wall-clock stamps of its phases to g_gemv_stamps
+// ([workgroup][wavefront][8]; 0 entry, 1 loads issued, 2 x staged, 3 after barrier, 4 main loop done, 5 exit).
+#ifndef GEMV_STAMP
+#define GEMV_STAMP 0
+#endif
+#if GEMV_STAMP
+__device__ unsigned long long* g_gemv_stamps;
+#define GEMV_STAMP_AT(i)                                                                                       \
+  do {                                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    const unsigned long long t_ = __builtin_amdgcn_s_memrealtime();                                            \
+    if (lane == 0) g_gemv_stamps[((size_t)blockIdx.x * GEMV_NW + wave) * 8 + (i)] = t_;                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+  } while (0)
+#else
+#define GEMV_STAMP_AT(i)
+#endif
+#ifndef GEMV_FORCE_OCC
+#define GEMV_FORCE_OCC 0
+#endif
+#ifndef GEMV_NW_MAIN
+#define GEMV_NW_MAIN 8
+#endif
 
 namespace bigdl {
 
@@ -66,6 +92,8 @@ struct GemvArgs {
   const float* slot_scale;
   int n_total;
   int slot_xdiv, n_slots;
+  // CU-resident kernels (template parameter CU): output tiles whose K-split partials fit the LDS at once
+  int cu_ntc;
 };
 
 template <int QT>
@@ -76,10 +104,17 @@ struct Tile {
   half4 d, m;          // block scales / mins of the lane's row for the 4 steps
 };
 
+#ifndef GEMV_NT
+#define GEMV_NT 1
+#endif
 template <typename T>
 __device__ __forceinline__ T ldg_nt(const void* p) {
   // weights are streamed exactly once per call: non-temporal loads keep them from displacing x/L2 state
+#if GEMV_NT
   return __builtin_nontemporal_load((const T*)p);
+#else
+  return *(const T*)p;
+#endif
 }
 
 // unconditional loads: the caller passes an in-range tile index
@@ -100,8 +135,48 @@ __device__ __forceinline__ void load_tile(Tile<QT>& t, const T16Planes& p, int64
     t.hi1 = h.y;
   }
   const int r = lane & 15;
+#ifdef GEMV_ABL_NOSC
+  t.d = half4{1, 1, 1, 1};
+  return;
+#endif
   t.d = ldg_nt<half4>(p.sc + tile * 64 + r * 4);
   if constexpr (QT == Q_ASYM_INT4 || QT == Q_ASYM_INT5 || QT == Q_WOQ_INT4) t.m = ldg_nt<half4>(p.mn + tile * 64 + r * 4);
+}
+
+// The GEMV fetches codes and scales separately: load_tile_codes per tile, then ONE scale load per round of up to four
+// tiles (RoundScales): lane group g = lane / 16 fetches the four block scales of row lane % 16 of the round's tile
+// g, and the consumer pulls the scales of tile j from lane group j with two ds_bpermute.  One 512-byte scale request
+// per round instead of a 4x redundant 64-byte one per tile: half as many memory instructions per wavefront and 6
+// fewer live registers per round, which is what lets three 8-wavefront workgroups share a CU.
+template <int QT>
+__device__ __forceinline__ void load_tile_codes(Tile<QT>& t, const T16Planes& p, int64_t tile, int lane) {
+  constexpr int LO = (QT == Q_SYM_INT8 || QT == Q_FP8_E4M3 || QT == Q_FP8_E5M2) ? 8 : 4;
+  if constexpr (LO == 4) {
+    t.lo0 = ldg_nt<uint4v>(p.lo + tile * 1024 + lane * 16);
+  } else {
+    t.lo0 = ldg_nt<uint4v>(p.lo + tile * 2048 + lane * 16);
+    t.lo1 = ldg_nt<uint4v>(p.lo + tile * 2048 + 1024 + lane * 16);
+  }
+  if constexpr (QT == Q_SYM_INT5 || QT == Q_ASYM_INT5) {
+    t.hi0 = ldg_nt<uint32_t>(p.hi + tile * 256 + lane * 4);
+  } else if constexpr (QT == Q_FP6) {
+    const uint2v h = ldg_nt<uint2v>(p.hi + tile * 512 + lane * 8);
+    t.hi0 = h.x;
+    t.hi1 = h.y;
+  }
+}
+
+struct RoundScales {
+  uint2v d, m;     // raw fp16 x 4: scales / mins of (tile = lane group, row = lane % 16)
+};
+
+// the four scales of row `lane % 16` of the round's tile j, from the lanes that loaded them
+__device__ __forceinline__ half4 round_scale(uint2v raw, int j, int lane) {
+  const int src = ((lane & 15) + 16 * j) << 2;
+  union { uint2v u; half4 h; } c;
+  c.u.x = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)raw.x);
+  c.u.y = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)raw.y);
+  return c.h;
 }
 
 // 8 int4 codes -> 8 fp16 values (code - bias): 1 shift, 4 and/or, 4 packed fp16 ops.
@@ -185,25 +260,59 @@ constexpr int XTAIL = 128;   // zero halves after each LDS x row: the k-tile "on
 // XLDS: x (after the optional RMSNorm scaling by gamma) is staged once per workgroup in LDS and the
 // A fragments are read from there; otherwise they are fetched from global memory (large M*K).
 // NW = wavefronts per workgroup (the K split)
-template <int QT, int MT, bool GATE_UP, bool XLDS, int NW>
-__global__ __launch_bounds__(NW * 64) void gemv_t16_kernel(GemvArgs a) {
+// ATT: x is the split-KV attention workspace (a.att_ws), combined while it is staged (needs XLDS, no norm)
+// Single-tile kernels with 8 wavefronts are launched three workgroups to a CU (N / 16 = 688 .. 768 workgroups on 256
+// CUs): 6 wavefronts per SIMD, i.e. at most 80 VGPRs, keeps all of them resident at once.
+// CU: "one workgroup per CU" form for up to 16 rows: the grid is min(#CUs, N / 16) workgroups of 16 wavefronts, workgroup b
+// owns the 16-row weight tiles b, b + grid, b + 2 grid, ... and streams them back to back through the same two register
+// sets, x is staged once per CU instead of once per tile, and the K-split partials of all its tiles are combined after
+// ONE barrier, one wavefront per tile.  With 1024 threads the register budget is 128 VGPRs whatever the tile count,
+// so residency no longer depends on the allocator staying under an occupancy step.
+// LEAN: every (chunk, row) item of x is one of the EX early items of its wavefront (M * ceil(ceil(K / 512) / NW) <= EX: one
+// row up to K = 8192, two up to K = 4096); the general staging loop is compiled out, which keeps the tile-per-workgroup kernel
+// within the 80 VGPRs that let three of its workgroups share a CU.
+template <int QT, int MT, bool GATE_UP, bool XLDS, int NW, bool ATT = false, bool CU = false, bool LEAN = false>
+#ifndef GEMV_GU_OCC
+#define GEMV_GU_OCC 5
+#endif
+__global__ __launch_bounds__(NW * 64, LEAN ? 6 : (NW + 3) / 4) void gemv_t16_kernel(GemvArgs a) {
+  static_assert(!ATT || XLDS, "the attention combine lives in the LDS staging of x");
+  static_assert(!CU || (MT == 1 && XLDS && NW == 16), "CU form: at most 16 rows, x in LDS, 16 wavefronts");
   constexpr int GEMV_NW = NW;
   constexpr int NACC = GATE_UP ? 2 : 1;
   constexpr int NSTREAM = GATE_UP ? 2 : 1;
-  // weight tiles fetched per wavefront per round trip (per stream): 16 B x 64 lanes x 4 = 4 KiB in flight
-  constexpr int U = (GATE_UP || NW > 8) ? 2 : 4;
+  // weight tiles per wavefront per round (per stream).  Two rounds (register sets ta / tb) are requested before anything
+  // else happens, so a wavefront has 4 KiB (8 KiB with two streams) of codes in flight from its first instructions on.
+#ifdef GEMV_U
+  constexpr int U = GEMV_U;
+#else
+  constexpr int U = 2;
+#endif
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // carve: red | ssq | sum | lut | xsum | x
-  float* red = (float*)smem;                                  // [NW][NACC*MT][64][4]
-  float* ssq_sh = red + GEMV_NW * NACC * MT * 256;            // [MT*16] sum of squares per row
-  float* sum_sh = ssq_sh + MT * 16;                           // [MT*16] sum per row (LayerNorm prologue)
-  _Float16* nf4_lut = (_Float16*)(sum_sh + MT * 16);          // [64*16] (nf4 only)
+  float* red = (float*)smem;                                  // [NW][NACC*MT][64][4]; CU: [ntc][NW][NACC][rows_g * 16][4]
+  const int rows_g = (a.M + 3) >> 2;                          // CU: lane groups (4 rows each) that hold valid rows
+  const int red_floats = CU ? a.cu_ntc * GEMV_NW * NACC * rows_g * 64 : GEMV_NW * NACC * MT * 256;
+  // per-wavefront partial sums of x^2 and x per row (RMSNorm / LayerNorm prologue): every wavefront only ever touches
+  // its own slice, so the staging needs neither atomics nor a barrier between zeroing and accumulation
+  float* ssq_sh = red + red_floats;                           // [NW][MT*16]
+  float* sum_sh = ssq_sh + GEMV_NW * MT * 16;                 // [NW][MT*16]
+  _Float16* nf4_lut = (_Float16*)(sum_sh + GEMV_NW * MT * 16);   // [64*16] (nf4 only)
   // formats with a block minimum: sum of (scaled) x over every 32-block, [Kp/32 + XTAIL/32][MT*16 rows], so that the
   // "+ min * sum(x)" term is one 16-byte LDS read per MFMA step instead of a cross-lane reduction of the fragment
   float* xsum = (float*)(nf4_lut + (QT == Q_NF4 ? 64 * 16 : 0));
   constexpr bool XSUM = XLDS && has_min<QT>();
   const int xsum_floats = XSUM ? (((a.K + 127) >> 7) * 4 + XTAIL / 32) * MT * 16 : 0;
-  _Float16* xs = (_Float16*)(xsum + xsum_floats);             // [M][Kp + XTAIL + XPAD]
+  // tile-per-workgroup form: the block scales (and minima) of the workgroup's whole tile row are staged in LDS by a
+  // few full-width loads (they are contiguous per tile row: KT x 128 bytes) instead of one 64-byte request per k-tile
+#ifndef GEMV_SCLDS
+#define GEMV_SCLDS 0
+#endif
+  constexpr bool SCLDS = GEMV_SCLDS && !CU;
+  constexpr int NPL = has_min<QT>() ? 2 : 1;                  // planes: scales, minima
+  const int KT_ = (a.K + 127) >> 7;
+  _Float16* sc_lds = (_Float16*)(xsum + xsum_floats);         // [NPL][NSTREAM][KT][16][4]
+  _Float16* xs = sc_lds + (SCLDS ? NPL * NSTREAM * KT_ * 64 : 0);   // [M][Kp + XTAIL + XPAD]
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -238,118 +347,272 @@ __global__ __launch_bounds__(NW * 64) void gemv_t16_kernel(GemvArgs a) {
   pl[0] = t16_planes(a.w, QT, n_planes, a.K);
   if constexpr (GATE_UP) pl[1] = t16_planes(a.w2, QT, n_planes, a.K);
   const int64_t tile0 = (wt + nt) * KT;
+  // CU form: this workgroup's tiles are nt + i * gridDim.x, i < cnt; a tile takes RPN rounds of U k-tiles per wavefront
+  const int n_tiles = (a.N + 15) >> 4;
+  const int cnt = CU ? (n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 1;
+  const int RPN = (((KT + GEMV_NW - 1) / GEMV_NW) + U - 1) / U;
 
   if constexpr (GEMV_PROBE == 1) return;
-  // ---- 1. put the first round of weight loads in flight before anything else ----
+  GEMV_STAMP_AT(0);
+  const bool norm = a.gamma != nullptr;
+  const bool lnorm = a.ln_c1 != nullptr;
+  const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  // x is cut into column chunks of 64 vectors (one 16-byte load per lane); wavefront w stages chunks w, w + NW, ...
+  // for all rows.  Only [0, K) is loaded, the rest of an LDS row (padding up to Kp plus the zero tail) is filled
+  // without touching memory.
+  const int kvec = a.K >> 3;
+  const int chunks = (kvec + 63) >> 6;
+  const int kmax = a.K - 8;
+  const int vec_per_row = (Kp + XTAIL) >> 3;
+
+  // ---- 1. x first: the first EX (chunk, row) items of this wavefront are requested BEFORE the weights.  Vector
+  // memory returns in order, so an x load issued behind the weight loads would only be usable once every weight
+  // tile of the round has landed: the whole workgroup would sit at the staging barrier for the length of the
+  // weight stream and dequantization + MFMA would start after it instead of under it.
+  constexpr int EX = 2;
+  half8 ex[EX], eg[EX];
+  bool ev[EX];
+  int ecol[EX], erow[EX];
+#ifdef GEMV_ABL_NOX
+  constexpr bool ABL_NOX = true;
+#else
+  constexpr bool ABL_NOX = false;
+#endif
+  if constexpr (XLDS && !ATT && !ABL_NOX) {
+    int ci = 0, m = 0;
+#pragma unroll
+    for (int e = 0; e < EX; ++e) {
+      const int c = wave + GEMV_NW * ci;
+      ev[e] = c < chunks;                       // wavefront-uniform
+      ecol[e] = (c * 64 + lane) << 3;
+      erow[e] = m;
+      ex[e] = zero8;
+      eg[e] = zero8;
+      if (ev[e]) {
+        const int cl = min(ecol[e], kmax);
+        ex[e] = *(const half8*)(a.x + (int64_t)m * a.ldx + cl);
+        if (norm) eg[e] = *(const half8*)(a.gamma + cl);
+      }
+      if (++m == a.M) { m = 0; ++ci; }
+    }
+  }
+
+  // scales / minima of the tile row: vector i (16 bytes) of plane pq = i / (KT * 8), one load per thread and pass
+  constexpr int ESC = 2;                                      // passes requested before the weights
+  uint4v esc[ESC];
+  const int sc_vecs = SCLDS ? NPL * NSTREAM * KT * 8 : 0;
+  auto sc_src = [&](int i) {
+    const int pq = i / (KT * 8), off = i - pq * (KT * 8);
+    const _Float16* base = pl[0].sc;
+    if constexpr (NSTREAM == 2) {
+      if (pq & 1) base = pl[1].sc;
+    }
+    if constexpr (has_min<QT>()) {
+      if (pq >= NSTREAM) {
+        base = pl[0].mn;
+        if constexpr (NSTREAM == 2) {
+          if (pq & 1) base = pl[1].mn;
+        }
+      }
+    }
+    return (const uint4v*)(base + tile0 * 64) + off;
+  };
+  if constexpr (SCLDS) {
+#pragma unroll
+    for (int e = 0; e < ESC; ++e) {
+      const int i = threadIdx.x + e * GEMV_NW * 64;
+      esc[e] = uint4v{0, 0, 0, 0};
+      if (i < sc_vecs) esc[e] = ldg_nt<uint4v>(sc_src(i));
+    }
+  }
+
+  // ---- 2. first round of weight loads ----
   // this wavefront owns k-tiles wave, wave+NW, ...; indices past the end are clamped to the last tile
   // (a valid address) and neutralised by reading the zero tail of x.
   const int ntw = wave < KT ? (KT - wave + GEMV_NW - 1) / GEMV_NW : 0;
-  Tile<QT> ta[NSTREAM][U], tb[NSTREAM][U];
+  // register sets: two (ping-pong) in the tile-per-workgroup form; three in the CU form, where they hold ALL the
+  // rounds of the usual decode shapes (three tiles of K = 4096, one of K = 11008), i.e. every weight byte of the
+  // workgroup is requested before the first one is used and no request ever waits for dequantization to free a set
+  // block scales: RSC = one scale load per round + ds_bpermute (see RoundScales); otherwise one 64-byte request per tile
+  // with every lane group fetching the same four scales.  The round form wins where registers decide how many
+  // workgroups share a CU (the lean single-stream kernel: 70 instead of 90 VGPRs) and in the CU form; the gate/up and
+  // 16-wavefront kernels measured faster with per-tile scale loads.
+  constexpr bool RSC = !SCLDS && (CU || (LEAN && !GATE_UP));
+  constexpr int NSET = CU ? 3 : 2;
+  Tile<QT> ta[NSTREAM][U], tb[NSTREAM][U], tc[CU ? NSTREAM : 1][CU ? U : 1];
+  RoundScales sa, sb, sc3;
+  constexpr int NT_R = NSTREAM * U;             // tiles per round, slot j = u * NSTREAM + st
+  static_assert(NT_R == 2 || NT_R == 4, "one scale load per round covers at most four tiles");
+  const int jl = g & (NT_R - 1), ul = jl / NSTREAM, sl = jl % NSTREAM;     // the slot whose scales this lane fetches
+  int f_i = 0, f_rd = 0;      // CU: fetch cursor (tile of this workgroup, round within the tile)
+  auto fetch = [&](Tile<QT> (&tt)[NSTREAM][U], RoundScales& rs, int base) {
+    int64_t t0 = tile0;
+    if constexpr (CU) {
+      // rounds are fetched strictly in order; past the end the last round is fetched again (never consumed)
+      t0 = (int64_t)((int)blockIdx.x + min(f_i, cnt - 1) * (int)gridDim.x) * KT;
+      base = f_rd * U;
+      if (++f_rd == RPN) { f_rd = 0; ++f_i; }
+    }
 #pragma unroll
-  for (int u = 0; u < U; ++u)
+    for (int u = 0; u < U; ++u)
 #pragma unroll
-    for (int st = 0; st < NSTREAM; ++st) load_tile<QT>(ta[st][u], pl[st], tile0 + min(wave + GEMV_NW * u, KT - 1), lane);
+      for (int st = 0; st < NSTREAM; ++st)
+      {
+        if constexpr (RSC || SCLDS) load_tile_codes<QT>(tt[st][u], pl[st], t0 + min(wave + GEMV_NW * (base + u), KT - 1), lane);
+        else load_tile<QT>(tt[st][u], pl[st], t0 + min(wave + GEMV_NW * (base + u), KT - 1), lane);
+      }
+    if constexpr (!RSC) return;
+#ifndef GEMV_ABL_NOSC
+    const int64_t tl = t0 + min(wave + GEMV_NW * (base + ul), KT - 1);
+    const _Float16* scp = pl[0].sc;
+    const _Float16* mnp = pl[0].mn;
+    if constexpr (NSTREAM == 2) {
+      if (sl) { scp = pl[1].sc; mnp = pl[1].mn; }
+    }
+    rs.d = ldg_nt<uint2v>(scp + tl * 64 + r * 4);
+    if constexpr (has_min<QT>()) rs.m = ldg_nt<uint2v>(mnp + tl * 64 + r * 4);
+#else
+    rs.d = uint2v{0x3c003c00u, 0x3c003c00u};
+    rs.m = uint2v{0, 0};
+#endif
+  };
+  fetch(ta, sa, 0);
+#ifndef GEMV_GU_PF2
+#define GEMV_GU_PF2 0
+#endif
+  // request the second set before x is staged as well: pays in the lean kernel (all of a K = 4096 tile row in flight
+  // from the start); the 16-wavefront and gate/up kernels measured slower with it
+  constexpr bool PF2 = LEAN || CU || (GATE_UP && GEMV_GU_PF2);
+  if (PF2 && (CU ? cnt * RPN > 1 : U < ntw)) fetch(tb, sb, U);
+  if constexpr (CU) {
+    if (cnt * RPN > 2) fetch(tc, sc3, 0);
+  }
 
-  // ---- 2. stage x (optionally scaled by the RMSNorm gamma) in LDS, all wavefronts together ----
-  const bool norm = a.gamma != nullptr;
-  const bool lnorm = a.ln_c1 != nullptr;
+  GEMV_STAMP_AT(1);
+  // ---- 3. stage x (optionally scaled by the norm's gamma) in LDS, all wavefronts together ----
   const _Float16* lut = nullptr;
   if constexpr (QT == Q_NF4) {
     fill_nf4_banked((uint32_t*)nf4_lut, threadIdx.x, GEMV_NW * 64);
     lut = (const _Float16*)((const uint32_t*)nf4_lut + (lane & 31));
   }
-  if (threadIdx.x < 2 * MT * 16) ssq_sh[threadIdx.x] = 0.0f;   // ssq_sh and sum_sh are adjacent
+  if constexpr (SCLDS) {
+#pragma unroll
+    for (int e = 0; e < ESC; ++e) {
+      const int i = threadIdx.x + e * GEMV_NW * 64;
+      if (i < sc_vecs) *(uint4v*)(sc_lds + 8 * i) = esc[e];
+    }
+    for (int i = threadIdx.x + ESC * GEMV_NW * 64; i < sc_vecs; i += GEMV_NW * 64) *(uint4v*)(sc_lds + 8 * i) = ldg_nt<uint4v>(sc_src(i));
+  }
+  if (lane < MT * 16) {
+    ssq_sh[wave * (MT * 16) + lane] = 0.0f;
+    sum_sh[wave * (MT * 16) + lane] = 0.0f;
+  }
   if constexpr (XSUM) {
     const float4v z4 = {0, 0, 0, 0};
     for (int i = threadIdx.x; i < (xsum_floats >> 2); i += GEMV_NW * 64) *(float4v*)(xsum + 4 * i) = z4;
+    __syncthreads();   // xsum zeroed before the block sums below
   }
-  if constexpr (XLDS) {
-    __syncthreads();   // ssq_sh / xsum zeroed before the atomics and block sums below
-    const int vec_per_row = (Kp + XTAIL) >> 3;
-    if (a.att_ws == nullptr) {
-      // Each wavefront stages whole 64-vector segments (one row, 64 x 16 bytes), up to 4 per round, with
-      // UNCONDITIONAL loads from clamped addresses (a load under a per-item condition makes the compiler wait for
-      // each one separately) and no dead slots (a redundant clamped load still costs L2 bandwidth): the loads of
-      // several rows are in flight together instead of one dependent L2 round trip per row (probe: +1.3 us per
-      // extra row of x with the row loop).
-      // rows are cut into segments of 64 vectors (one wavefront load); only [0, K) is loaded, the rest of the LDS
-      // row (padding up to Kp plus the zero tail) is filled without touching memory
-      const int kvec = a.K >> 3;
-      const int chunks = (kvec + 63) >> 6;
-      const int kmax = a.K - 8;
-      const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-      for (int i = threadIdx.x; i < a.M * (vec_per_row - kvec); i += GEMV_NW * 64) {
-        const int m = i / (vec_per_row - kvec), v = kvec + i % (vec_per_row - kvec);
-        *(half8*)(xs + m * XS + (v << 3)) = zero8;
+  if constexpr (XLDS && !ABL_NOX) {
+    for (int i = threadIdx.x; i < a.M * (vec_per_row - kvec); i += GEMV_NW * 64) {
+      const int m = i / (vec_per_row - kvec), v = kvec + i % (vec_per_row - kvec);
+      *(half8*)(xs + m * XS + (v << 3)) = zero8;
+    }
+    // one staged vector: norm statistics into this wavefront's partial slots, gamma, block sums, LDS store
+    auto finish = [&](half8 v, half8 g8, int col, int m) {
+      const bool inside = col < a.K;
+      if (!inside) v = zero8;
+      if (norm) {
+        const float ssq = wave_sum(frag_sumsq(v));
+        if (lane == 0) ssq_sh[wave * (MT * 16) + m] += ssq;
+        if (lnorm) {
+          const float sm = wave_sum(frag_sum(v));
+          if (lane == 0) sum_sh[wave * (MT * 16) + m] += sm;
+        }
+        if (a.gamma_offset != 0.0f) g8 = g8 + (_Float16)a.gamma_offset;
+        v = v * g8;
       }
-      // a wavefront owns a column chunk (64 vectors) for all rows: gamma is fetched once per chunk, and the rows of
-      // the chunk are loaded SU at a time
+      if constexpr (XSUM) {
+        float bs = frag_sum(v);                       // 4 consecutive lanes = one 32-block of this row
+        bs += __shfl_xor(bs, 1);
+        bs += __shfl_xor(bs, 2);
+        if (inside && (lane & 3) == 0) xsum[(col >> 5) * (MT * 16) + m] = bs;
+      }
+      if (inside) *(half8*)(xs + m * XS + col) = v;
+    };
+    if constexpr (!ATT) {
+#pragma unroll
+      for (int e = 0; e < EX; ++e)
+        if (ev[e]) finish(ex[e], eg[e], ecol[e], erow[e]);
+      // items beyond the early ones (many rows, or K above EX * NW * 512): SU rows of a chunk in flight together,
+      // with UNCONDITIONAL loads from clamped addresses (a load under a per-lane condition makes the compiler wait for
+      // each one separately)
       auto stage = [&](auto su_tag, int col, half8 g8, int m0) {
         constexpr int SU = decltype(su_tag)::value;     // rows in flight together, all valid
         const int cl = min(col, kmax);
-        const bool inside = col < a.K;
         half8 xv[SU];
 #pragma unroll
         for (int u = 0; u < SU; ++u) xv[u] = *(const half8*)(a.x + (int64_t)(m0 + u) * a.ldx + cl);
 #pragma unroll
-        for (int u = 0; u < SU; ++u) {
-          half8 v = inside ? xv[u] : zero8;
-          if (norm) {
-            const float ssq = wave_sum(frag_sumsq(v));
-            if (lane == 0) atomicAdd(&ssq_sh[m0 + u], ssq);
-            if (lnorm) {
-              const float sm = wave_sum(frag_sum(v));
-              if (lane == 0) atomicAdd(&sum_sh[m0 + u], sm);
-            }
-            v = v * g8;
-          }
-          if constexpr (XSUM) {
-            float bs = frag_sum(v);                       // 4 consecutive lanes = one 32-block of this row
-            bs += __shfl_xor(bs, 1);
-            bs += __shfl_xor(bs, 2);
-            if (inside && (lane & 3) == 0) xsum[(col >> 5) * (MT * 16) + m0 + u] = bs;
-          }
-          if (inside) *(half8*)(xs + (m0 + u) * XS + col) = v;
-        }
+        for (int u = 0; u < SU; ++u) finish(xv[u], g8, col, m0 + u);
       };
-      for (int c = wave; c < chunks; c += GEMV_NW) {
+      const int ci0 = EX / a.M, mstart = EX % a.M;       // first item after the early ones
+      for (int ci = ci0, c = wave + GEMV_NW * ci0; !LEAN && c < chunks; ++ci, c += GEMV_NW) {
         const int col = (c * 64 + lane) << 3;
         half8 g8 = zero8;
-        if (norm) {
-          g8 = *(const half8*)(a.gamma + min(col, kmax));
-          if (a.gamma_offset != 0.0f) g8 = g8 + (_Float16)a.gamma_offset;
-        }
-        int m0 = 0;
+        if (norm) g8 = *(const half8*)(a.gamma + min(col, kmax));
+        int m0 = ci == ci0 ? mstart : 0;
         for (; m0 + 3 < a.M; m0 += 4) stage(std::integral_constant<int, 4>{}, col, g8, m0);
         for (; m0 + 1 < a.M; m0 += 2) stage(std::integral_constant<int, 2>{}, col, g8, m0);
         for (; m0 < a.M; ++m0) stage(std::integral_constant<int, 1>{}, col, g8, m0);
       }
     } else {
-    for (int m = 0; m < a.M; ++m) {
-      for (int v = threadIdx.x; v < vec_per_row; v += GEMV_NW * 64) {
-        const int c = v << 3;
-        half8 xv = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (c < a.K) {
-          const int hq = c / a.att_D, d = c % a.att_D;
-          const int bb = m / a.att_qlen, tok = m % a.att_qlen;
-          const int64_t bh = (int64_t)bb * a.att_Hkv + hq / a.att_G;
-          const int row = tok * a.att_G + hq % a.att_G;
-          const int64_t stride = (int64_t)a.att_rows_alloc * (a.att_D + 4);
-          const float* p0 = a.att_ws + (bh * a.att_splits * a.att_rows_alloc + row) * (a.att_D + 4);
-          float mm = -1.0e30f;
-          for (int sp = 0; sp < a.att_splits; ++sp) mm = fmaxf(mm, p0[sp * stride + a.att_D]);
-          float lt = 0.0f, o8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-          for (int sp = 0; sp < a.att_splits; ++sp) {
-            const float* ps = p0 + sp * stride;
-            const float f = exp2f(ps[a.att_D] - mm);
-            lt += f * ps[a.att_D + 1];
-            const float4v v0 = *(const float4v*)(ps + d), v1 = *(const float4v*)(ps + d + 4);
+      // x[m][hq * D + d] = softmax-weighted combination of the attention kernel's per-split partial rows.  One thread
+      // per 8 channels; the (m, l) pairs and O pieces of 8 splits are requested together (one memory round trip per 8
+      // splits instead of two dependent ones per split) and folded in with a running maximum.
+      const int D = a.att_D;
+      const int64_t stride = (int64_t)a.att_rows_alloc * (D + 4);
+      for (int i = threadIdx.x; i < a.M * kvec; i += GEMV_NW * 64) {
+        const int m = a.M == 1 ? 0 : i / kvec, c = (a.M == 1 ? i : i % kvec) << 3;
+        const int hq = c / D, d = c - hq * D;
+        const int bb = a.att_qlen == 1 ? m : m / a.att_qlen, tok = a.att_qlen == 1 ? 0 : m % a.att_qlen;
+        const int hk = a.att_G == 1 ? hq : hq / a.att_G, gq = a.att_G == 1 ? 0 : hq % a.att_G;
+        const int64_t bh = (int64_t)bb * a.att_Hkv + hk;
+        const int row = tok * a.att_G + gq;
+        const float* p0 = a.att_ws + (bh * a.att_splits * a.att_rows_alloc + row) * (D + 4);
+        float mm = -1.0e30f, lt = 0.0f;
+        float4v o0 = {0, 0, 0, 0}, o1 = {0, 0, 0, 0};
+        for (int s0 = 0; s0 < a.att_splits; s0 += 8) {
+          float2v ml[8];
+          float4v v0[8], v1[8];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { o8[q] += f * v0[q]; o8[4 + q] += f * v1[q]; }
+          for (int j = 0; j < 8; ++j) {
+            const float* ps = p0 + min(s0 + j, a.att_splits - 1) * stride;
+            ml[j] = *(const float2v*)(ps + D);
+            v0[j] = *(const float4v*)(ps + d);
+            v1[j] = *(const float4v*)(ps + d + 4);
           }
-          const float inv = lt > 0.0f ? 1.0f / lt : 0.0f;
+          float gm = mm;
 #pragma unroll
-          for (int q = 0; q < 8; ++q) xv[q] = (_Float16)(o8[q] * inv);
+          for (int j = 0; j < 8; ++j) gm = fmaxf(gm, s0 + j < a.att_splits ? ml[j][0] : -1.0e30f);
+          const float fo = exp2f(mm - gm);
+          lt *= fo;
+          o0 *= fo;
+          o1 *= fo;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float f = s0 + j < a.att_splits ? exp2f(ml[j][0] - gm) : 0.0f;
+            lt += f * ml[j][1];
+            o0 += v0[j] * f;
+            o1 += v1[j] * f;
+          }
+          mm = gm;
+        }
+        const float inv = lt > 0.0f ? 1.0f / lt : 0.0f;
+        half8 xv;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          xv[q] = (_Float16)(o0[q] * inv);
+          xv[4 + q] = (_Float16)(o1[q] * inv);
         }
         if constexpr (XSUM) {
           float bs = frag_sum(xv);
@@ -360,9 +623,10 @@ __global__ __launch_bounds__(NW * 64) void gemv_t16_kernel(GemvArgs a) {
         *(half8*)(xs + m * XS + c) = xv;
       }
     }
-    }
   }
-  __syncthreads();
+  GEMV_STAMP_AT(2);
+  if constexpr (!ABL_NOX) __syncthreads();
+  GEMV_STAMP_AT(3);
 
   float2v acc[NACC][MT][2];
 #pragma unroll
@@ -380,7 +644,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_t16_kernel(GemvArgs a) {
 #pragma unroll
   for (int j = 0; j < MT; ++j) xrow[j] = min(16 * j + r, a.M - 1) * XS + 8 * g;
 
-  auto consume = [&](Tile<QT> (&tt)[NSTREAM][U], int base) {
+  auto consume = [&](Tile<QT> (&tt)[NSTREAM][U], const RoundScales& rs, int base) {
     if constexpr (GEMV_PROBE >= 2) {
       uint32_t x = 0;
 #pragma unroll
@@ -388,8 +652,9 @@ __global__ __launch_bounds__(NW * 64) void gemv_t16_kernel(GemvArgs a) {
 #pragma unroll
         for (int st = 0; st < NSTREAM; ++st) {
           const Tile<QT>& t = tt[st][u];
-          x ^= t.lo0[0] ^ t.lo0[1] ^ t.lo0[2] ^ t.lo0[3] ^ (uint32_t)(float)t.d[0] ^ (uint32_t)(float)t.d[3];
+          x ^= t.lo0[0] ^ t.lo0[1] ^ t.lo0[2] ^ t.lo0[3];
         }
+      if constexpr (RSC) x ^= rs.d.x ^ rs.d.y;
       acc[0][0][0][0] += __uint_as_float(x & 0x3f800000u);
       return;
     }
@@ -397,6 +662,21 @@ __global__ __launch_bounds__(NW * 64) void gemv_t16_kernel(GemvArgs a) {
     for (int u = 0; u < U; ++u) {
       const int kt = wave + GEMV_NW * (base + u);
       const int ktx = min(kt, KT);   // KT = zero tail
+      half4 dd[NSTREAM], mn4[NSTREAM];
+#pragma unroll
+      for (int st = 0; st < NSTREAM; ++st) {
+        if constexpr (SCLDS) {
+          const int kts = min(kt, KT - 1);
+          dd[st] = *(const half4*)(sc_lds + ((st * KT + kts) * 16 + r) * 4);
+          if constexpr (has_min<QT>()) mn4[st] = *(const half4*)(sc_lds + (((NSTREAM + st) * KT + kts) * 16 + r) * 4);
+        } else if constexpr (RSC) {
+          dd[st] = round_scale(rs.d, u * NSTREAM + st, lane);
+          if constexpr (has_min<QT>()) mn4[st] = round_scale(rs.m, u * NSTREAM + st, lane);
+        } else {
+          dd[st] = tt[st][u].d;
+          if constexpr (has_min<QT>()) mn4[st] = tt[st][u].m;
+        }
+      }
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         half8 xa[MT];
@@ -422,7 +702,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_t16_kernel(GemvArgs a) {
         for (int st = 0; st < NSTREAM; ++st) {
           const Tile<QT>& t = tt[st][u];
           const half8 bf = decode_step<QT>(t, s, lut);
-          const float d = (float)t.d[s] * post_scale<QT>();
+          const float d = (float)dd[st][s] * post_scale<QT>();
           const float2v d2 = {d, d};
 #pragma unroll
           for (int j = 0; j < MT; ++j) {
@@ -432,7 +712,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_t16_kernel(GemvArgs a) {
             if constexpr (XSUM) {
               // + min * sum_k x[m][k] over the block, block sums precomputed at staging: rows 4g .. 4g+3
               const float4v x4 = *(const float4v*)(xsum + (ktx * 4 + s) * (MT * 16) + 16 * j + 4 * g);
-              const float mn = (float)t.m[s];
+              const float mn = (float)mn4[st][s];
               acc[st][j][0] = __builtin_elementwise_fma(float2v{x4[0], x4[1]}, float2v{mn, mn}, acc[st][j][0]);
               acc[st][j][1] = __builtin_elementwise_fma(float2v{x4[2], x4[3]}, float2v{mn, mn}, acc[st][j][1]);
             } else if constexpr (has_min<QT>()) {
@@ -441,7 +721,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_t16_kernel(GemvArgs a) {
               float sx = frag_sum(xa[j]);
               sx += __shfl_xor(sx, 16);
               sx += __shfl_xor(sx, 32);
-              const float mn = (float)t.m[s];
+              const float mn = (float)mn4[st][s];
               acc[st][j][0][0] += mn * __shfl(sx, 4 * g + 0);
               acc[st][j][0][1] += mn * __shfl(sx, 4 * g + 1);
               acc[st][j][1][0] += mn * __shfl(sx, 4 * g + 2);
@@ -449,27 +729,136 @@ __global__ __launch_bounds__(NW * 64) void gemv_t16_kernel(GemvArgs a) {
             }
           }
         }
+#ifdef GEMV_SCHED_STEP
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+      }
+#ifdef GEMV_SCHED_TILE
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+  };
+  // row statistics of the fused norm, from the per-wavefront partials (valid after the barrier that ends the main loop)
+  auto row_stats = [&](int m, float& rs, float& mean) {
+    rs = 1.0f;
+    mean = 0.0f;
+    if (norm) {
+      float ssq = 0.0f, sm = 0.0f;
+#pragma unroll
+      for (int w = 0; w < GEMV_NW; ++w) {
+        ssq += ssq_sh[w * (MT * 16) + m];
+        sm += sum_sh[w * (MT * 16) + m];
+      }
+      if (lnorm) {
+        mean = sm / (float)a.K;
+        rs = rsqrtf(fmaxf(ssq / (float)a.K - mean * mean, 0.0f) + a.eps);
+      } else {
+        rs = rsqrtf(ssq / (float)a.K + a.eps);
       }
     }
   };
-  auto fetch = [&](Tile<QT> (&tt)[NSTREAM][U], int base) {
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-#pragma unroll
-      for (int st = 0; st < NSTREAM; ++st)
-        load_tile<QT>(tt[st][u], pl[st], tile0 + min(wave + GEMV_NW * (base + u), KT - 1), lane);
+  // epilogue of one output element: norm factors, bias, activation / gate, residual, store
+  auto emit = [&](float v, float u, int m, int n) {
+    float rs, mean;
+    row_stats(m, rs, mean);
+    v *= rs;
+    if (lnorm) v += a.ln_c2[n] - rs * mean * a.ln_c1[n];
+    if (a.bias) v += (float)((const _Float16*)a.bias)[n];
+    if constexpr (GATE_UP) {
+      u *= rs;
+      if (lnorm) u += a.ln2_c2[n] - rs * mean * a.ln2_c1[n];
+      if (a.bias2) u += (float)((const _Float16*)a.bias2)[n];
+      v = act_apply(a.act, v) * u;
+    } else {
+      v = act_apply(a.act, v);
+    }
+    v *= oscale;
+    const int64_t oi = (int64_t)(m + orow) * a.ldo + n;
+    if (a.out_type == OUT_F16) {
+      if (a.residual) v += load_out<OUT_F16>(a.residual, oi);
+      store_out<OUT_F16>(a.out, oi, v);
+    } else if (a.out_type == OUT_BF16) {
+      if (a.residual) v += load_out<OUT_BF16>(a.residual, oi);
+      store_out<OUT_BF16>(a.out, oi, v);
+    } else {
+      if (a.residual) v += load_out<OUT_F32>(a.residual, oi);
+      store_out<OUT_F32>(a.out, oi, v);
+    }
   };
 
-  // ---- 3. main loop: ping-pong between two register sets; a round is fetched while the other is consumed ----
+  if constexpr (CU) {
+    // ---- 3'. all tiles of this workgroup, round after round through the two register sets ----
+    const int Q = GEMV_PROBE == 2 ? 1 : cnt * RPN;
+    const int ntc = a.cu_ntc;
+    int c_i = 0, c_rd = 0;          // consume cursor
+    // after the last round of a tile: park the partial sums in the tile's LDS slot; after the last tile of a chunk of
+    // ntc tiles (or of the workgroup): barrier, one wavefront per tile adds the 16 partials and writes the outputs
+    auto round_done = [&]() {
+      if (++c_rd < RPN) return;
+      c_rd = 0;
+      const int slot = c_i % ntc;
+      if (g < rows_g) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) {
+          const float4v v = {acc[i][0][0][0], acc[i][0][0][1], acc[i][0][1][0], acc[i][0][1][1]};
+          *(float4v*)(red + ((((slot * GEMV_NW + wave) * NACC + i) * rows_g + g) * 16 + r) * 4) = v;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NACC; ++i) acc[i][0][0] = acc[i][0][1] = float2v{0, 0};
+      ++c_i;
+      if (slot != ntc - 1 && c_i != cnt) return;
+      __syncthreads();
+      const int first = c_i - 1 - slot;           // first tile of the chunk
+      if (wave <= slot && g < rows_g) {
+        const int n = ((int)blockIdx.x + (first + wave) * (int)gridDim.x) * 16 + r;
+        float4v o[NACC];
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) {
+          o[i] = float4v{0, 0, 0, 0};
+#pragma unroll
+          for (int w = 0; w < GEMV_NW; ++w) o[i] += *(const float4v*)(red + ((((wave * GEMV_NW + w) * NACC + i) * rows_g + g) * 16 + r) * 4);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int m = 4 * g + q;
+          if (m < a.M && n < a.N) emit(o[0][q], o[NACC - 1][q], m, n);
+        }
+      }
+      if (c_i != cnt) __syncthreads();            // the slots are reused by the next chunk
+    };
+    if constexpr (CU) {
+      for (int q = 0; q < Q; q += 3) {
+        consume(ta, sa, c_rd * U);
+        round_done();
+        if (q + 3 < Q) fetch(ta, sa, 0);
+        if (q + 1 < Q) {
+          consume(tb, sb, c_rd * U);
+          round_done();
+          if (q + 4 < Q) fetch(tb, sb, 0);
+        }
+        if (q + 2 < Q) {
+          consume(tc, sc3, c_rd * U);
+          round_done();
+          if (q + 5 < Q) fetch(tc, sc3, 0);
+        }
+      }
+    }
+    GEMV_STAMP_AT(5);
+    return;
+  }
+
+  // ---- 3. main loop: ping-pong between two register sets; a set is re-requested as soon as it has been consumed ----
   for (int base = 0; base < (GEMV_PROBE == 2 ? min(ntw, 1) : ntw); base += 2 * U) {
-    if (GEMV_PROBE != 2 && base + U < ntw) fetch(tb, base + U);
-    consume(ta, base);
+    if (GEMV_PROBE != 2 && base + U < ntw && !(PF2 && base == 0)) fetch(tb, sb, base + U);
+    consume(ta, sa, base);
     if (GEMV_PROBE != 2 && base + U < ntw) {
-      if (base + 2 * U < ntw) fetch(ta, base + 2 * U);
-      consume(tb, base + U);
+      if (base + 2 * U < ntw) fetch(ta, sa, base + 2 * U);
+      consume(tb, sb, base + U);
     }
   }
 
+  GEMV_STAMP_AT(4);
   // ---- 4. combine the K-split across wavefronts ----
 #pragma unroll
   for (int i = 0; i < NACC; ++i)
@@ -485,12 +874,15 @@ __global__ __launch_bounds__(NW * 64) void gemv_t16_kernel(GemvArgs a) {
         float s = ssq_g[j];
         s += __shfl_xor(s, 16);
         s += __shfl_xor(s, 32);
-        if (g == 0) atomicAdd(&ssq_sh[16 * j + r], s);
+        if (g == 0) ssq_sh[wave * (MT * 16) + 16 * j + r] = s;
       }
     }
   }
   __syncthreads();
-  if (wave != 0) return;
+  if (wave != 0) {
+    GEMV_STAMP_AT(5);
+    return;
+  }
 
   const int n = (int)nt * 16 + r;
 #pragma unroll
@@ -505,39 +897,10 @@ __global__ __launch_bounds__(NW * 64) void gemv_t16_kernel(GemvArgs a) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int m = 16 * j + 4 * g + q;
-      if (m >= a.M || n >= a.N) continue;
-      float rs = 1.0f, mean = 0.0f;
-      if (lnorm) {
-        mean = sum_sh[m] / (float)a.K;
-        rs = rsqrtf(fmaxf(ssq_sh[m] / (float)a.K - mean * mean, 0.0f) + a.eps);
-      } else if (norm) {
-        rs = rsqrtf(ssq_sh[m] / (float)a.K + a.eps);
-      }
-      float v = o[0][q] * rs;
-      if (lnorm) v += a.ln_c2[n] - rs * mean * a.ln_c1[n];
-      if (a.bias) v += (float)((const _Float16*)a.bias)[n];
-      if constexpr (GATE_UP) {
-        float u = o[1][q] * rs;
-        if (lnorm) u += a.ln2_c2[n] - rs * mean * a.ln2_c1[n];
-        if (a.bias2) u += (float)((const _Float16*)a.bias2)[n];
-        v = act_apply(a.act, v) * u;
-      } else {
-        v = act_apply(a.act, v);
-      }
-      v *= oscale;
-      const int64_t oi = (int64_t)(m + orow) * a.ldo + n;
-      if (a.out_type == OUT_F16) {
-        if (a.residual) v += load_out<OUT_F16>(a.residual, oi);
-        store_out<OUT_F16>(a.out, oi, v);
-      } else if (a.out_type == OUT_BF16) {
-        if (a.residual) v += load_out<OUT_BF16>(a.residual, oi);
-        store_out<OUT_BF16>(a.out, oi, v);
-      } else {
-        if (a.residual) v += load_out<OUT_F32>(a.residual, oi);
-        store_out<OUT_F32>(a.out, oi, v);
-      }
+      if (m < a.M && n < a.N) emit(o[0][q], o[NACC - 1][q], m, n);
     }
   }
+  GEMV_STAMP_AT(5);
 }
 
 constexpr size_t GEMV_XLDS_LIMIT = 48 * 1024;   // stage x in LDS when it fits this budget
@@ -546,35 +909,119 @@ constexpr size_t GEMV_XLDS_LIMIT = 48 * 1024;   // stage x in LDS when it fits t
 // workgroup per CU that such a footprint allows loses more than the LDS staging wins (measured at 16 rows).
 constexpr size_t GEMV_XLDS_LIMIT_FEW_ROWS = 100 * 1024;
 
-template <typename KernelT>
-static inline bool gemv_allow_lds(KernelT kernel, size_t bytes) {
-  if (bytes <= 64 * 1024) return true;          // more dynamic LDS has to be requested once per kernel
-  static bool done = false;
-  if (!done) {
-    if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) return false;
-    done = true;
-  }
-  return bytes <= 128 * 1024;
+// more than 64 KiB of dynamic LDS has to be requested once per kernel
+static inline bool gemv_allow_lds(const void* kernel, size_t bytes) {
+  if (bytes <= 64 * 1024) return true;
+  if (bytes > 160 * 1024) return false;
+  static const void* done[256];
+  static int n_done = 0;
+  for (int i = 0; i < n_done; ++i)
+    if (done[i] == kernel) return true;
+  if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
+  if (n_done < 256) done[n_done++] = kernel;
+  return true;
 }
 
+static inline int gemv_cu_count() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    n = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  return n;
+}
+
+// GEMV_CU_ENABLE: 0 = tile-per-workgroup kernels only (the attention combine then has no kernel), 1 = CU-resident form
+// wherever it applies, 2 = CU-resident form only where one workgroup per CU covers the grid anyway (N <= 16 * #CUs)
+#ifndef GEMV_CU_ENABLE
+#define GEMV_CU_ENABLE 0
+#endif
+
 template <int QT, int MT, bool GATE_UP>
-static int launch_x(const GemvArgs& a, hipStream_t st) {
+static int launch_x(const GemvArgs& a_in, hipStream_t st) {
+  GemvArgs a = a_in;
+  a.cu_ntc = 1;
   const dim3 grid((a.N + 15) / 16, a.slot_expert ? a.n_slots : 1);
   const int Kp = (a.K + 127) / 128 * 128;
   const size_t xbytes = (size_t)a.M * (Kp + XTAIL + XPAD) * 2;
-  auto fixed = [&](int nw, bool xlds = true) {
-    return (size_t)nw * (GATE_UP ? 2 : 1) * MT * 256 * 4 + 2 * MT * 16 * 4 + (QT == Q_NF4 ? 64 * 16 * 2 : 0) +
+  constexpr int NACC = GATE_UP ? 2 : 1;
+  auto misc = [&](int nw, bool xlds = true) {
+    return (size_t)2 * nw * MT * 16 * 4 + (QT == Q_NF4 ? 64 * 16 * 2 : 0) +
            (has_min_of(QT) && xlds ? (size_t)(Kp / 32 + XTAIL / 32) * MT * 16 * 4 : 0);
   };
+  // tile-per-workgroup kernels: partial-sum slots, staged scales (and minima) of the tile row
+  auto fixed = [&](int nw, bool xlds = true) {
+    return (size_t)nw * NACC * MT * 256 * 4 + misc(nw, xlds) +
+           (GEMV_SCLDS ? (size_t)(has_min_of(QT) ? 2 : 1) * NACC * (Kp / 128) * 128 : 0);
+  };
+  if constexpr (MT == 1) {
+    // CU-resident form: one workgroup per CU streams all its output tiles (see the kernel's comment).  Needs x and
+    // at least one tile's partial sums in LDS.
+    if (GEMV_CU_ENABLE && a.slot_expert == nullptr && (GEMV_CU_ENABLE == 1 || (a.N + 15) / 16 <= gemv_cu_count())) {
+      const int n_tiles = (a.N + 15) / 16;
+      const int G = n_tiles < gemv_cu_count() ? n_tiles : gemv_cu_count();
+      const int cnt_max = (n_tiles + G - 1) / G;
+      const size_t slot = (size_t)16 * NACC * ((a.M + 3) / 4) * 64 * 4;
+      const size_t budget = 150 * 1024;
+      if (xbytes + misc(16) + slot <= budget) {
+        size_t ntc = (budget - xbytes - misc(16)) / slot;
+        if (ntc > 16) ntc = 16;
+        if (ntc > (size_t)cnt_max) ntc = cnt_max;
+        a.cu_ntc = (int)ntc;
+        const size_t lds = ntc * slot + misc(16) + xbytes;
+        if (a.att_ws != nullptr) {
+          if constexpr (!GATE_UP) {
+            auto k = gemv_t16_kernel<QT, 1, false, true, 16, true, true>;
+            if (!gemv_allow_lds((const void*)k, lds)) return -5;
+            hipLaunchKernelGGL(k, dim3(G), dim3(1024), lds, st, a);
+            return HIP_CHECK_LAUNCH();
+          } else {
+            return -7;
+          }
+        }
+        auto k = gemv_t16_kernel<QT, 1, GATE_UP, true, 16, false, true>;
+        if (!gemv_allow_lds((const void*)k, lds)) return -5;
+        hipLaunchKernelGGL(k, dim3(G), dim3(1024), lds, st, a);
+        return HIP_CHECK_LAUNCH();
+      }
+    }
+  }
   // 16 wavefronts when the grid is small (about one workgroup per CU) and every wavefront still gets
   // at least two k-tiles: halves the per-wavefront instruction stream of the latency-bound small GEMVs
-  const bool wide = MT == 1 && !GATE_UP && xbytes <= GEMV_XLDS_LIMIT && grid.x <= 256 && Kp / 128 >= 64;
-  if (wide) {
-    if constexpr (MT == 1 && !GATE_UP)
-      hipLaunchKernelGGL((gemv_t16_kernel<QT, MT, GATE_UP, true, 16>), grid, dim3(1024), fixed(16) + xbytes, st, a);
-  } else if (xbytes <= GEMV_XLDS_LIMIT ||
-             (a.M <= 8 && xbytes <= GEMV_XLDS_LIMIT_FEW_ROWS && gemv_allow_lds(gemv_t16_kernel<QT, MT, GATE_UP, true, 8>, fixed(8) + xbytes))) {
-    hipLaunchKernelGGL((gemv_t16_kernel<QT, MT, GATE_UP, true, 8>), grid, dim3(512), fixed(8) + xbytes, st, a);
+  const bool wide = MT == 1 && !GATE_UP && xbytes <= GEMV_XLDS_LIMIT && grid.x <= 256 && grid.y == 1 && Kp / 128 >= 64;
+  if (a.att_ws != nullptr) {
+    // split-KV attention partials combined in the staging prologue (host entry: x fits GEMV_XLDS_LIMIT, at most 16 rows)
+    if constexpr (MT == 1 && !GATE_UP) {
+      if (wide) hipLaunchKernelGGL((gemv_t16_kernel<QT, 1, false, true, 16, true>), grid, dim3(1024), fixed(16) + xbytes, st, a);
+      else hipLaunchKernelGGL((gemv_t16_kernel<QT, 1, false, true, 8, true>), grid, dim3(512), fixed(8) + xbytes, st, a);
+      return HIP_CHECK_LAUNCH();
+    } else {
+      return -7;
+    }
+  }
+  if constexpr (MT == 1) {
+    if (wide) {
+      if constexpr (!GATE_UP) {
+        hipLaunchKernelGGL((gemv_t16_kernel<QT, 1, false, true, 16>), grid, dim3(1024), fixed(16) + xbytes, st, a);
+        return HIP_CHECK_LAUNCH();
+      }
+    }
+    // one or two rows of the usual hidden sizes: the lean kernel, three (gate/up: two and a half) workgroups per CU
+#ifndef GEMV_GU_LEAN
+#define GEMV_GU_LEAN 0
+#endif
+    if ((!GATE_UP || GEMV_GU_LEAN) && a.M * (((a.K + 511) / 512 + 7) / 8) <= 2 && a.ln_c1 == nullptr && xbytes <= GEMV_XLDS_LIMIT) {
+      hipLaunchKernelGGL((gemv_t16_kernel<QT, 1, GATE_UP, true, 8, false, false, true>), grid, dim3(512), fixed(8) + xbytes, st, a);
+      return HIP_CHECK_LAUNCH();
+    }
+  }
+  if (xbytes <= GEMV_XLDS_LIMIT ||
+      (a.M <= 8 && xbytes <= GEMV_XLDS_LIMIT_FEW_ROWS &&
+       gemv_allow_lds((const void*)gemv_t16_kernel<QT, MT, GATE_UP, true, GEMV_NW_MAIN>, fixed(GEMV_NW_MAIN) + xbytes))) {
+    hipLaunchKernelGGL((gemv_t16_kernel<QT, MT, GATE_UP, true, GEMV_NW_MAIN>), grid, dim3(GEMV_NW_MAIN * 64),
+                       fixed(GEMV_NW_MAIN) + xbytes, st, a);
   } else {
     if (a.ln_c1 != nullptr) return -7;     // the LayerNorm prologue lives in the LDS staging of x
     hipLaunchKernelGGL((gemv_t16_kernel<QT, MT, GATE_UP, false, 8>), grid, dim3(512), fixed(8, false), st, a);

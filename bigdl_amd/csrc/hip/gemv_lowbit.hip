@@ -58,7 +58,8 @@ static int gemv_lowbit_impl(const void* x, const void* w, const void* w2, void* 
   if (M > (w2 ? 32 : 64)) return -4;
   if (att_ws) {
     if (att_splits <= 0 || att_D <= 0 || (att_D & 7) || att_G <= 0 || att_Hkv <= 0 || att_qlen <= 0 || att_rows_alloc <= 0 ||
-        K != att_Hkv * att_G * att_D || M % att_qlen || att_G * att_qlen > att_rows_alloc || gamma || ((uintptr_t)att_ws & 15))
+        K != att_Hkv * att_G * att_D || M % att_qlen || att_G * att_qlen > att_rows_alloc || gamma || ((uintptr_t)att_ws & 15) ||
+        M > 16 || w2 != nullptr)
       return -7;
     // the combine is only implemented in the LDS staging prologue
     if ((size_t)M * ((K + 127) / 128 * 128 + XTAIL + XPAD) * 2 > GEMV_XLDS_LIMIT) return -7;

@@ -807,7 +807,8 @@ class NativeDecoder:
         g = cfg.num_heads // cfg.num_kv_heads
         rows = g * q_len
         kp = (cfg.q_size + 127) // 128 * 128
-        st["defer"] = splits > 1 and rows <= 32 and m * (kp + 136) * 2 <= 48 * 1024 and not os.environ.get("BIGDL_NO_DEFER")
+        st["defer"] = (splits > 1 and rows <= 32 and m <= 16 and m * (kp + 136) * 2 <= 48 * 1024
+                       and not os.environ.get("BIGDL_NO_DEFER"))
         st["att_partials"] = (st["ws"], splits, cfg.head_dim, g, cfg.num_kv_heads, q_len, (rows + 15) // 16 * 16)
         return st
 

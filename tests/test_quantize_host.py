@@ -174,3 +174,79 @@ def test_moe_indexes():
     offsets, perm = host.moe_indexes(sel, 4)
     assert offsets.tolist() == [0, 2, 4, 6, 6]
     assert perm.tolist() == [0, 4, 2, 5, 1, 3]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Independent oracles: the public ggml block formulas written out in numpy (the reference keeps the same formulas in
+# python/llm/src/ipex_llm/transformers/gguf/gguf.py:285-367), applied to the host-layout bytes our quantizer wrote.
+# ---------------------------------------------------------------------------------------------------------------
+def _f16(b):
+    return b.copy().view(np.float16).astype(np.float32)
+
+
+def _ggml_q4_1(buf):
+    b = buf.reshape(-1, 20)
+    d, m, qs = _f16(b[:, 0:2]), _f16(b[:, 2:4]), b[:, 4:]
+    q = np.concatenate([qs & 15, qs >> 4], axis=1).astype(np.float32)
+    return q * d + m
+
+
+def _ggml_q5_0(buf):
+    b = buf.reshape(-1, 22)
+    d, qh, qs = _f16(b[:, 0:2]), b[:, 2:6].copy().view(np.uint32), b[:, 6:]
+    j = np.arange(16, dtype=np.uint32)
+    lo = (qs & 15) | (((qh >> j) & 1) << 4).astype(np.uint8)
+    hi = (qs >> 4) | (((qh >> (j + 16)) & 1) << 4).astype(np.uint8)
+    return (np.concatenate([lo, hi], axis=1).astype(np.float32) - 16) * d
+
+
+def _ggml_q5_1(buf):
+    b = buf.reshape(-1, 24)
+    d, m, qh, qs = _f16(b[:, 0:2]), _f16(b[:, 2:4]), b[:, 4:8].copy().view(np.uint32), b[:, 8:]
+    j = np.arange(16, dtype=np.uint32)
+    lo = (qs & 15) | (((qh >> j) & 1) << 4).astype(np.uint8)
+    hi = (qs >> 4) | (((qh >> (j + 16)) & 1) << 4).astype(np.uint8)
+    return np.concatenate([lo, hi], axis=1).astype(np.float32) * d + m
+
+
+def _ggml_q8_0(buf):
+    b = buf.reshape(-1, 34)
+    return b[:, 2:].copy().view(np.int8).astype(np.float32) * _f16(b[:, 0:2])
+
+
+def _ggml_q6_k(buf):
+    b = buf.reshape(-1, 210)
+    ql, qh, sc, d = b[:, :128], b[:, 128:192], b[:, 192:208].copy().view(np.int8).astype(np.float32), _f16(b[:, 208:210])
+    out = np.zeros((b.shape[0], 256), dtype=np.float32)
+    for half in range(2):
+        l_ = ql[:, 64 * half: 64 * half + 64].astype(np.int32)
+        h_ = qh[:, 32 * half: 32 * half + 32].astype(np.int32)
+        s_ = sc[:, 8 * half: 8 * half + 8]
+        pos = np.arange(32)
+        isc = pos // 16
+        q1 = ((l_[:, :32] & 15) | (((h_ >> 0) & 3) << 4)) - 32
+        q2 = ((l_[:, 32:] & 15) | (((h_ >> 2) & 3) << 4)) - 32
+        q3 = ((l_[:, :32] >> 4) | (((h_ >> 4) & 3) << 4)) - 32
+        q4 = ((l_[:, 32:] >> 4) | (((h_ >> 6) & 3) << 4)) - 32
+        base = 128 * half
+        out[:, base: base + 32] = d * s_[:, isc] * q1
+        out[:, base + 32: base + 64] = d * s_[:, isc + 2] * q2
+        out[:, base + 64: base + 96] = d * s_[:, isc + 4] * q3
+        out[:, base + 96: base + 128] = d * s_[:, isc + 6] * q4
+    return out
+
+
+@pytest.mark.parametrize("name,oracle,qk", [("asym_int4", _ggml_q4_1, 32), ("sym_int5", _ggml_q5_0, 32),
+                                            ("asym_int5", _ggml_q5_1, 32), ("sym_int8", _ggml_q8_0, 32),
+                                            ("q6_k", _ggml_q6_k, 256)])
+def test_block_layout_matches_public_ggml_formula(name, oracle, qk):
+    torch.manual_seed(11)
+    qt = Q.ggml_tensor_qtype[name]
+    w = torch.randn(6, 512) * 0.3
+    buf = host.quantize(w, qt)
+    raw = (buf.view(torch.uint8) if buf.dtype != torch.uint8 else buf).numpy().reshape(-1)
+    ref = oracle(raw).reshape(6, 512)
+    deq = host.dequantize(torch.from_numpy(raw.copy()), qt, (6, 512)).numpy()
+    np.testing.assert_allclose(deq, ref, rtol=1e-6, atol=1e-7)
+    # and the codes are a sensible quantization of w, not merely self-consistent
+    assert _rel_rms(torch.from_numpy(ref), w) < REL_RMS[name]
