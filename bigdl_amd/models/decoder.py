@@ -103,9 +103,13 @@ def alibi_slopes(n_heads: int) -> torch.Tensor:
     return torch.tensor(v, dtype=torch.float32)
 
 
-def compute_inv_freq(cfg: DecoderConfig, device=None):
-    """inv_freq (fp32 [rot/2]) and the cos/sin scaling factor for the rope variants llama3 / linear /
-    dynamic-ntk(at max_position) / yarn / longrope(short factors)."""
+SUPPORTED_ROPE_TYPES = (None, "default", "linear", "llama3", "yarn", "longrope", "su")
+
+
+def compute_inv_freq(cfg: DecoderConfig, device=None, seq_len: Optional[int] = None):
+    """inv_freq (fp32 [rot/2]) and the cos/sin scaling factor for the rope variants llama3 / linear / yarn / longrope.
+    ``seq_len``: the longest position the table will serve; longrope switches from its short to its long factors once
+    that exceeds ``original_max_position_embeddings`` (HF modeling_rope_utils._compute_longrope_parameters)."""
     rot = cfg.rot_dim or cfg.head_dim
     inv = 1.0 / (cfg.rope_theta ** (torch.arange(0, rot, 2, dtype=torch.float32) / rot))
     scaling = 1.0
@@ -133,8 +137,14 @@ def compute_inv_freq(cfg: DecoderConfig, device=None):
         inv = inv / factor * ramp + inv * (1 - ramp)
         scaling = rs.get("attention_factor") or (0.1 * math.log(factor) + 1.0)
     elif kind in ("longrope", "su"):
-        short = torch.tensor(rs["short_factor"], dtype=torch.float32)
-        inv = inv / short
+        orig = rs.get("original_max_position_embeddings") or cfg.max_position
+        factor = cfg.max_position / orig if rs.get("original_max_position_embeddings") else float(rs.get("factor", 1.0))
+        use_long = seq_len is not None and seq_len > orig and "long_factor" in rs
+        ext = torch.tensor(rs["long_factor"] if use_long else rs["short_factor"], dtype=torch.float32)
+        inv = inv / ext
+        scaling = rs.get("attention_factor") or (1.0 if factor <= 1.0 else math.sqrt(1.0 + math.log(factor) / math.log(orig)))
+    elif kind not in (None, "default"):
+        raise NotImplementedError(f"rope scaling type {kind!r} is not implemented on the native engine")
     return inv.to(device) if device is not None else inv, scaling
 
 
@@ -352,6 +362,8 @@ class NativeDecoder:
             self.cache = KVCache(self.cfg, batch, cap, fp8, self.device)
             self._graphs.clear()
             self._static.clear()
+            # (longrope picks its factor set by the length the table has to serve)
+            self.inv_freq, self.rope_scaling_factor = compute_inv_freq(self.cfg, self.device, seq_len=needed)
             self._build_rope_table(self.cache.capacity)
             if self.cache.int4 and not self.fused_rope:
                 raise ValueError("the int4 KV cache needs the attention kernel's own RoPE + append (full or interleaved "
@@ -1004,6 +1016,8 @@ class NativeDecoder:
         greedy = not do_sample and repetition_penalty == 1.0
         times = []
         nxt = None
+        if streamer is not None:
+            streamer.put(input_ids.cpu())       # the prompt first, as HF generate does (skip_prompt drops exactly this)
         for step in range(max_new_tokens):
             if step > 0:
                 if greedy:
@@ -1045,6 +1059,10 @@ class NativeDecoder:
                 break
         if streamer is not None:
             streamer.end()
+        if self.tp_fast_allreduce is not None:
+            # the IPC all-reduce kernels give up on a peer after a bounded spin and flag it: never return tokens that
+            # were computed from a partial sum
+            self.tp_fast_allreduce.check()
         self.first_cost = self.first_token_time = times[0]
         self.last_token_time = times[1:]
         self.rest_cost_mean = sum(times[1:]) / max(1, len(times) - 1)

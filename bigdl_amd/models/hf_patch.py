@@ -362,7 +362,10 @@ def decoder_config_from_hf(cfg):
     if mt in ("mistral", "mixtral"):
         dc.sliding_window = int(getattr(cfg, "sliding_window", 0) or 0)
     if mt == "granite":
+        # (residual_multiplier has no engine equivalent: native_engine_supported sends such checkpoints to the HF path)
         dc.logit_scale = 1.0 / float(getattr(cfg, "logits_scaling", 1.0))
+        dc.embed_scale = float(getattr(cfg, "embedding_multiplier", 1.0))
+        dc.attn_scale = float(getattr(cfg, "attention_multiplier", None) or hd ** -0.5)
     if mt == "mixtral":
         dc.num_experts, dc.top_k = cfg.num_local_experts, cfg.num_experts_per_tok
         dc.moe_intermediate_size = cfg.intermediate_size
@@ -466,6 +469,12 @@ def native_engine_supported(model) -> bool:
     hd = getattr(cfg, "head_dim", None) or cfg.hidden_size // cfg.num_attention_heads
     if hd not in (64, 96, 128, 256):
         return False
+    if getattr(cfg, "model_type") == "granite" and float(getattr(cfg, "residual_multiplier", 1.0)) != 1.0:
+        return False          # the engine adds projection outputs to the residual stream unscaled
+    from .decoder import SUPPORTED_ROPE_TYPES
+    rs = getattr(cfg, "rope_scaling", None) or getattr(cfg, "rope_parameters", None) or {}
+    if rs.get("rope_type", rs.get("type")) not in SUPPORTED_ROPE_TYPES:
+        return False          # e.g. dynamic NTK: HF's own forward handles it
     if getattr(cfg, "model_type") in ("mixtral", "qwen2_moe"):
         try:
             from . import moe  # noqa: F401

@@ -74,12 +74,20 @@ def slice_param(p: FP4Params, rows=None, cols=None) -> FP4Params:
 
 
 def _parts_ranges(sizes, rank, world, unit):
-    """Row ranges that give this rank 1/world of every part of a merged projection (units = whole heads)."""
+    """Row ranges that give this rank 1/world of every part of a merged projection (units = whole heads).  A part with
+    fewer heads than ranks (the K / V heads of a grouped-query model at a high TP degree) is replicated instead:
+    ``world / heads`` consecutive ranks keep the same head, which is the kv head their query heads belong to."""
     out, off = [], 0
     for s in sizes:
-        assert s % (unit * world) == 0, f"cannot split {s // unit} heads over {world} ranks"
-        per = s // world
-        out.append((off + rank * per, off + (rank + 1) * per))
+        heads = s // unit
+        if heads < world and unit > 1:
+            assert world % heads == 0, f"cannot place {heads} heads on {world} ranks"
+            h = rank // (world // heads)
+            out.append((off + h * unit, off + (h + 1) * unit))
+        else:
+            assert s % (unit * world) == 0, f"cannot split {heads} heads over {world} ranks"
+            per = s // world
+            out.append((off + rank * per, off + (rank + 1) * per))
         off += s
     return out
 
@@ -167,14 +175,16 @@ def tensor_parallel(model, group=None, rank=None, world=None):
         if hasattr(att, "qkv_proj"):
             sizes = list(att._merged_sizes)
             shard_linear(att.qkv_proj, rank, world, "column", parts=sizes, unit=hd)
-            att._merged_sizes = tuple(s // world for s in sizes)
+            att._merged_sizes = tuple(max(s // world, hd) for s in sizes)
         else:
             for name in ("q_proj", "k_proj", "v_proj"):
                 shard_linear(getattr(att, name), rank, world, "column", unit=hd)
         shard_linear(att.o_proj, rank, world, "row", group=group)
         for a in ("num_heads", "num_key_value_heads"):
             if hasattr(att, a):
-                setattr(att, a, getattr(att, a) // world)
+                setattr(att, a, max(getattr(att, a) // world, 1))
+        if hasattr(att, "num_key_value_groups") and hasattr(att, "num_heads") and hasattr(att, "num_key_value_heads"):
+            att.num_key_value_groups = att.num_heads // att.num_key_value_heads
         mlp = layer.mlp
         if all(hasattr(mlp, n) for n in ("gate_proj", "up_proj", "down_proj")) and not hasattr(mlp, "num_experts"):
             shard_linear(mlp.gate_proj, rank, world, "column")
@@ -239,7 +249,8 @@ def shard_engine(engine, rank: int, world: int, group=None, fast_allreduce=None)
         return engine
     cfg = engine.cfg
     hd = cfg.head_dim
-    assert cfg.num_heads % world == 0 and cfg.num_kv_heads % world == 0, "heads must divide the TP degree"
+    assert cfg.num_heads % world == 0, "query heads must divide the TP degree"
+    assert cfg.num_kv_heads % world == 0 or world % cfg.num_kv_heads == 0, "kv heads must divide, or be divided by, the TP degree"
     q, kv = cfg.q_size, cfg.kv_size
     for lw in engine.layers:
         if lw.mla is not None:
@@ -249,10 +260,11 @@ def shard_engine(engine, rank: int, world: int, group=None, fast_allreduce=None)
         if lw.moe is not None:
             lw.moe.shard_experts(rank, world, group)
         else:
-            lw.gate = _shard_lin(lw.gate, rank, world, "column")
+            if lw.gate is not None:        # (LayerNorm families have no gate projection)
+                lw.gate = _shard_lin(lw.gate, rank, world, "column")
             lw.up = _shard_lin(lw.up, rank, world, "column")
             lw.down = _shard_lin(lw.down, rank, world, "row")
-    engine.cfg = dataclasses.replace(cfg, num_heads=cfg.num_heads // world, num_kv_heads=cfg.num_kv_heads // world,
+    engine.cfg = dataclasses.replace(cfg, num_heads=cfg.num_heads // world, num_kv_heads=max(cfg.num_kv_heads // world, 1),
                                      intermediate_size=cfg.intermediate_size // world)
     if getattr(engine, "alibi", None) is not None:
         per = cfg.num_heads // world

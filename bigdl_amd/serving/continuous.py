@@ -90,6 +90,8 @@ class ContinuousBatcher:
 
     # ------------------------------------------------------------------ queue
     def submit(self, req: SeqRequest) -> SeqRequest:
+        if len(req.input_ids) == 0:
+            raise ValueError(f"request {req.request_id}: empty prompt")
         if len(req.input_ids) + req.max_new_tokens > self.cache.capacity:
             raise ValueError(f"request {req.request_id}: prompt + max_new_tokens exceeds the slot capacity "
                              f"({self.cache.capacity})")
@@ -100,6 +102,24 @@ class ContinuousBatcher:
 
     def has_work(self) -> bool:
         return bool(self.waiting or self.running or self._prefilling)
+
+    def fail_all(self, reason: str = "error"):
+        """After an exception inside ``step``: finish every admitted request (running, being prefilled) with
+        ``finish_reason = reason``, free their slots and leave the batcher ready for new work.  Returns the failed
+        requests; waiting requests stay queued.  Without this a failing step leaves ``has_work()`` true for ever."""
+        failed = list(self.running.values())
+        if self._prefilling is not None:
+            failed.append(self._prefilling[0])
+            self._prefilling = None
+        now = time.perf_counter()
+        for req in failed:
+            req.finished, req.finish_reason, req.finish_time = True, reason, now
+            if req.slot is not None:
+                self.cache.set_active(req.slot, False)
+                self.running.pop(req.slot, None)
+                if req.slot not in self.free_slots:
+                    self.free_slots.append(req.slot)
+        return failed
 
     # ------------------------------------------------------------------ one iteration
     def _token_buffer(self):

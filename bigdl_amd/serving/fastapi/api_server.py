@@ -10,6 +10,7 @@ import asyncio
 import os
 import json
 import uuid
+import logging
 from typing import List, Optional
 
 from fastapi import FastAPI, HTTPException
@@ -22,6 +23,8 @@ from .openai_protocol import (ChatCompletionRequest, ChatCompletionResponse, Cha
                               CompletionRequest, CompletionResponse, CompletionResponseChoice, CompletionStreamResponse,
                               DeltaMessage, ModelCard, ModelList, UsageInfo)
 from .tgi_protocol import GenerateResponse, InputsRequest, Parameters
+
+logger = logging.getLogger(__name__)
 
 
 def get_prompt(messages, tokenizer=None) -> str:
@@ -99,19 +102,32 @@ class FastApp:
         self.name = served_model_name
         self.default_max = max_new_tokens_default
         self.token_timeout = float(os.environ.get("IPEX_LLM_FASTAPI_TIMEOUT", 60))
+        self.max_consecutive_errors = int(os.environ.get("BIGDL_SERVING_MAX_ERRORS", 8))
+        self.loop_dead = False
         self.app = FastAPI(title="bigdl_amd lightweight serving")
         self._task = None
         self._routes()
 
     # ---------------------------------------------------------------------------------------
     async def _loop(self):
+        """Drives the worker.  A failed step is logged with its traceback and the loop goes on (the worker has already
+        failed the requests the step carried); ``max_consecutive_errors`` failures in a row mean the worker cannot make
+        progress at all (device fault, corrupted state): the loop stops and ``/health`` reports it instead of spinning."""
+        errors = 0
         while True:
             try:
                 await self.worker.process_step()
+                errors = 0
             except asyncio.CancelledError:
                 break
-            except Exception:                       # keep serving after a failed request
-                await asyncio.sleep(0)
+            except Exception:
+                errors += 1
+                logger.exception("serving step failed (%d in a row)", errors)
+                if errors >= self.max_consecutive_errors:
+                    self.loop_dead = True
+                    logger.error("serving loop stopped after %d consecutive failures", errors)
+                    break
+                await asyncio.sleep(min(0.05 * errors, 1.0))
 
     def _request(self, prompt, p: Parameters) -> Request:
         return Request(request_id=uuid.uuid4().hex, prompt=prompt, max_new_tokens=p.max_new_tokens or self.default_max,
@@ -177,6 +193,8 @@ class FastApp:
 
         @app.get("/health")
         async def health():
+            if self.loop_dead:
+                return JSONResponse({"status": "failed", "detail": "serving loop stopped after repeated errors"}, status_code=503)
             return JSONResponse({"status": "ok", "waiting": self.worker.waiting_requests.qsize()})
 
         @app.get("/v1/models")

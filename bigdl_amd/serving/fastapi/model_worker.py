@@ -68,6 +68,10 @@ class _QueueStreamer:
         text = self.tokenizer.decode(self.tokens, skip_special_tokens=True)
         self._emit((text[self.printed:], True))
 
+    def fail(self, message: str):
+        """Close the stream with an error note instead of leaving the client to its token timeout."""
+        self._emit((message, True))
+
 
 class ModelWorker:
     def __init__(self, checkpoint=None, low_bit="sym_int4", model_type="normal", torch_dtype=torch.float16, model=None,
@@ -211,10 +215,20 @@ class BatchedModelWorker(ModelWorker):
 
     def _iterate(self):
         t0 = time.time()
-        with torch.inference_mode():
-            self.batcher.step()
-        with self._lock:
-            self.stats["busy_s"] += time.time() - t0
+        try:
+            with torch.inference_mode():
+                self.batcher.step()
+        except Exception as e:
+            # a failed iteration (capacity assert, device error): end the requests it carried instead of leaving them
+            # to the client-side token timeout with their slots held, then let the serving loop see the error
+            for seq in self.batcher.fail_all("error"):
+                st = self._text.pop(seq.request_id, None)
+                if st is not None:
+                    st.fail(f"[generation failed: {type(e).__name__}: {e}]")
+            raise
+        finally:
+            with self._lock:
+                self.stats["busy_s"] += time.time() - t0
 
     async def process_step(self):
         if self.batcher is None:

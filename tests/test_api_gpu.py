@@ -276,3 +276,44 @@ def test_attention_registry_reaches_flash_kernel(family, monkeypatch):
         assert gen.shape == (1, 13)
     assert calls["n"] >= 2, "the flash kernel was not reached"
     assert _rel(out, ref) < 0.03
+
+
+def test_granite_multipliers_and_streamed_prompt(tmp_path):
+    """Granite checkpoints scale the embedding, the attention scores and the logits: the native engine takes the first
+    three from the config (engine logits = HF module logits); a residual multiplier sends the model to the HF path.
+    A streamer with skip_prompt=True sees exactly the generated tokens (the prompt is put first, as HF generate does)."""
+    from transformers import GraniteConfig, GraniteForCausalLM, TextIteratorStreamer
+    from ipex_llm.transformers import AutoModelForCausalLM
+    from bigdl_amd.models.hf_patch import native_engine_supported
+    torch.manual_seed(0)
+    cfg = GraniteConfig(vocab_size=320, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                        num_key_value_heads=2, max_position_embeddings=512, embedding_multiplier=6.0,
+                        attention_multiplier=0.07, logits_scaling=4.0, residual_multiplier=1.0, tie_word_embeddings=False)
+    d = str(tmp_path / "granite")
+    GraniteForCausalLM(cfg).eval().save_pretrained(d)
+    q = AutoModelForCausalLM.from_pretrained(d, load_in_low_bit="sym_int8").half().to("cuda")
+    assert native_engine_supported(q)
+    ids = torch.randint(0, 320, (1, 12)).cuda()
+    out = q.generate(ids, max_new_tokens=6, do_sample=False)
+    eng = q._native_engine
+    eng.cache.reset()
+    lg = eng.prefill(ids, last_only=False)[:, :9].float()
+    with torch.no_grad():
+        ref = q(ids[:, :9]).logits.float()
+    assert _rel(lg, ref) < 0.02
+
+    class Tok:          # the streamer only needs decode()
+        def decode(self, toks, **kw):
+            return "".join(f"<{int(t)}>" for t in toks)
+    st = TextIteratorStreamer(Tok(), skip_prompt=True)
+    out2 = q.generate(ids, max_new_tokens=6, do_sample=False, streamer=st)
+    text = "".join(st)
+    assert text == Tok().decode(out2[0, 12:])
+    assert torch.equal(out, out2)
+
+    cfg.residual_multiplier = 0.5
+    d2 = str(tmp_path / "granite_res")
+    GraniteForCausalLM(cfg).eval().save_pretrained(d2)
+    q2 = AutoModelForCausalLM.from_pretrained(d2, load_in_low_bit="sym_int8").half().to("cuda")
+    assert not native_engine_supported(q2)
+    assert q2.generate(ids, max_new_tokens=3, do_sample=False).shape == (1, 15)

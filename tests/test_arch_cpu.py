@@ -278,3 +278,38 @@ def test_quantized_cpu_model_and_checkpoint_round_trip(case, tmp_path):
     assert torch.equal(again.generate(ids, max_new_tokens=4), out)
     with pytest.raises(Exception):
         AutoModelForCausalLM.from_pretrained(str(tmp_path / "lb"))      # "Please use load_low_bit"
+
+
+def test_longrope_factors_and_unsupported_rope_types():
+    """longrope: short factors + attention factor below the original context, long factors above it, both equal to HF's
+    ROPE_INIT_FUNCTIONS; rope types without an engine implementation are refused instead of silently unscaled."""
+    import math
+    import pytest
+    from bigdl_amd.models.decoder import DecoderConfig, compute_inv_freq
+    rot = 32
+    short = [1.0 + 0.01 * i for i in range(rot // 2)]
+    long_ = [2.0 + 0.05 * i for i in range(rot // 2)]
+    rs = dict(rope_type="longrope", short_factor=short, long_factor=long_, original_max_position_embeddings=128)
+    cfg = DecoderConfig(vocab_size=32, hidden_size=64, intermediate_size=64, num_layers=1, num_heads=2, num_kv_heads=2,
+                        head_dim=rot, max_position=1024, rope_scaling=rs)
+    base = 1.0 / (10000.0 ** (torch.arange(0, rot, 2, dtype=torch.float32) / rot))
+    want_factor = math.sqrt(1 + math.log(1024 / 128) / math.log(128))
+    inv_s, f_s = compute_inv_freq(cfg, seq_len=100)
+    inv_l, f_l = compute_inv_freq(cfg, seq_len=500)
+    torch.testing.assert_close(inv_s, base / torch.tensor(short))
+    torch.testing.assert_close(inv_l, base / torch.tensor(long_))
+    assert abs(f_s - want_factor) < 1e-6 and abs(f_l - want_factor) < 1e-6
+    try:
+        from transformers.modeling_rope_utils import ROPE_INIT_FUNCTIONS
+        from transformers import Phi3Config
+        hf = Phi3Config(hidden_size=64, num_attention_heads=2, max_position_embeddings=1024,
+                        original_max_position_embeddings=128, pad_token_id=0,
+                        rope_scaling=dict(type="longrope", short_factor=short, long_factor=long_))
+        inv_hf, f_hf = ROPE_INIT_FUNCTIONS["longrope"](hf, "cpu", seq_len=500)
+        torch.testing.assert_close(inv_l, inv_hf)
+        assert abs(f_hf - f_l) < 1e-6
+    except (ImportError, KeyError, TypeError):
+        pass
+    cfg.rope_scaling = dict(rope_type="dynamic", factor=2.0)
+    with pytest.raises(NotImplementedError):
+        compute_inv_freq(cfg)

@@ -153,3 +153,38 @@ def test_capacity_is_checked_at_submit():
     except ValueError:
         return
     raise AssertionError("over-capacity request was accepted")
+
+
+def test_failed_step_releases_requests_and_slots():
+    """An exception inside step() must not leave has_work() true for ever: fail_all() ends the admitted requests, frees
+    their slots and the batcher serves the next request normally; empty prompts are refused at submit."""
+    eng = _FakeEngine()
+    cb = ContinuousBatcher(eng, max_num_seqs=2, max_seq_len=32)
+    a = cb.submit(SeqRequest("a", [1, 2, 3], max_new_tokens=4))
+    b = cb.submit(SeqRequest("b", [4, 5], max_new_tokens=4))
+    cb.step()
+    cb.step()
+    assert cb.running
+
+    def boom(*args, **kw):
+        raise RuntimeError("device fault")
+    good_decode, eng.decode = eng.decode, boom
+    try:
+        while cb.has_work():
+            cb.step()
+        raise AssertionError("the failing step did not raise")
+    except RuntimeError:
+        failed = cb.fail_all("error")
+    assert {r.request_id for r in failed} <= {"a", "b"} and failed
+    assert all(r.finished and r.finish_reason == "error" for r in failed)
+    assert not cb.has_work() and sorted(cb.free_slots) == [0, 1]
+    eng.decode = good_decode
+    c = cb.submit(SeqRequest("c", [9, 9], max_new_tokens=3))
+    while cb.has_work():
+        cb.step()
+    assert c.output_ids == _expected([9, 9], 3)
+    try:
+        cb.submit(SeqRequest("empty", [], max_new_tokens=3))
+    except ValueError:
+        return
+    raise AssertionError("empty prompt was accepted")

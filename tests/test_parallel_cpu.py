@@ -69,6 +69,32 @@ def _tp_worker(rank, port, low_bit, tmp):
     dist.destroy_process_group()
 
 
+def _tp_kv_replica_worker(rank, port, tmp):
+    """fewer kv heads than ranks: every rank keeps the kv head its query heads belong to"""
+    _boot(rank, port)
+    from bigdl_amd.optimize import optimize_model
+    from bigdl_amd.parallel.tensor_parallel import tensor_parallel
+    torch.manual_seed(0)
+    cfg = LlamaConfig(vocab_size=320, hidden_size=128 * WORLD, intermediate_size=256 * WORLD, num_hidden_layers=2,
+                      num_attention_heads=2 * WORLD, num_key_value_heads=1, max_position_embeddings=256,
+                      tie_word_embeddings=False)
+    full = optimize_model(LlamaForCausalLM(cfg).eval(), low_bit="sym_int8")
+    ids = torch.load(os.path.join(tmp, "ids.pt"))
+    with torch.no_grad():
+        ref = full(ids).logits
+        out = tensor_parallel(copy.deepcopy(full))(ids).logits
+    rel = ((out - ref).abs().mean() / ref.abs().mean()).item()
+    assert rel < 2e-3, rel
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_tensor_parallel_replicates_kv_heads_when_ranks_outnumber_them(tmp_path):
+    torch.manual_seed(1)
+    torch.save(torch.randint(0, 320, (2, 9)), tmp_path / "ids.pt")
+    _run(_tp_kv_replica_worker, str(tmp_path))
+
+
 @pytest.mark.parametrize("low_bit", ["sym_int4", "q4_k", "bf16"])
 def test_tensor_parallel_matches_single_process(tmp_path, low_bit):
     torch.manual_seed(1)
