@@ -59,7 +59,7 @@ def random_lowbit_llama(cfg, qtype, device, skip=("lm_head",), seed=0):
     return model
 
 
-def main():
+def main(process_group_ready: bool = False):
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
@@ -68,11 +68,14 @@ def main():
     ap.add_argument("--low-bit", default="nf4")
     ap.add_argument("--model", default="llama2-7b", choices=["llama2-7b", "tiny"])
     ap.add_argument("--grad-ckpt", action="store_true")
+    ap.add_argument("--full-targets", action="store_true",
+                    help="LoRA on all seven projections (q, k, v, o, gate, up, down) as in the reference's alpaca-qlora "
+                         "recipe (alpaca_qlora_finetuning.py:80-88) instead of q/k/v only")
     args = ap.parse_args()
     rank, local, world = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("LOCAL_RANK", 0), ("WORLD_SIZE", 1)))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 and not process_group_ready:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
     from transformers import LlamaConfig
@@ -89,7 +92,8 @@ def main():
     model = random_lowbit_llama(cfg, Q.ggml_tensor_qtype[args.low_bit], dev)
     model.train()
     model = prepare_model_for_kbit_training(model, use_gradient_checkpointing=args.grad_ckpt)
-    model = get_peft_model(model, LoraConfig(r=8, lora_alpha=32, target_modules=["q_proj", "k_proj", "v_proj"],
+    targets = ["q_proj", "k_proj", "v_proj"] + (["o_proj", "gate_proj", "up_proj", "down_proj"] if args.full_targets else [])
+    model = get_peft_model(model, LoraConfig(r=8, lora_alpha=32, target_modules=targets,
                                              lora_dropout=0.05, bias="none", task_type="CAUSAL_LM", training_mode="qlora"))
     params = [p for p in model.parameters() if p.requires_grad]
     opt = torch.optim.AdamW(params, lr=2e-5)
@@ -118,7 +122,16 @@ def main():
     sync()
     dt = (time.perf_counter() - t0) / args.steps
     if rank == 0:
-        print(json.dumps({"bench": "qlora_train_step", "model": args.model, "low_bit": args.low_bit, "n_gpus": world,
+        print(json.dumps({"metric": "QLoRA finetune step time (s/it), %s %s, batch %d x %d tokens per GPU" %
+                                    (args.low_bit, "Llama-2-7B" if args.model == "llama2-7b" else "test-size llama", args.batch, args.seq_len),
+                          "value": round(dt, 4), "unit": "s/it", "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(dt * 1e3, 2), "higher_is_better": False, "scaling": "weak",
+                          "vs_baseline": round(dt / 1.40, 4) if args.model == "llama2-7b" and not args.full_targets else None,
+                          "dtype": "bf16 compute, %s base weights" % args.low_bit, "data": "synthetic",
+                          "config": {"model": args.model + " (random-init)", "global_batch": world * args.batch,
+                                     "seq_len": args.seq_len, "parallelism": f"dp{world}" if world > 1 else "single",
+                                     "lora_targets": targets, "lora_r": 8},
+                          "bench": "qlora_train_step", "model": args.model, "low_bit": args.low_bit, "n_gpus": world,
                           "per_device_batch": args.batch, "seq_len": args.seq_len, "s_per_it": round(dt, 4),
                           "samples_per_s": round(world * args.batch / dt, 2),
                           "tokens_per_s": round(world * args.batch * args.seq_len / dt, 1),
@@ -126,7 +139,7 @@ def main():
                           "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
                           "reference_published": {"s_per_it": 1.40, "samples_per_s": 2.864,
                                                   "hardware": "1 Intel GPU (unnamed), english_quotes, batch 4"}}))
-    if world > 1:
+    if world > 1 and not process_group_ready:
         torch.distributed.destroy_process_group()
 
 

@@ -342,6 +342,10 @@ class NativeDecoder:
             sl = torch.tensor(cfg.alibi_slopes, dtype=torch.float32) if cfg.alibi_slopes else alibi_slopes(cfg.num_heads)
             self.alibi = sl.to(self.device).contiguous()
         self.use_graph = True
+        # pipeline stages (bigdl_amd/parallel/pipeline.py): a stage that is not the first takes hidden states instead of
+        # token ids, a stage that is not the last returns hidden states instead of logits
+        self.stage_first = True
+        self.stage_last = True
         if os.environ.get("BIGDL_PREFILL_DENSE_CACHE") == "1":
             Lin.cache_dense = True
         # tensor parallelism (bigdl_amd/parallel/tensor_parallel.py ``shard_engine``): partial sums of the
@@ -429,8 +433,8 @@ class NativeDecoder:
         return self._tp_reduce(self._linear_dense(g, lw.down))
 
     @torch.no_grad()
-    def prefill(self, input_ids: torch.Tensor, last_only: bool = True, slot: Optional[int] = None,
-                with_decode: bool = False):
+    def prefill(self, input_ids: Optional[torch.Tensor], last_only: bool = True, slot: Optional[int] = None,
+                with_decode: bool = False, hidden: Optional[torch.Tensor] = None):
         """input_ids [B, S] (device).  Fills the cache from position past_len and returns logits
         ([B, 1, V] if last_only else [B, S, V]).  With ``slot`` (continuous batching) input_ids is one sequence
         [1, S] that is appended to cache row ``slot`` only.
@@ -444,7 +448,11 @@ class NativeDecoder:
         slot by one token exactly like ``decode(None, 1, chain=True)``."""
         from ..ops import hip
         cfg, cache = self.cfg, self.cache
-        b, s = input_ids.shape
+        if not self.stage_first:
+            assert hidden is not None and not with_decode, "a later pipeline stage is fed hidden states [B, S, hidden]"
+            b, s = hidden.shape[:2]
+        else:
+            b, s = input_ids.shape
         if slot is not None:
             assert b == 1 and cache.slot_len is not None, "slot prefill takes one sequence on a cache in slot mode"
             past = cache.slot_len[slot]
@@ -458,16 +466,19 @@ class NativeDecoder:
             assert max(cache.slot_len) + 1 <= cache.capacity, "KV cache capacity exceeded"
             nd = cache.batch
             st = self._get_graph(nd, 1, True)[1]         # the decode step's static buffers: tokens, workspace
-        h = F.embedding(input_ids, self.embed).to(torch.float16)
-        if cfg.embed_scale != 1.0:
-            h = h * cfg.embed_scale
-        h = h.reshape(b * s, cfg.hidden_size)
-        pos = torch.arange(past, past + s, device=self.device)[None].expand(b, s)
-        if nd:
-            hd = F.embedding(st["tokens"].view(-1), self.embed).to(torch.float16)
-            h = torch.cat([h, hd * cfg.embed_scale if cfg.embed_scale != 1.0 else hd])
-            pos = torch.cat([pos.reshape(-1), cache.past_len.to(torch.int64)])
-        h = self._embed_extras(h, pos.reshape(-1))
+        if self.stage_first:
+            h = F.embedding(input_ids, self.embed).to(torch.float16)
+            if cfg.embed_scale != 1.0:
+                h = h * cfg.embed_scale
+            h = h.reshape(b * s, cfg.hidden_size)
+            pos = torch.arange(past, past + s, device=self.device)[None].expand(b, s)
+            if nd:
+                hd = F.embedding(st["tokens"].view(-1), self.embed).to(torch.float16)
+                h = torch.cat([h, hd * cfg.embed_scale if cfg.embed_scale != 1.0 else hd])
+                pos = torch.cat([pos.reshape(-1), cache.past_len.to(torch.int64)])
+            h = self._embed_extras(h, pos.reshape(-1))
+        else:
+            h = hidden.to(torch.float16).reshape(b * s, cfg.hidden_size)
         hq, hkv, d = cfg.num_heads, cfg.num_kv_heads, cfg.head_dim
         for li, lw in enumerate(self.layers):
             x = self._norm(h, lw.input_norm, lw.input_norm_b)
@@ -538,6 +549,8 @@ class NativeDecoder:
             cache.slot_len = [n + a for n, a in zip(cache.slot_len, cache.active_host)]
             return logits[:1].view(1, 1, cfg.vocab_size), st["logits"], st["tokens"].view(-1)
         h = h.view(b, s, -1)
+        if not self.stage_last:
+            return h                         # every position: the next stage needs them all for its own cache
         if last_only:
             h = h[:, -1:, :]
         x = self._norm(h.reshape(-1, cfg.hidden_size), self.final_norm, self.final_norm_b)
@@ -798,9 +811,13 @@ class NativeDecoder:
         splits = max(1, min(max_splits, (256 + batch * cfg.num_kv_heads - 1) // (batch * cfg.num_kv_heads), 16))
         if os.environ.get("BIGDL_ATTN_SPLITS"):
             splits = max(1, min(max_splits, int(os.environ["BIGDL_ATTN_SPLITS"])))
+        # the residual stream is the payload of the message a pipeline stage hands to the next one; 8 spare halves behind
+        # it carry the stop flag (bigdl_amd/parallel/pipeline.py)
+        msg = torch.zeros(m * cfg.hidden_size + 8, dtype=torch.float16, device=dev)
         st = {
             "tokens": torch.zeros(batch, q_len, dtype=torch.int64, device=dev),
-            "h": torch.zeros(m, cfg.hidden_size, dtype=torch.float16, device=dev),
+            "msg": msg,
+            "h": msg[: m * cfg.hidden_size].view(m, cfg.hidden_size),
             "qkv": torch.zeros(m, cfg.q_size + 2 * cfg.kv_size, dtype=torch.float16, device=dev),
             "attn": torch.zeros(m, cfg.q_size, dtype=torch.float16, device=dev),
             "act": torch.zeros(m, max(cfg.intermediate_size, cfg.moe_intermediate_size, 8), dtype=torch.float16, device=dev),
@@ -877,12 +894,14 @@ class NativeDecoder:
         from ..ops import hip
         cfg, cache = self.cfg, self.cache
         h, qkv, attn, act, tmp = st["h"], st["qkv"], st["attn"], st["act"], st["tmp"]
-        if cfg.embed_scale != 1.0 or self.embed.dtype != h.dtype:
+        if not self.stage_first:
+            pass                              # st["h"] holds the previous stage's output
+        elif cfg.embed_scale != 1.0 or self.embed.dtype != h.dtype:
             h.copy_(F.embedding(st["tokens"].view(-1), self.embed) * cfg.embed_scale)
         else:
             torch.index_select(self.embed, 0, st["tokens"].view(-1), out=h)      # gather straight into the residual stream
         layer_norm = cfg.norm == "layer"
-        if self.pos_embed is not None or self.embed_norm is not None:
+        if self.stage_first and (self.pos_embed is not None or self.embed_norm is not None):
             pos = cache.past_len.to(torch.int64)[:, None] + torch.arange(q_len, device=self.device)[None]
             h.copy_(self._embed_extras(h, pos.reshape(-1)))
         for li, lw in enumerate(self.layers):
@@ -933,6 +952,9 @@ class NativeDecoder:
                 if lw.post_ffn_out_norm is not None:
                     hip.rms_norm(tmp, lw.post_ffn_out_norm, cfg.rms_eps, offset=cfg.norm_offset, out=tmp)
                 h.add_(tmp)
+        if not self.stage_last:
+            cache.past_len.add_(cache.active, alpha=q_len)
+            return
         self._gemv(h, self.lm_head, st["logits"], gamma=self.final_norm, beta=self.final_norm_b if layer_norm else False)
         if cfg.logit_scale != 1.0 or cfg.final_softcap > 0:
             st["logits"].copy_(self._finish_logits(st["logits"]))
@@ -1071,12 +1093,13 @@ class NativeDecoder:
 
     def dense_copy_bytes(self):
         """HBM an fp16 copy of every fused linear takes (what ``Lin.cache_dense`` keeps resident for the prompt GEMMs)"""
-        lins = [self.lm_head] + [lin for lw in self.layers for lin in (lw.qkv, lw.o, lw.gate, lw.up, lw.down)]
+        lins = [self.lm_head] * (self.lm_head is not None) + [lin for lw in self.layers for lin in (lw.qkv, lw.o, lw.gate, lw.up, lw.down)]
         lins += [lin for lw in self.layers if lw.mla is not None for lin in lw.mla.lins()]
         return sum(2 * lin.n * lin.k for lin in lins if lin is not None and lin.fused)
 
     def weight_bytes(self):
-        tot = self.embed.numel() * self.embed.element_size() + self.lm_head.nbytes
+        tot = 0 if self.embed is None else self.embed.numel() * self.embed.element_size()
+        tot += 0 if self.lm_head is None else self.lm_head.nbytes
         for lw in self.layers:
             for lin in (lw.qkv, lw.o, lw.gate, lw.up, lw.down):
                 if lin is not None:

@@ -105,7 +105,9 @@ def is_lm_head(name, model_config, out_features):
     if name in ("lm_head", "output_layer", "embed_out"):
         return True
     vocab = getattr(model_config, "vocab_size", None) if model_config is not None else None
-    return vocab is not None and out_features == vocab and name not in ("embed_tokens", "word_embeddings")
+    # (a merged qkv / gate-up projection whose width happens to equal the vocabulary is not an output head)
+    return vocab is not None and out_features == vocab and name not in ("embed_tokens", "word_embeddings") \
+        and not name.endswith("_proj") and "qkv" not in name
 
 
 # --------------------------------------------------------------------------------------------

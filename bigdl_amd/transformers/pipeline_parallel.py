@@ -267,16 +267,29 @@ def make_attention_mask(prompt_lengths, device):
     return mask
 
 
+KIND_STEP, KIND_FREE, KIND_STOP = 1, 2, 3
+HEADER_FIXED = 8          # [kind, serial, batch_size, n_tokens, step_no, max_tokens, 0, 0] + prompt lengths
+
+
 class PPModelWorker:
     """Continuous-batching worker for one pipeline stage.
 
-    The head stage admits requests (up to ``max_num_seqs`` sequences per micro-batch), runs its layers and sends the
-    hidden states on; the tail stage samples and sends the tokens back to the head, which appends them and schedules
-    the next step.  Up to ``pp_world_size`` micro-batches are in flight so that every stage has work.
+    The head stage admits requests (up to ``max_num_seqs`` sequences per micro-batch; ``max_prefilled_seqs`` > 0 caps the
+    sequences a newly admitted micro-batch may hold, which bounds the size of one prompt pass), runs its layers and sends
+    the hidden states on; the tail stage picks the tokens and sends them straight back to the head, which appends them
+    and schedules the next step.  Up to ``pp_world_size`` micro-batches are in flight, so in steady state every stage has
+    a micro-batch to work on at every tick.
+
+    Control travels with the data: each hidden-state message is preceded by a small integer header (kind, serial
+    number, shapes, step), so no stage takes part in a collective or an object broadcast per token; a FREE header drops
+    a finished micro-batch's cache on every stage and a STOP header ends the serving loops.  Sends are asynchronous and
+    their buffers are only released once the transfer has completed.
     """
 
     def __init__(self, checkpoint, rank, world_size, low_bit, max_num_seqs, max_prefilled_seqs=0,
-                 torch_dtype=torch.float16, model=None, tokenizer=None):
+                 torch_dtype=torch.float16, model=None, tokenizer=None, link=None):
+        from collections import deque
+        from ..parallel.p2p import PipelineLink
         self.pp_config = PPConfig(rank, world_size)
         self.dtype = torch_dtype
         self.rank, self.world_size = rank, world_size
@@ -286,18 +299,28 @@ class PPModelWorker:
         self.model = model if model is not None else self.load_model(checkpoint, world_size, low_bit)
         self.device = next(p for p in self.model.parameters() if p.numel() > 0).device
         self.tokenizer = tokenizer
+        self.link = link if link is not None else (PipelineLink(stage=rank) if world_size > 1 else None)
         self.waiting_requests = asyncio.Queue()
         self.kv_caches = {}                 # batch_id -> cache
         self.positions = {}                 # batch_id -> tokens already in the cache
-        self.tokens = {}                    # batch_id -> [B, generated] (head)
+        self.tokens = {}                    # batch_id -> list of [B, 1] token tensors (head)
         self.token_times = {}
         self.streamer = {}                  # request_id -> asyncio.Queue of text deltas
         self.token_cache = {}
         self.print_len = {}
         self.is_finish = {}
-        self.on_going_batches = [None] * world_size
+        self.inflight = deque()             # head: micro-batches whose tokens are still to come back, oldest first
+        self.on_going_batches = self.inflight
+        self.results = {}                   # head: batch_id -> generated ids [B, T] of finished micro-batches
         self.input_ids_dict = {}
         self.attention_mask_dict = {}
+        self._sends = deque()               # (work, tensor) of transfers not known to have completed
+        self._local_tokens = deque()        # single-stage pipeline: the head is its own tail
+        self._serial = 0
+        self.stopped = False
+        self.trace = []                     # (serial, step_no) of every stage step this rank ran
+        self.stats = dict(requests=0, prompt_tokens=0, generated_tokens=0, busy_s=0.0, first_token_s=[], per_token_s=[])
+        self.max_inflight = 0
         self.clean_cache()
 
     def load_model(self, model_path, world_size, low_bit="sym_int4"):
@@ -329,6 +352,8 @@ class PPModelWorker:
         n = inp.shape[1]
         bs = inp.shape[0]
         am = self.attention_mask_dict.get(bid)
+        if am is None and past == 0 and len(set(cur_batch.prompt_lengths)) > 1:
+            am = make_attention_mask(cur_batch.prompt_lengths, self.device)
         if am is not None:
             grow = past + n - am.shape[1]
             if grow > 0:
@@ -350,14 +375,59 @@ class PPModelWorker:
     def is_initialized(self):
         return True
 
+    # -- transport ------------------------------------------------------------------------------
+    def _header_device(self):
+        return self.device if self.link is not None and not self.link.host_staged else torch.device("cpu")
+
+    def _post(self, work, tensor):
+        """Remember an asynchronous send; drop the ones that have completed (their buffers may be reused now)."""
+        self._sends.append((work, tensor))
+        while self._sends and self._sends[0][0].is_completed():
+            self._sends.popleft()
+
+    def _send_header(self, kind, task: Optional[BatchTask] = None, n_tokens=0, step_no=0):
+        h = torch.zeros(HEADER_FIXED + self.max_num_seqs, dtype=torch.int64)
+        h[0] = kind
+        if task is not None:
+            h[1], h[2], h[3], h[4], h[5] = task.serial, task.batch_size, n_tokens, step_no, task.max_tokens
+            h[HEADER_FIXED: HEADER_FIXED + task.batch_size] = torch.tensor(task.prompt_lengths)
+        h = h.to(self._header_device())
+        self._post(self.link.send_hidden(h), h)
+
+    def _recv_header(self):
+        h = torch.zeros(HEADER_FIXED + self.max_num_seqs, dtype=torch.int64, device=self._header_device())
+        self.link.recv_hidden(h).wait()
+        return h.tolist()
+
+    def drain_sends(self):
+        while self._sends:
+            self._sends.popleft()[0].wait()
+
     # -- head-side request handling -------------------------------------------------------------
-    async def add_request(self, request_id: str, prompt_ids: List[int], max_tokens: int):
-        self.streamer[request_id] = asyncio.Queue()
-        await self.waiting_requests.put((request_id, prompt_ids, max_tokens))
+    async def add_request(self, request, prompt_ids: Optional[List[int]] = None, max_tokens: Optional[int] = None):
+        """``add_request(request_id, prompt_ids, max_tokens)`` or ``add_request(req)`` with the serving front end's
+        request object (serving/fastapi/model_worker.py ``Request``).  Returns the queue of (text delta, finished)."""
+        if prompt_ids is None:
+            req = request
+            request = req.request_id
+            prompt_ids = req.input_ids if req.input_ids is not None else self.tokenizer(req.prompt).input_ids
+            max_tokens = req.max_new_tokens
+        q = self.streamer[request] = asyncio.Queue()
+        self.stats["requests"] += 1
+        self.stats["prompt_tokens"] += len(prompt_ids)
+        await self.waiting_requests.put((request, list(prompt_ids), max_tokens))
+        return q
+
+    def finish(self, request_id: str):
+        self.streamer.pop(request_id, None)
+        self.is_finish.pop(request_id, None)
 
     def _admit(self):
+        limit = self.max_num_seqs
+        if self.max_prefilled_seqs and self.max_prefilled_seqs > 0:
+            limit = min(limit, self.max_prefilled_seqs)
         reqs = []
-        while len(reqs) < self.max_num_seqs and not self.waiting_requests.empty():
+        while len(reqs) < limit and not self.waiting_requests.empty():
             reqs.append(self.waiting_requests.get_nowait())
         if not reqs:
             return None, None
@@ -367,10 +437,11 @@ class PPModelWorker:
         ids = torch.full((len(reqs), mx), pad, dtype=torch.long, device=self.device)
         for i, (_, p, _) in enumerate(reqs):
             ids[i, mx - len(p):] = torch.tensor(p, device=self.device)
-        task = BatchTask(batch_id="batch_" + "_".join(r[0] for r in reqs)[:64] + f"_{time.time_ns()}",
-                         request_ids=[r[0] for r in reqs], max_tokens=max(r[2] for r in reqs), batch_size=len(reqs),
-                         input_len=mx, prompt_lengths=lens)
-        self.attention_mask_dict[task.batch_id] = make_attention_mask(lens, self.device)
+        self._serial += 1
+        task = BatchTask(batch_id=f"batch_{self._serial}", request_ids=[r[0] for r in reqs],
+                         max_tokens=max(r[2] for r in reqs), batch_size=len(reqs), input_len=mx, prompt_lengths=lens)
+        task.serial = self._serial
+        task.step_no = 0
         return task, ids
 
     def get_printable_text(self, cur_text, request_id):
@@ -403,7 +474,9 @@ class PPModelWorker:
                 delta = self.get_printable_text(text, rid) if not finished else text[self.print_len.get(rid, 0):]
             else:
                 delta = t
-            self.streamer[rid].put_nowait((delta, finished))
+            if rid in self.streamer:          # (a client that went away has had its queue dropped)
+                self.streamer[rid].put_nowait((delta, finished))
+            self.stats["generated_tokens"] += 1
             if finished:
                 self.is_finish[rid] = True
                 self.token_cache.pop(rid, None)
@@ -413,49 +486,114 @@ class PPModelWorker:
         return all_done
 
     @torch.no_grad()
-    def run_batch_sync(self, task: Optional[BatchTask], ids: Optional[torch.Tensor]):
-        """Drive one micro-batch to completion across all stages (every rank calls this with the same schedule; the
-        head passes the admitted task, the others ``None``).  Returns generated ids [B, T] on every rank."""
-        from ..parallel.comm import broadcast_object
-        meta = broadcast_object(task.dict() if task is not None else None, src=0)
-        if meta is None:
-            return None
-        task = BatchTask(**meta)
-        hs = self.model.config.hidden_size
-        gen = []
-        cur = ids
-        for step_no in range(task.max_tokens):
-            n = task.input_len if step_no == 0 else 1
-            if self.pp_config.is_head:
-                out = self.model_step(cur, task)
+    def _head_step(self, task: BatchTask, inp: torch.Tensor):
+        """Head: run this stage on ``inp`` (prompt ids or the last tokens) and hand the result to the next stage."""
+        self.trace.append((task.serial, task.step_no))
+        out = self.model_step(inp, task)
+        if self.link is None:
+            self._local_tokens.append(out)
+        else:
+            self._send_header(KIND_STEP, task, n_tokens=inp.shape[1], step_no=task.step_no)
+            out = out.to(self.dtype).contiguous()
+            self._post(self.link.send_hidden(out), out)
+        self.inflight.append(task)
+        self.max_inflight = max(self.max_inflight, len(self.inflight))
+
+    def _head_collect(self):
+        """Head: take the tokens of the oldest micro-batch in flight, stream them, and either step it again or retire
+        it.  Returns the finished micro-batch's ids [B, T], or None while it goes on."""
+        task = self.inflight.popleft()
+        if self.link is None:
+            next_ids = self._local_tokens.popleft()
+        else:
+            next_ids = torch.empty(task.batch_size, 1, dtype=torch.int64, device=self.device)
+            self.link.recv_tokens(next_ids).wait()
+        self.tokens.setdefault(task.batch_id, []).append(next_ids)
+        done = self._emit(task, next_ids.view(-1).tolist(), task.step_no)
+        if done:
+            gen = torch.cat(self.tokens[task.batch_id], 1)
+            self.results[task.batch_id] = gen
+            self.clear_batch(task.batch_id)
+            if self.link is not None:
+                self._send_header(KIND_FREE, task)
+            return gen
+        task.step_no += 1
+        self._head_step(task, next_ids)
+        return None
+
+    @torch.no_grad()
+    def _serve_one(self):
+        """A later stage: take the next message from the previous stage and act on it."""
+        h = self._recv_header()
+        kind, serial, bs, n, step_no, max_tokens = h[:6]
+        task = BatchTask(batch_id=f"batch_{serial}", request_ids=[], max_tokens=max_tokens, batch_size=bs, input_len=n,
+                         prompt_lengths=h[HEADER_FIXED: HEADER_FIXED + bs])
+        task.serial, task.step_no = serial, step_no
+        if kind != KIND_STEP:
+            if kind == KIND_FREE:
+                self.clear_batch(task.batch_id)
             else:
-                if step_no == 0 and task.batch_id not in self.attention_mask_dict:
-                    self.attention_mask_dict[task.batch_id] = make_attention_mask(task.prompt_lengths, self.device)
-                hidden = torch.empty(task.batch_size, n, hs, device=self.device, dtype=self.dtype)
-                dist.recv(hidden, src=self.pre_rank)
-                out = self.model_step(hidden, task)
-            if self.pp_config.is_tail:
-                next_ids = out
-            else:
-                dist.send(out.to(self.dtype).contiguous(), dst=self.next_rank)
-                next_ids = torch.empty(task.batch_size, 1, dtype=torch.int64, device=self.device)
-            if self.world_size > 1:
-                dist.broadcast(next_ids, src=self.world_size - 1)
-            gen.append(next_ids)
-            cur = next_ids
-            done = False
-            if self.pp_config.is_head:
-                done = self._emit(task, next_ids.view(-1).tolist(), step_no)
-            done = broadcast_object(done, src=0)
-            if done:
-                break
-        self.clear_batch(task.batch_id)
-        return torch.cat(gen, 1)
+                self.stopped = True
+            if not self.pp_config.is_tail:
+                self._send_header(kind, task)
+            return kind
+        hidden = torch.empty(bs, n, self.model.config.hidden_size, device=self.device, dtype=self.dtype)
+        self.link.recv_hidden(hidden).wait()
+        self.trace.append((serial, step_no))
+        out = self.model_step(hidden, task)
+        if self.pp_config.is_tail:
+            out = out.contiguous()
+            self._post(self.link.send_tokens(out), out)
+        else:
+            self._send_header(KIND_STEP, task, n_tokens=n, step_no=step_no)
+            out = out.to(self.dtype).contiguous()
+            self._post(self.link.send_hidden(out), out)
+        return kind
 
     async def process_step(self):
-        """One scheduling tick of the serving loop (called repeatedly by the API server on every rank)."""
-        task, ids = (self._admit() if self.pp_config.is_head else (None, None))
-        return self.run_batch_sync(task, ids)
+        """One scheduling tick (called repeatedly by the serving loop of every rank).  Head: fill the pipeline with
+        newly admitted micro-batches while there is room, then advance the oldest one in flight; returns the ids of a
+        micro-batch that finished in this tick, else None.  Other stages: serve one incoming message."""
+        if not self.pp_config.is_head:
+            return None if self.stopped else self._serve_one()
+        if not self.busy():
+            await asyncio.sleep(0.002)        # idle: leave the event loop to the HTTP handlers
+            return None
+        await asyncio.sleep(0)
+        tic = time.time()
+        try:
+            return self._head_tick()
+        finally:
+            self.stats["busy_s"] += time.time() - tic
+
+    def _head_tick(self):
+        while len(self.inflight) < self.world_size and not self.waiting_requests.empty():
+            task, ids = self._admit()
+            self._head_step(task, ids)
+        if not self.inflight:
+            return None
+        return self._head_collect()
+
+    def busy(self):
+        return bool(self.inflight) or not self.waiting_requests.empty()
+
+    def shutdown(self):
+        """Head: tell the other stages to leave their serving loops.  Every rank: wait for its sends."""
+        if self.pp_config.is_head and self.link is not None and not self.stopped:
+            self._send_header(KIND_STOP)
+            self.stopped = True
+        self.drain_sends()
+
+    async def run_until_idle(self):
+        """Head: drive every admitted and waiting request to completion; other stages: serve until STOP."""
+        if self.pp_config.is_head:
+            while self.busy():
+                await self.process_step()
+            return dict(self.results)
+        while not self.stopped:
+            await self.process_step()
+        self.drain_sends()
+        return {}
 
 
 def _is_chinese_char(cp):

@@ -1,0 +1,37 @@
+"""bench.py's own launcher: ``--gpus N`` starts N ranks (gloo on the host with BIGDL_FORCE_CPU=1) and reports the size
+of the process group that ran, for every parallel mode the driver can ask for."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*flags):
+    env = dict(os.environ, BIGDL_FORCE_CPU="1", PYTHONPATH=ROOT)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--model", "tiny", "--steps", "1", "--warmup", "0",
+                        "--in-len", "16", "--out-len", "4", *flags], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout          # rank 0 prints exactly one JSON line
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("par,scaling", [("tp", "strong"), ("pp", "strong"), ("dp", "weak")])
+def test_gpus_flag_starts_that_many_ranks(par, scaling):
+    out = _bench("--gpus", "2", "--parallelism", par)
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == f"{par}2" and out["scaling"] == scaling
+    assert out["value"] > 0 and out["unit"] == "ms/token" and out["higher_is_better"] is False
+    assert out["config"]["global_batch"] == (2 if par == "dp" else 1)
+
+
+def test_single_process_default():
+    out = _bench()
+    assert out["n_gpus"] == 1 and out["config"]["parallelism"] == "single"
+    for key in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert key in out

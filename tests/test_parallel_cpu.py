@@ -128,17 +128,44 @@ def _pp_worker(rank, port, tmp):
         if rank == 0:
             await w.add_request("a", ids[0].tolist(), 5)
             await w.add_request("b", ids[1, 3:].tolist(), 5)
-        return await w.process_step()
-    got = asyncio.run(drive())
-    assert got.shape == (2, 5)
-    assert torch.equal(got[0], ref[0, ids.shape[1]:ids.shape[1] + 5])       # unpadded row equals plain generation
+        res = await w.run_until_idle()
+        w.shutdown()
+        return res
+    res = asyncio.run(drive())
     single = full.generate(ids[1:2, 3:], max_new_tokens=5, do_sample=False)
-    assert torch.equal(got[1], single[0, -5:])                              # left-padded row too
     if rank == 0:
+        got = res["batch_1"]
+        assert got.shape == (2, 5)
+        assert torch.equal(got[0], ref[0, ids.shape[1]:ids.shape[1] + 5])       # unpadded row equals plain generation
+        assert torch.equal(got[1], single[0, -5:])                              # left-padded row too
         toks = []
         while not w.streamer["a"].empty():
             toks.append(w.streamer["a"].get_nowait())
         assert [t for t, _ in toks] == got[0].tolist() and toks[-1][1] is True
+    assert not w.kv_caches and not w.positions                                  # FREE reached every stage
+    # three micro-batches of one request each: two are in flight at any time (one per stage), the third joins as soon as
+    # one retires, and no stage waits for a whole batch to finish before it sees the next
+    w2 = PPModelWorker(None, rank, WORLD, "sym_int8", max_num_seqs=1, torch_dtype=torch.float32, model=stage)
+    budgets = {"x": 6, "y": 4, "z": 5}
+    prompts = {"x": ids[0].tolist(), "y": ids[1].tolist(), "z": ids[0, 2:].tolist()}
+
+    async def drive3():
+        if rank == 0:
+            for k in budgets:
+                await w2.add_request(k, prompts[k], budgets[k])
+        res = await w2.run_until_idle()
+        w2.shutdown()
+        return res
+    res = asyncio.run(drive3())
+    if rank == 0:
+        assert w2.max_inflight == WORLD
+        for serial, k in enumerate(budgets, start=1):
+            want = full.generate(torch.tensor([prompts[k]]), max_new_tokens=budgets[k], do_sample=False)[0, len(prompts[k]):]
+            assert torch.equal(res[f"batch_{serial}"][0], want), k
+    # every stage alternates between the two micro-batches in flight: x0 y0 x1 y1 x2 y2 x3 y3, then z takes y's place
+    assert w2.trace[:8] == [(1, 0), (2, 0), (1, 1), (2, 1), (1, 2), (2, 2), (1, 3), (2, 3)], w2.trace
+    assert w2.trace[8:12] == [(1, 4), (3, 0), (1, 5), (3, 1)], w2.trace
+    assert len(w2.trace) == sum(budgets.values())
     dist.barrier()
     dist.destroy_process_group()
 
