@@ -114,6 +114,7 @@ def main():
     runner = cpu_module_path if cpu else native_engine
     runner(args, rank, local_rank, world, dist)
     if dist_on:
+        dist.barrier()                         # nobody tears its connections down while a peer still reads from them
         dist.destroy_process_group()
 
 
