@@ -210,6 +210,12 @@ def native_engine(args, rank, local_rank, world, dist):
         return model.first_cost, model.rest_cost_mean, model.peak_memory
 
     stats = timed_trials(args, trial, dist, dev)
+    if os.environ.get("BIGDL_PMC_CALIBRATE") == "1":
+        # a known amount of read traffic for benchmark/pmc_summary.py: three reductions over exactly 1 GiB
+        ref = torch.zeros(1 << 28, dtype=torch.float32, device=dev)
+        for _ in range(3):
+            ref.sum()
+        torch.cuda.synchronize()
     if rank == 0:
         report(args, world, par, label, stats, floor_ms=model.weight_bytes() / 8e12 * 1e3)
 

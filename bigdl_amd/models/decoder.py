@@ -868,6 +868,12 @@ class NativeDecoder:
                                    bias2=None if w2 is None else w2.bias, residual=residual, gamma=gamma,
                                    eps=cfg.rms_eps, gamma_offset=cfg.norm_offset, act=act, out=out,
                                    att_partials=att_partials)
+        if (not lin.fused and (w2 is None or not w2.fused) and att_partials is None and hip.gemv_f16_ok(m, lin.n, lin.k)
+                and lin.w.is_contiguous() and (w2 is None or w2.w.is_contiguous())):
+            # plain fp16 weights: one kernel per projection, streamed row-major as stored
+            return hip.gemv_f16(x, lin.w, w2=None if w2 is None else w2.w, bias=lin.bias,
+                                bias2=None if w2 is None else w2.bias, residual=residual, gamma=gamma, eps=cfg.rms_eps,
+                                gamma_offset=cfg.norm_offset, act=act, out=out)
         xin = x if gamma is None else hip.rms_norm(x, gamma, cfg.rms_eps, offset=cfg.norm_offset)
         y = F.linear(xin, lin.dense())
         if lin.bias is not None:

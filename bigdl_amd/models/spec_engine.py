@@ -1,0 +1,171 @@
+"""Self-speculative decoding on the native engine: a low-bit copy of the model drafts, the fp16 (or higher-bit) target
+verifies the whole draft in one multi-row step.
+
+Capability: the reference's ``speculative_generate`` (python/llm/src/ipex_llm/transformers/speculative.py:802-1269):
+draft loop :944-1052, the draft runs on the target's own ``past_key_values`` :931-935, greedy verification :1162-1175,
+KV rollback :1201-1206, ``max_step_draft`` adaptation (``hf_adjust``) :1238-1242, statistics :444-456.
+
+How it maps to this engine:
+
+* ONE KV cache.  The draft engine is handed the target's cache object: it attends to the target's exact prompt keys
+  (no draft prefill, no second cache) and appends its own approximate keys for the tokens it is drafting; the
+  verification step then rewrites exactly those positions with the target's keys.  Rejection is a counter write.
+* The draft loop is a chain of graph replays: the greedy token of step i is written by the graph where step i + 1
+  reads its input, a tiny device copy files it in the round's draft buffer.  Nothing returns to the host per draft
+  token.
+* Verification is one graph replay over ``k + 1`` rows; the accepted prefix length is computed on the device and
+  ``[m, target tokens]`` come back in ONE host read per round.
+* The draft length adapts between rounds from what was accepted (host side, no extra read): a fully accepted round
+  grows it, a rejection shrinks it.  ``th_stop_draft`` (stop drafting when the draft is unsure) would need a host
+  read per draft token; verifying a few doubtful tokens is cheaper here than asking.
+"""
+from __future__ import annotations
+
+import time
+from typing import Optional
+
+import torch
+
+
+class SelfSpeculativeEngine:
+    def __init__(self, target, draft, max_step_draft: int = 6, min_step_draft: int = 1, adapt: bool = True):
+        assert target.cfg.num_layers == draft.cfg.num_layers and target.cfg.kv_size == draft.cfg.kv_size \
+            and target.cfg.head_dim == draft.cfg.head_dim, "draft and target must share the KV layout"
+        self.target, self.draft = target, draft
+        self.max_step_draft, self.min_step_draft, self.adapt = max_step_draft, max(1, min_step_draft), adapt
+        self.device = target.device
+        self.clear_benchmarks()
+
+    def clear_benchmarks(self):
+        self.first_token_time = 0.0
+        self.generate_time, self.draft_time, self.verify_time = [], [], []
+        self.draft_num, self.accept_num = [], []
+        self.n_drafted = self.n_matched = 0
+        self.first_cost = self.rest_cost_mean = 0.0
+        self.n_token_generated = 0
+
+    def _share_cache(self, batch, capacity, kv_fp8):
+        t, d = self.target, self.draft
+        t.ensure_cache(batch, capacity, fp8=kv_fp8)
+        if d.cache is not t.cache:
+            d.cache = t.cache
+            d._graphs.clear()
+            d._static.clear()
+            d.inv_freq, d.rope_scaling_factor = t.inv_freq, t.rope_scaling_factor
+            d.rope_table, d.no_rope, d.fused_rope = t.rope_table, t.no_rope, t.fused_rope
+        t.cache.reset()
+
+    @torch.no_grad()
+    def generate(self, input_ids: torch.Tensor, max_new_tokens: int = 32, eos_token_id=None, kv_fp8=False, streamer=None,
+                 time_phases: bool = False, **unused):
+        """Greedy.  ``time_phases`` synchronises between the draft and verify phases of every round to fill
+        ``draft_time`` / ``verify_time`` (costs one extra host wait per round); otherwise only ``generate_time`` per
+        round is recorded."""
+        t, d, dev = self.target, self.draft, self.device
+        input_ids = input_ids.to(dev)
+        assert input_ids.shape[0] == 1, "speculative decoding serves one sequence"
+        s = input_ids.shape[1]
+        kmax = self.max_step_draft
+        self._share_cache(1, s + max_new_tokens + kmax + 2, kv_fp8)
+        cache = t.cache
+        eos = set([eos_token_id] if isinstance(eos_token_id, int) else (eos_token_id or []))
+        self.clear_benchmarks()
+        torch.cuda.synchronize()
+        tic = time.perf_counter()
+        logits = t.prefill(input_ids)[:, -1, :]
+        last = logits.argmax(-1).view(1, 1)                  # device
+        generated = [int(last)]
+        self.first_token_time = self.first_cost = time.perf_counter() - tic
+        if streamer is not None:
+            streamer.put(input_ids.cpu())
+            streamer.put(last.view(-1).cpu())
+        drafts = torch.zeros(kmax, dtype=torch.int64, device=dev)
+        verify_in = torch.zeros(1, kmax + 1, dtype=torch.int64, device=dev)
+        result = torch.zeros(kmax + 2, dtype=torch.int64, device=dev)      # [m, target tokens ...]
+        k = min(kmax, max(self.min_step_draft, 4))
+        done = generated[-1] in eos
+        e2e = time.perf_counter()
+        while not done and len(generated) < max_new_tokens:
+            t0 = time.perf_counter()
+            base = cache.host_len
+            k = max(1, min(k, max_new_tokens - len(generated) - 1)) if max_new_tokens - len(generated) > 1 else 0
+            # ---- draft: k chained replays of the low-bit engine on the shared cache
+            if k:
+                _, chained = d.decode(last, 1, chain=True)
+                drafts[0:1].copy_(chained)
+                for i in range(1, k):
+                    _, chained = d.decode(None, 1, chain=True)
+                    drafts[i:i + 1].copy_(chained)
+            if time_phases:
+                torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            # ---- verify: [last, drafts] in one step of the target, over the positions the draft just used
+            cache.crop(base)
+            verify_in[0, 0:1].copy_(last.view(-1))
+            if k:
+                verify_in[0, 1:k + 1].copy_(drafts[:k])
+            _, choice = t.decode(verify_in[:, :k + 1], k + 1, chain=False)            # choice: [k + 1]
+            if k:
+                ok = (choice[:k] == drafts[:k]).to(torch.int64)
+                m_dev = torch.cumprod(ok, 0).sum()
+            else:
+                m_dev = torch.zeros((), dtype=torch.int64, device=dev)
+            result[0] = m_dev
+            result[1:k + 2].copy_(choice)
+            host = result[:k + 2].tolist()                                           # the round's one host read
+            m, choice_h = host[0], host[1:]
+            accepted = choice_h[:m + 1]
+            cache.crop(base + 1 + m)
+            last = choice[m:m + 1].view(1, 1).clone()
+            t2 = time.perf_counter()
+            self.draft_time.append(t1 - t0)
+            self.verify_time.append(t2 - t1)
+            self.generate_time.append(t2 - t0)
+            self.draft_num.append(k)
+            self.accept_num.append(m + 1)
+            self.n_drafted += k
+            self.n_matched += m
+            if eos:
+                for i, tok in enumerate(accepted):
+                    if tok in eos:
+                        accepted, done = accepted[:i + 1], True
+                        break
+            generated.extend(accepted)
+            if streamer is not None:
+                streamer.put(torch.tensor(accepted))
+            if self.adapt and k:
+                k = min(kmax, k + 1) if m == k else max(self.min_step_draft, k - 1)
+        if streamer is not None:
+            streamer.end()
+        generated = generated[:max_new_tokens]
+        self.n_token_generated = len(generated)
+        self.e2e_time_without_first = time.perf_counter() - e2e
+        self.rest_cost_mean = self.e2e_time_without_first / max(1, len(generated) - 1)
+        return torch.cat([input_ids, torch.tensor([generated], dtype=input_ids.dtype, device=dev)], 1)
+
+
+def quantized_draft_of(target, qtype, lm_head_qtype: Optional[int] = None):
+    """A draft engine for ``target``: the same weights quantized to ``qtype`` (embedding and norms are shared, not
+    copied).  This is what ``from_pretrained(..., speculative=True)`` builds from a checkpoint (reference
+    transformers/model.py:330-340: the draft is the sym_int4 conversion of the same model)."""
+    import dataclasses
+    from ..ops import host
+    from .decoder import Lin, NativeDecoder
+    from ..transformers.low_bit_linear import FP4Params
+
+    def q(lin, qt=qtype):
+        if lin is None:
+            return None
+        # host quantizer (csrc/host/quantize.cpp), then the tiled device layout
+        raw = host.quantize(lin.dense().float().cpu(), qt)
+        data = host.relayout_to_device(raw, qt, lin.n, lin.k).to(target.device)
+        return Lin(FP4Params(data, quantized=True, _shape=(lin.n, lin.k), qtype=qt, qlayout="t16"), bias=lin.bias)
+
+    layers = []
+    for lw in target.layers:
+        assert lw.moe is None and lw.mla is None, "quantized_draft_of covers dense decoder layers"
+        layers.append(dataclasses.replace(lw, qkv=q(lw.qkv), o=q(lw.o), gate=q(lw.gate), up=q(lw.up), down=q(lw.down)))
+    draft = NativeDecoder(target.cfg, target.embed, layers, target.final_norm, q(target.lm_head, lm_head_qtype or qtype),
+                          device=target.device, final_norm_b=target.final_norm_b, pos_embed=target.pos_embed,
+                          embed_norm=target.embed_norm)
+    return draft

@@ -37,6 +37,7 @@ def lib():
         L = ctypes.CDLL(str(_LIB_PATH))
         vp, i64, ci, cf = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
         L.bigdl_gemv_lowbit.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, cf, cf, ci, ci, ci, ci, ci, ci, ci, ci, vp, ci, ci, ci, ci, ci, ci, vp]
+        L.bigdl_gemv_f16.argtypes = [vp] * 8 + [cf, cf] + [ci] * 7 + [vp]
         L.bigdl_gemv_lowbit_ln.argtypes = [vp] * 8 + [cf] + [ci] * 8 + [vp] * 5
         L.bigdl_attn_decode.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, ci, ci, ci, cf, cf] + [ci] * 14 + [vp, vp, vp]
         L.bigdl_kv_int4_append.argtypes = [vp, vp, vp, vp, vp] + [ci] * 7 + [i64, vp]
@@ -144,6 +145,46 @@ def gemv_lowbit(x, w, qtype, out_features, in_features, *, w2=None, bias=None, b
                                  _ptr(gamma), eps, gamma_offset, m, out_features, k, x.stride(0), out.stride(0),
                                  qtype, ACT[act], _out_type(out_dtype), *att, _stream())
     _check(rc, "gemv_lowbit")
+    return out
+
+
+def gemv_f16_ok(m, n, k):
+    """shapes the fp16 skinny GEMM takes (csrc/hip/gemv_f16.hip)"""
+    return 0 < m <= 16 and n % 16 == 0 and k % 64 == 0
+
+
+def gemv_f16(x, w, *, w2=None, bias=None, bias2=None, residual=None, gamma=None, eps=1e-6, gamma_offset=0.0, act=None,
+             out=None, out_dtype=None):
+    """``y = act(rmsnorm?(x) @ w^T + bias) [* (x @ w2^T + bias2)] [+ residual]`` for plain fp16 weights [N, K]
+    (row-major, contiguous), M <= 16 rows of x."""
+    _need_cuda(x, w, w2, bias, bias2, residual, gamma, out)
+    if x.dim() != 2 or x.dtype != torch.float16 or x.stride(1) != 1:
+        raise ValueError("x must be a 2-D fp16 tensor with contiguous rows")
+    m, k = x.shape
+    for ww in (w, w2):
+        if ww is not None and (ww.dtype != torch.float16 or ww.dim() != 2 or not ww.is_contiguous() or ww.shape != w.shape
+                               or ww.shape[1] != k):
+            raise ValueError("weights must be contiguous fp16 [out_features, in_features] matching x")
+    n = w.shape[0]
+    if not gemv_f16_ok(m, n, k):
+        raise ValueError(f"gemv_f16 takes M <= 16, N % 16 == 0, K % 64 == 0; got M={m} N={n} K={k}")
+    out_dtype = out_dtype or (out.dtype if out is not None else torch.float16)
+    if out is None:
+        out = torch.empty((m, n), dtype=out_dtype, device=x.device)
+    if out.shape != (m, n) or out.stride(1) != 1 or out.dtype != out_dtype:
+        raise ValueError("bad out tensor")
+    for b in (bias, bias2):
+        if b is not None and (b.dtype != torch.float16 or b.numel() != n or not b.is_contiguous()):
+            raise ValueError("bias must be contiguous fp16 [out_features]")
+    if residual is not None and (residual.shape != out.shape or residual.dtype != out.dtype
+                                 or residual.stride() != out.stride()):
+        raise ValueError("residual must match out")
+    if gamma is not None and (gamma.dtype != torch.float16 or gamma.numel() != k or not gamma.is_contiguous()):
+        raise ValueError("gamma must be contiguous fp16 [in_features]")
+    rc = lib().bigdl_gemv_f16(_ptr(x), _ptr(w), _ptr(w2), _ptr(out), _ptr(bias), _ptr(bias2), _ptr(residual), _ptr(gamma),
+                              eps, gamma_offset, m, n, k, x.stride(0), out.stride(0), ACT[act], _out_type(out_dtype),
+                              _stream())
+    _check(rc, "gemv_f16")
     return out
 
 

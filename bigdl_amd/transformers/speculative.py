@@ -49,6 +49,29 @@ def _probs(logits, temperature, top_k, top_p):
     return torch.softmax(logits, -1)
 
 
+def _engine_pair(model, draft_model, do_sample, kwargs):
+    """The engine-level loop for (model, draft_model), or None when this call has to take the generic stepper loop
+    (sampling, caller-provided steppers, a model without a native engine, CPU)."""
+    import os
+    if do_sample or "stepper" in kwargs or "draft_stepper" in kwargs or os.environ.get("BIGDL_SPEC_STEPPER_LOOP") == "1":
+        return None
+    try:
+        dev = next(model.parameters()).device
+    except (StopIteration, AttributeError):
+        return None
+    if dev.type != "cuda":
+        return None
+    from ..models.hf_patch import get_native_engine, native_engine_supported
+    if not (native_engine_supported(model) and native_engine_supported(draft_model)):
+        return None
+    pair = getattr(model, "_spec_engine", None)
+    if pair is None:
+        from ..models.spec_engine import SelfSpeculativeEngine
+        pair = SelfSpeculativeEngine(get_native_engine(model), get_native_engine(draft_model))
+        object.__setattr__(model, "_spec_engine", pair)
+    return pair
+
+
 @torch.no_grad()
 def speculative_generate(self, inputs: Optional[torch.Tensor] = None, draft_model=None, max_new_tokens=10,
                          max_step_draft=8, th_stop_draft=0.8, auto_th_stop_draft=True,
@@ -66,6 +89,20 @@ def speculative_generate(self, inputs: Optional[torch.Tensor] = None, draft_mode
     eos = sampling_kwargs.get("eos_token_id", getattr(gc, "eos_token_id", None))
     eos = set([eos] if isinstance(eos, int) else (eos or []))
     auto_parameters = list(auto_parameters)
+
+    fast = _engine_pair(self, draft_model, do_sample, sampling_kwargs)
+    if fast is not None:
+        # both models run on the native engine: shared KV cache, device-chained draft loop, one host read per round
+        # (bigdl_amd/models/spec_engine.py).  th_stop_draft has no effect there: the draft length adapts from what was
+        # accepted instead of from the draft's confidence.
+        from .utils import engine_kv_mode
+        fast.max_step_draft = max_step_draft
+        out = fast.generate(input_ids, max_new_tokens=max_new_tokens, eos_token_id=eos, kv_fp8=engine_kv_mode(),
+                            streamer=streamer)
+        for k in ("first_token_time", "generate_time", "draft_time", "verify_time", "draft_num", "accept_num", "n_drafted",
+                  "n_matched", "n_token_generated", "e2e_time_without_first", "first_cost", "rest_cost_mean"):
+            object.__setattr__(self, k, getattr(fast, k))
+        return out
 
     cap = input_ids.shape[1] + max_new_tokens + max_step_draft + 16
     target = sampling_kwargs.pop("stepper", None) or make_stepper(self, capacity=cap)

@@ -139,3 +139,61 @@ def test_attention_1100_keys_32_heads_with_deferred_combine(hip, fp8, batch):
     got_k = kcache[:, :, past].cpu()
     got_k = got_k.view(torch.float8_e5m2).float() if fp8 else got_k.float()
     _close(got_k, kn, 2e-2 if fp8 else 2e-3)
+
+
+# ------------------------------------------------------------------------------------------------
+# fp16 weights, row-major as stored (csrc/hip/gemv_f16.hip): decode / speculative-verification rows
+@pytest.mark.parametrize("n,k,m", [(12288, 4096, 1), (4096, 4096, 5), (4096, 11008, 1), (4096, 11008, 9), (32000, 4096, 1),
+                                    (4544, 4544, 3), (256, 64, 16)])
+def test_gemv_f16_against_fp32(n, k, m):
+    from bigdl_amd.ops import hip
+    g = torch.Generator(device="cuda").manual_seed(n + k + m)
+    w = (torch.randn(n, k, device="cuda", generator=g) / k ** 0.5).half()
+    x = torch.randn(m, k, device="cuda", generator=g).half()
+    gamma = (1 + 0.1 * torch.randn(k, device="cuda", generator=g)).half()
+    res = torch.randn(m, n, device="cuda", generator=g).half()
+    bias = (0.1 * torch.randn(n, device="cuda", generator=g)).half()
+    xf = x.float()
+    xn = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5) * gamma.float()
+    want = xn @ w.float().T + bias.float() + res.float()
+    got = hip.gemv_f16(x, w, bias=bias, residual=res, gamma=gamma, eps=1e-5)
+    err = (got.float() - want).abs().max().item()
+    assert err < 2e-2 * max(1.0, want.abs().max().item()), err
+    # no norm, no epilogue, fp32 out
+    got = hip.gemv_f16(x, w, out_dtype=torch.float32)
+    want = xf @ w.float().T
+    assert (got - want).abs().max().item() < 5e-3 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("m", [1, 4, 9])
+def test_gemv_f16_gate_up(m):
+    from bigdl_amd.ops import hip
+    n, k = 11008, 4096
+    g = torch.Generator(device="cuda").manual_seed(m)
+    wg = (torch.randn(n, k, device="cuda", generator=g) / k ** 0.5).half()
+    wu = (torch.randn(n, k, device="cuda", generator=g) / k ** 0.5).half()
+    x = torch.randn(m, k, device="cuda", generator=g).half()
+    gamma = (1 + 0.1 * torch.randn(k, device="cuda", generator=g)).half()
+    xf = x.float()
+    xn = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6) * gamma.float()
+    want = torch.nn.functional.silu(xn @ wg.float().T) * (xn @ wu.float().T)
+    got = hip.gemv_f16(x, wg, w2=wu, gamma=gamma, eps=1e-6, act="silu")
+    assert (got.float() - want).abs().max().item() < 2e-2 * max(1.0, want.abs().max().item())
+
+
+def test_fp16_engine_decode_matches_its_prefill():
+    """The fp16 engine (fused fp16 GEMVs per projection) decodes the same tokens as its own prompt pass predicts."""
+    from bigdl_amd import qtypes as Q
+    from bigdl_amd.models.decoder import DecoderConfig, build_random_decoder
+    cfg = DecoderConfig(vocab_size=4096, hidden_size=2048, intermediate_size=5632, num_layers=4, num_heads=16, num_kv_heads=8,
+                        head_dim=128, max_position=2048)
+    eng = build_random_decoder(cfg, Q.FP16, device="cuda", seed=11)
+    assert not eng.layers[0].qkv.fused
+    ids = torch.randint(3, cfg.vocab_size, (1, 40), generator=torch.Generator().manual_seed(0)).cuda()
+    out = eng.generate(ids, max_new_tokens=10)
+    # teacher-forced prompt pass over the generated sequence must predict the same continuation
+    eng.ensure_cache(1, 64)
+    eng.cache.reset()
+    logits = eng.prefill(out[:, :-1], last_only=False)
+    pred = logits[0, 39:].argmax(-1)
+    assert (pred == out[0, 40:]).float().mean().item() >= 0.9
