@@ -186,7 +186,7 @@ def native_engine(args, rank, local_rank, world, dist):
         model.tp_group, model.tp_world = dist.group.WORLD, world
         if not args.rccl_allreduce:
             from bigdl_amd.parallel.xgmi_allreduce import XgmiAllReduce
-            model.tp_fast_allreduce = XgmiAllReduce(model.tp_group, device=dev)
+            model.tp_fast_allreduce = XgmiAllReduce.create_verified(model.tp_group, device=dev)   # None: RCCL
     elif par == "pp":
         from bigdl_amd.parallel.pipeline import EnginePipeline, build_random_stage
         model = EnginePipeline(build_random_stage(cfg, qt, rank, world, device=str(dev), seed=1234))

@@ -10,11 +10,13 @@
 // Mapping (wave64, 8 waves per workgroup, one workgroup per 16 output columns):
 //   * K is cut into 64-wide chunks; wave w takes chunks w, w + 8, ...  A lane (r = lane % 16, g = lane / 16) loads 32
 //     contiguous bytes of weight row n0 + r at k = 64 c + 16 g: the four lane groups of a row cover one full 128-byte
-//     line per request, so a row-major matrix streams at line granularity without a tiled copy.
+//     line, so a row-major matrix streams at line granularity without a tiled copy.
 //   * The MFMA (v_mfma_f32_16x16x32_f16, x as the A operand, 16 weight rows as B) does not care which k an operand
-//     slot holds as long as A and B agree: slot (g, i) of the first issue is k = 64 c + 16 g + i, of the second
-//     k = 64 c + 16 g + 8 + i.  x is read from global memory in exactly that order (it is a few KB and stays in L2).
-//   * Four chunks (128 B per lane, 8 requests) are in flight per wave and stream before the first MFMA of a round.
+//     slot holds as long as A and B agree: slot (g, i) of issue h is k = 64 c + 16 g + 8 h + i.  x is read in exactly
+//     that order.
+//     When M * K fits 64 KB, x * gamma is staged once in LDS instead (the first weight requests are already in flight).
+//   * Two register sets of four chunks each (128 B per lane and set): the next round streams while this one is
+//     multiplied.
 //   * Partial sums of the 8 waves meet in LDS; wave 0 applies the epilogue.
 #include "common.h"
 
@@ -41,63 +43,108 @@ __device__ __forceinline__ float frag_sumsq_f16(half8 a) {
   return s;
 }
 
+#ifndef F16_H
+// 16-byte pieces a lane loads per chunk (contiguous): a chunk is 32 * F16_H halves of K.  Measured on MI355X at the
+// Llama-2-7B shapes (M = 1): 2 pieces -> 4.6 / 3.4 / 4.3 / 3.6 TB/s for qkv / o / gate+up / down, 4 pieces -> 3.4 / 2.6 /
+// 3.0 / 2.9 TB/s: what counts is how close together the 64 addresses of ONE request are (pieces of a row 32 B apart
+// with 2, 64 B apart with 4), not how much of a row a lane covers over several requests.
+#define F16_H 2
+#endif
 constexpr int F16_NW = 8;      // waves per workgroup
-constexpr int F16_U = 4;       // chunks in flight per wave
+constexpr int F16_U = 8 / F16_H;   // chunks per register set and wave
+constexpr int F16_CK = 32 * F16_H;     // halves of K per chunk
+constexpr int F16_LK = 8 * F16_H;      // contiguous halves per lane and chunk
 
-template <bool GATE_UP, bool NORM>
+// Weight fragments of one round (F16_U chunks) of one wave
+template <int NACC>
+struct F16Round {
+  uint4v w[NACC][F16_U][F16_H];
+};
+
+template <int NACC>
+__device__ __forceinline__ void f16_fetch(F16Round<NACC>& t, const _Float16* wrow, const _Float16* w2row, int c0, int nchunks) {
+#pragma unroll
+  for (int u = 0; u < F16_U; ++u) {
+    const int c = min(c0 + u * F16_NW, nchunks - 1);
+#pragma unroll
+    for (int h = 0; h < F16_H; ++h) {
+      t.w[0][u][h] = __builtin_nontemporal_load((const uint4v*)(wrow + c * F16_CK + 8 * h));
+      if constexpr (NACC == 2) t.w[1][u][h] = __builtin_nontemporal_load((const uint4v*)(w2row + c * F16_CK + 8 * h));
+    }
+  }
+}
+
+// XLDS: x (already multiplied by gamma) is staged once in LDS, rows of K + 8 halves; otherwise every wave reads its
+// x fragments from global memory (row counts whose x does not fit the staging budget).
+template <bool GATE_UP, bool NORM, bool XLDS>
 __global__ __launch_bounds__(F16_NW * 64) void gemv_f16_kernel(GemvF16Args a) {
   constexpr int NACC = GATE_UP ? 2 : 1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
   const int n0 = blockIdx.x * 16;
-  const int nchunks = a.K >> 6;
-  const _Float16* wrow = a.w + (int64_t)(n0 + r) * a.K + 16 * g;
-  const _Float16* w2row = GATE_UP ? a.w2 + (int64_t)(n0 + r) * a.K + 16 * g : nullptr;
-  const _Float16* xrow = a.x + (int64_t)min(r, a.M - 1) * a.ldx + 16 * g;
-  const _Float16* grow = NORM ? a.gamma + 16 * g : nullptr;
+  const int nchunks = a.K / F16_CK;
+  const _Float16* wrow = a.w + (int64_t)(n0 + r) * a.K + F16_LK * g;
+  const _Float16* w2row = GATE_UP ? a.w2 + (int64_t)(n0 + r) * a.K + F16_LK * g : nullptr;
+  const _Float16* xrow = a.x + (int64_t)min(r, a.M - 1) * a.ldx + F16_LK * g;
+  const _Float16* grow = NORM ? a.gamma + F16_LK * g : nullptr;
 
   __shared__ float4v red[F16_NW][NACC][64];
   __shared__ float ssq_sh[F16_NW][16];
+  extern __shared__ _Float16 xs[];
+  const int XS = a.K + 8;
 
   float4v acc[NACC];
 #pragma unroll
   for (int i = 0; i < NACC; ++i) acc[i] = float4v{0, 0, 0, 0};
   float ssq = 0.0f;
 
-  for (int c0 = wave; c0 < nchunks; c0 += F16_NW * F16_U) {
-    uint4v wv[NACC][F16_U][2], xv[F16_U][2], gv[F16_U][2];
-    // x (and gamma) first: they are L2 hits the MFMAs wait for, the weight stream follows
-#pragma unroll
-    for (int u = 0; u < F16_U; ++u) {
-      const int c = min(c0 + u * F16_NW, nchunks - 1);
-      xv[u][0] = *(const uint4v*)(xrow + c * 64);
-      xv[u][1] = *(const uint4v*)(xrow + c * 64 + 8);
-      if constexpr (NORM) {
-        gv[u][0] = *(const uint4v*)(grow + c * 64);
-        gv[u][1] = *(const uint4v*)(grow + c * 64 + 8);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < F16_U; ++u) {
-      const int c = min(c0 + u * F16_NW, nchunks - 1);
-      wv[0][u][0] = __builtin_nontemporal_load((const uint4v*)(wrow + c * 64));
-      wv[0][u][1] = __builtin_nontemporal_load((const uint4v*)(wrow + c * 64 + 8));
-      if constexpr (GATE_UP) {
-        wv[1][u][0] = __builtin_nontemporal_load((const uint4v*)(w2row + c * 64));
-        wv[1][u][1] = __builtin_nontemporal_load((const uint4v*)(w2row + c * 64 + 8));
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < F16_U; ++u) {
-      const bool live = c0 + u * F16_NW < nchunks;     // (wave-uniform) a chunk past the end contributes zeros
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        H8 xa;
-        xa.q = xv[u][h];
-        if (!live) xa.q = uint4v{0, 0, 0, 0};
+  F16Round<NACC> ta, tb;
+  f16_fetch<NACC>(ta, wrow, w2row, wave, nchunks);          // the weight stream starts before x is staged
+
+  if constexpr (XLDS) {
+    const int per_row = a.K >> 3;                            // 16-byte pieces per row
+    for (int m = 0; m < a.M; ++m) {
+      float s = 0.0f;
+      for (int i = tid; i < per_row; i += F16_NW * 64) {
+        H8 xv;
+        xv.q = *(const uint4v*)(a.x + (int64_t)m * a.ldx + i * 8);
         if constexpr (NORM) {
+          s += frag_sumsq_f16(xv.v);
+          H8 gm;
+          gm.q = *(const uint4v*)(a.gamma + i * 8);
+          half8 gmv = gm.v;
+          if (a.gamma_offset != 0.0f) gmv = gmv + (_Float16)a.gamma_offset;
+          xv.v = xv.v * gmv;
+        }
+        *(uint4v*)(xs + m * XS + i * 8) = xv.q;
+      }
+      if constexpr (NORM) {
+        s = wave_sum(s);
+        if (lane == 0) ssq_sh[wave][m] = s;
+      }
+    }
+    __syncthreads();
+  }
+  const _Float16* xl = xs + min(r, a.M - 1) * XS + F16_LK * g;
+
+  auto consume = [&](const F16Round<NACC>& t, int c0) {
+#pragma unroll
+    for (int u = 0; u < F16_U; ++u) {
+      const int cu = c0 + u * F16_NW;
+      const bool live = cu < nchunks;                        // (wave-uniform) a chunk past the end contributes zeros
+      const int c = min(cu, nchunks - 1);
+#pragma unroll
+      for (int h = 0; h < F16_H; ++h) {
+        H8 xa;
+        if constexpr (XLDS) {
+          xa.q = *(const uint4v*)(xl + c * F16_CK + 8 * h);
+        } else {
+          xa.q = *(const uint4v*)(xrow + c * F16_CK + 8 * h);
+        }
+        if (!live) xa.q = uint4v{0, 0, 0, 0};
+        if constexpr (NORM && !XLDS) {
           ssq += frag_sumsq_f16(xa.v);
           H8 gm;
-          gm.q = gv[u][h];
+          gm.q = *(const uint4v*)(grow + c * F16_CK + 8 * h);
           half8 gmv = gm.v;
           if (a.gamma_offset != 0.0f) gmv = gmv + (_Float16)a.gamma_offset;
           xa.v = xa.v * gmv;
@@ -105,17 +152,28 @@ __global__ __launch_bounds__(F16_NW * 64) void gemv_f16_kernel(GemvF16Args a) {
 #pragma unroll
         for (int i = 0; i < NACC; ++i) {
           H8 b;
-          b.q = wv[i][u][h];
+          b.q = t.w[i][u][h];
           acc[i] = mfma16(xa.v, b.v, acc[i]);
         }
       }
+    }
+  };
+
+  // two register sets: the next round's weights are in flight while this one is multiplied
+  constexpr int STEP = F16_NW * F16_U;
+  for (int c0 = wave; c0 < nchunks; c0 += 2 * STEP) {
+    if (c0 + STEP < nchunks) f16_fetch<NACC>(tb, wrow, w2row, c0 + STEP, nchunks);
+    consume(ta, c0);
+    if (c0 + STEP < nchunks) {
+      if (c0 + 2 * STEP < nchunks) f16_fetch<NACC>(ta, wrow, w2row, c0 + 2 * STEP, nchunks);
+      consume(tb, c0 + STEP);
     }
   }
 
   // ---- cross-wave reduction: lane holds C[m = 4g + q][n = r], q = 0..3
 #pragma unroll
   for (int i = 0; i < NACC; ++i) red[wave][i][lane] = acc[i];
-  if constexpr (NORM) {
+  if constexpr (NORM && !XLDS) {
     ssq += __shfl_xor(ssq, 16);
     ssq += __shfl_xor(ssq, 32);
     if (lane < 16) ssq_sh[wave][lane] = ssq;
@@ -160,6 +218,24 @@ __global__ __launch_bounds__(F16_NW * 64) void gemv_f16_kernel(GemvF16Args a) {
   }
 }
 
+template <bool GATE_UP, bool NORM>
+static int launch_f16(const GemvF16Args& a, hipStream_t stream) {
+  const dim3 grid(a.N / 16), block(F16_NW * 64);
+  const size_t xbytes = (size_t)a.M * (a.K + 8) * 2;
+  if (xbytes <= 64 * 1024) {
+    auto k = gemv_f16_kernel<GATE_UP, NORM, true>;
+    static bool raised = false;                 // one opt-in per instantiation: dynamic LDS above the default 48 KB
+    if (!raised && xbytes > 32 * 1024) {
+      if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess) return -5;
+      raised = true;
+    }
+    hipLaunchKernelGGL(k, grid, block, xbytes, stream, a);
+  } else {
+    hipLaunchKernelGGL((gemv_f16_kernel<GATE_UP, NORM, false>), grid, block, 0, stream, a);
+  }
+  return HIP_CHECK_LAUNCH();
+}
+
 }  // namespace bigdl
 
 using namespace bigdl;
@@ -169,7 +245,7 @@ using namespace bigdl;
 extern "C" int bigdl_gemv_f16(const void* x, const void* w, const void* w2, void* out, const void* bias,
                               const void* bias2, const void* residual, const void* gamma, float eps, float gamma_offset,
                               int M, int N, int K, int ldx, int ldo, int act, int out_type, hipStream_t stream) {
-  if (M <= 0 || M > 16 || N <= 0 || (N & 15) || K <= 0 || (K & 63) || (ldx & 7) || ldx < K || ldo < N) return -1;
+  if (M <= 0 || M > 16 || N <= 0 || (N & 15) || K <= 0 || (K % F16_CK) || (ldx & 7) || ldx < K || ldo < N) return -1;
   if (((uintptr_t)x & 15) || ((uintptr_t)w & 15) || (w2 && ((uintptr_t)w2 & 15)) || (gamma && ((uintptr_t)gamma & 15)))
     return -1;
   if (out_type < 0 || out_type > 2) return -3;
@@ -178,13 +254,6 @@ extern "C" int bigdl_gemv_f16(const void* x, const void* w, const void* w2, void
   a.bias = (const _Float16*)bias; a.bias2 = (const _Float16*)bias2; a.residual = residual;
   a.gamma = (const _Float16*)gamma; a.eps = eps; a.gamma_offset = gamma_offset;
   a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldo = ldo; a.act = act; a.out_type = out_type;
-  const dim3 grid(N / 16), block(F16_NW * 64);
-  if (w2) {
-    if (gamma) hipLaunchKernelGGL((gemv_f16_kernel<true, true>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((gemv_f16_kernel<true, false>), grid, block, 0, stream, a);
-  } else {
-    if (gamma) hipLaunchKernelGGL((gemv_f16_kernel<false, true>), grid, block, 0, stream, a);
-    else hipLaunchKernelGGL((gemv_f16_kernel<false, false>), grid, block, 0, stream, a);
-  }
-  return HIP_CHECK_LAUNCH();
+  if (w2) return gamma ? launch_f16<true, true>(a, stream) : launch_f16<true, false>(a, stream);
+  return gamma ? launch_f16<false, true>(a, stream) : launch_f16<false, false>(a, stream);
 }

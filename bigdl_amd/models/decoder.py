@@ -346,13 +346,21 @@ class NativeDecoder:
         # token ids, a stage that is not the last returns hidden states instead of logits
         self.stage_first = True
         self.stage_last = True
+        # SnapKV prompt compression (transformers/kv.py ``snapkv_indices``; reference models/llama.py:182-188 +
+        # transformers/kv.py:171-243): dict(window_size, max_capacity_prompt, kernel_size, pooling) or None.  After a
+        # compressed prompt the cache is shorter than the sequence: decode steps take their rotary angles from a copy of
+        # the table shifted by the difference (``rope_dec``), so positions keep counting from the real length.
+        self.compress_kv = None
+        self.rope_dec = None
+        self._rope_shift = 0
+        self._rope_shift_buf = None
         if os.environ.get("BIGDL_PREFILL_DENSE_CACHE") == "1":
             Lin.cache_dense = True
         # tensor parallelism (bigdl_amd/parallel/tensor_parallel.py ``shard_engine``): partial sums of the
         # row-parallel projections are all-reduced over this group
         self.tp_group = None
         self.tp_world = 1
-        self.tp_fast_allreduce = None   # parallel/xgmi_allreduce.py ``OneShotAllReduce`` (opt-in)
+        self.tp_fast_allreduce = None   # parallel/xgmi_allreduce.py ``XgmiAllReduce`` once its self-check passed
         # timing attributes with the reference's names (utils/benchmark_util_4_47.py:3372-3393)
         self.first_cost = self.rest_cost_mean = self.encoder_time = self.peak_memory = 0.0
         self.first_token_time = 0.0
@@ -369,6 +377,8 @@ class NativeDecoder:
             # (longrope picks its factor set by the length the table has to serve)
             self.inv_freq, self.rope_scaling_factor = compute_inv_freq(self.cfg, self.device, seq_len=needed)
             self._build_rope_table(self.cache.capacity)
+            self._rope_shift_buf = None
+            self._set_rope_shift(0)
             if self.cache.int4 and not self.fused_rope:
                 raise ValueError("the int4 KV cache needs the attention kernel's own RoPE + append (full or interleaved "
                                  "rotary); this model rotates part of the head in rotate-half order")
@@ -385,6 +395,30 @@ class NativeDecoder:
             ang = torch.zeros_like(ang)          # identity rotation: the prompt path only appends k / v
         self.rope_table = torch.stack([ang.cos(), ang.sin()], -1).mul_(self.rope_scaling_factor).contiguous()
         self.fused_rope = self.no_rope or cfg.rope_interleaved or (cfg.rot_dim or cfg.head_dim) == cfg.head_dim
+
+    def _set_rope_shift(self, off: int):
+        """Decode position = cache length + ``off`` (non-zero after a compressed prompt)."""
+        self._rope_shift = off
+        if off == 0:
+            self.rope_dec = self.rope_table
+            return
+        if self._rope_shift_buf is None:
+            self._rope_shift_buf = torch.zeros_like(self.rope_table)
+        n = self.rope_table.shape[0]
+        self._rope_shift_buf[: n - off].copy_(self.rope_table[off:])
+        self.rope_dec = self._rope_shift_buf
+
+    def _compress_plan(self, past, s, slot, nd):
+        """The SnapKV settings that apply to this prompt pass, or None."""
+        ck = self.compress_kv
+        if not ck or past != 0 or slot is not None or nd or s <= ck.get("max_capacity_prompt", 1024):
+            return None
+        if self.cache.int4 or not self.fused_rope or self.no_rope or self.tp_group is not None:
+            return None          # (int4 rows carry per-key scales in a second plane; ALiBi / learned positions count keys)
+        if any(lw.window or lw.mla is not None for lw in self.layers):
+            return None
+        return dict(window_size=ck.get("window_size", 32), max_capacity_prompt=ck.get("max_capacity_prompt", 1024),
+                    kernel_size=ck.get("kernel_size", 7), pooling=ck.get("pooling", "maxpool"))
 
     # ------------------------------------------------------------------ prefill (eager)
     def _linear_dense(self, x, lin: Lin):
@@ -480,6 +514,9 @@ class NativeDecoder:
         else:
             h = hidden.to(torch.float16).reshape(b * s, cfg.hidden_size)
         hq, hkv, d = cfg.num_heads, cfg.num_kv_heads, cfg.head_dim
+        snap = self._compress_plan(past, s, slot, nd)
+        if past == 0 and slot is None and self._rope_shift:
+            self._set_rope_shift(0)
         for li, lw in enumerate(self.layers):
             x = self._norm(h, lw.input_norm, lw.input_norm_b)
             qkv = self._linear_dense(x, lw.qkv) if lw.mla is None else self._mla_qkv_dense(x, lw.mla)
@@ -516,6 +553,16 @@ class NativeDecoder:
             else:
                 kk, vt = self._read_cache(li, past + s, slot)
             attn = self._sdpa(q, kk, vt, past, lw.window).reshape(b * s, hq * d)
+            if snap is not None:
+                # the prompt has attended to all of its keys; what later tokens will see is the voted subset + the window
+                from ..transformers.kv import snapkv_indices
+                w_, cap_ = snap["window_size"], snap["max_capacity_prompt"]
+                keep = snapkv_indices(q, k, num_key_value_groups=hq // hkv, scale=self.attn_scale, **snap)   # [b,hkv,cap-w]
+                nk = cap_ - w_
+                kc[:, :, :nk] = kc[:, :, : s - w_].gather(2, keep[..., None].expand(-1, -1, -1, d))
+                kc[:, :, nk:cap_] = kc[:, :, s - w_: s].clone()
+                vc[:, :, :, :nk] = vc[:, :, :, : s - w_].gather(3, keep[:, :, None, :].expand(-1, -1, d, -1))
+                vc[:, :, :, nk:cap_] = vc[:, :, :, s - w_: s].clone()
             if nd:
                 attn = torch.cat([attn, attn_d])
             o = self._tp_reduce(self._linear_dense(attn, lw.o))
@@ -537,6 +584,10 @@ class NativeDecoder:
         if slot is not None:
             cache.past_len[slot] += s
             cache.slot_len[slot] += s
+        elif snap is not None:
+            cache.past_len.fill_(snap["max_capacity_prompt"])
+            cache.host_len = snap["max_capacity_prompt"]
+            self._set_rope_shift(s - snap["max_capacity_prompt"])
         else:
             cache.past_len.add_(s)
             cache.host_len += s
@@ -671,7 +722,7 @@ class NativeDecoder:
         hip.attn_decode(qkv, cache.k[li], cache.v[li], cache.past_len, out, st["ws"], st["counters"],
                         n_heads=cfg.num_heads, n_kv_heads=cfg.num_kv_heads, head_dim=cfg.head_dim, q_len=1,
                         batch=batch, scale=self.attn_scale, splits=st["splits"], softcap=cfg.attn_softcap,
-                        window=lw.window, rope_table=self.rope_table if self.fused_rope and not self.no_rope else None,
+                        window=lw.window, rope_table=self.rope_dec if self.fused_rope and not self.no_rope else None,
                         append=self.no_rope, alibi=self.alibi, interleaved=cfg.rope_interleaved, defer_combine=False,
                         **cache.scales(li))
         return out
@@ -926,7 +977,7 @@ class NativeDecoder:
                             n_heads=cfg.num_heads, n_kv_heads=cfg.num_kv_heads, head_dim=cfg.head_dim, q_len=q_len,
                             batch=batch, scale=self.attn_scale, splits=st["splits"], softcap=cfg.attn_softcap,
                             window=lw.window,
-                            rope_table=self.rope_table if self.fused_rope and not self.no_rope else None,
+                            rope_table=self.rope_dec if self.fused_rope and not self.no_rope else None,
                             append=self.no_rope, alibi=self.alibi,
                             interleaved=cfg.rope_interleaved, defer_combine=st["defer"] and lw.o.fused, **cache.scales(li))
             att_partials = st["att_partials"] if st["defer"] and lw.o.fused else None
@@ -972,7 +1023,7 @@ class NativeDecoder:
         cache.past_len.add_(cache.active, alpha=q_len)
 
     def _get_graph(self, batch: int, q_len: int, chain: bool):
-        key = (batch, q_len, chain)
+        key = (batch, q_len, chain, self._rope_shift != 0)      # (the shifted rotary table is a different buffer)
         if key in self._graphs:
             return self._graphs[key], self._static[(batch, q_len)]
         st = self._static.get((batch, q_len))

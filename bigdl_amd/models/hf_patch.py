@@ -533,8 +533,11 @@ def native_generate(self, inputs=None, **kwargs):
     if max_new is None:
         ml = kwargs.get("max_length", getattr(gc, "max_length", None) or 20)
         max_new = max(1, ml - input_ids.shape[1])
-    from ..transformers.utils import engine_kv_mode
+    from ..transformers.utils import engine_kv_mode, should_use_compresskv
     eng = get_native_engine(self)
+    # IPEX_LLM_COMPRESS_KV_CACHE=1: SnapKV selection at the end of every layer's prompt pass (engine prefill)
+    eng.compress_kv = dict(window_size=32, max_capacity_prompt=1024, kernel_size=7, pooling="maxpool") \
+        if should_use_compresskv(None, input_ids.shape[1]) else None
     out = eng.generate(
         input_ids, max_new_tokens=max_new, min_new_tokens=kwargs.get("min_new_tokens", 0) or 0,
         do_sample=kwargs.get("do_sample", getattr(gc, "do_sample", False)) or False,

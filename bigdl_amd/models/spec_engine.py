@@ -53,6 +53,8 @@ class SelfSpeculativeEngine:
             d._static.clear()
             d.inv_freq, d.rope_scaling_factor = t.inv_freq, t.rope_scaling_factor
             d.rope_table, d.no_rope, d.fused_rope = t.rope_table, t.no_rope, t.fused_rope
+            d._rope_shift_buf = None
+            d._set_rope_shift(0)
         t.cache.reset()
 
     @torch.no_grad()
@@ -73,6 +75,8 @@ class SelfSpeculativeEngine:
         torch.cuda.synchronize()
         tic = time.perf_counter()
         logits = t.prefill(input_ids)[:, -1, :]
+        if d._rope_shift != t._rope_shift:                   # a compressed prompt: both count positions from its real length
+            d._set_rope_shift(t._rope_shift)
         last = logits.argmax(-1).view(1, 1)                  # device
         generated = [int(last)]
         self.first_token_time = self.first_cost = time.perf_counter() - tic

@@ -56,6 +56,8 @@ def init_distributed(backend: Optional[str] = None, timeout_s: int = 1800):
             kw["device_id"] = device
         dist.init_process_group(backend=backend, rank=rank, world_size=world,
                                 timeout=datetime.timedelta(seconds=timeout_s), **kw)
+        if world > 1 and os.environ.get("BIGDL_NO_CONTROL_GROUP") != "1":
+            control_group()          # every rank passes here: the side group exists before anyone needs it
     return dist.get_rank(), dist.get_world_size(), device
 
 
@@ -143,11 +145,32 @@ def all_reduce_coalesced_(tensors, group=None, bucket_mb: int = DEFAULT_BUCKET_M
     return tensors
 
 
+_CONTROL = {}       # default group id -> gloo side group
+
+
+def control_group():
+    """A gloo group over the same ranks as the default group, for host-side control messages (pickled requests, stop
+    flags, shapes).  On an RCCL job ``broadcast_object_list`` would otherwise stage every pickle through the GPU: a
+    device allocation, two collectives and a stream synchronisation per message, queued behind whatever compute the
+    stream holds.  Created on first use by ALL ranks together (call it once at start-up, e.g. right after
+    ``init_distributed``); on a gloo job the default group already is one."""
+    if world_size() <= 1:
+        return None
+    if dist.get_backend() == "gloo":
+        return dist.group.WORLD
+    key = id(dist.group.WORLD)
+    if key not in _CONTROL:
+        _CONTROL[key] = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=1800))
+    return _CONTROL[key]
+
+
 def broadcast_object(obj, src=0, group=None):
+    """Pickle-broadcast over the control (gloo) group unless a group is given."""
     if world_size() <= 1:
         return obj
     box = [obj]
-    dist.broadcast_object_list(box, src=src, group=group)
+    dist.broadcast_object_list(box, src=src, group=group if group is not None else control_group(),
+                               device=torch.device("cpu") if group is None else None)
     return box[0]
 
 

@@ -241,9 +241,9 @@ def _concat_t16(bufs, qtype, rows, k):
 
 def shard_engine(engine, rank: int, world: int, group=None, fast_allreduce=None):
     """Tensor-parallel view of a ``NativeDecoder``: attention heads and MLP columns are split over ``world`` ranks,
-    the engine all-reduces after o_proj and down_proj (see ``NativeDecoder.tp_group``).  ``fast_allreduce=True`` (or
-    ``BIGDL_XGMI_ALLREDUCE=1``) routes the decode-sized all-reduces through the one-shot IPC kernel
-    (``parallel/xgmi_allreduce.py``) instead of RCCL."""
+    the engine all-reduces after o_proj and down_proj (see ``NativeDecoder.tp_group``).  On GPUs the all-reduces go
+    through the IPC kernels of ``parallel/xgmi_allreduce.py`` once their start-up self-check has passed on every rank
+    (``fast_allreduce=False`` or ``BIGDL_XGMI_ALLREDUCE=0``: RCCL)."""
     import dataclasses
     if world == 1:
         return engine
@@ -273,10 +273,10 @@ def shard_engine(engine, rank: int, world: int, group=None, fast_allreduce=None)
     engine.tp_world = world
     if fast_allreduce is None:
         import os
-        fast_allreduce = os.environ.get("BIGDL_XGMI_ALLREDUCE") == "1"
+        fast_allreduce = os.environ.get("BIGDL_XGMI_ALLREDUCE", "1") != "0"
     if fast_allreduce and engine.device.type == "cuda":
         from .xgmi_allreduce import XgmiAllReduce
-        engine.tp_fast_allreduce = XgmiAllReduce(engine.tp_group, device=engine.device)
+        engine.tp_fast_allreduce = XgmiAllReduce.create_verified(engine.tp_group, device=engine.device)
     engine.cache = None
     engine._graphs.clear()
     engine._static.clear()

@@ -7,8 +7,10 @@ gloo) process group, and each call is a single kernel launch on the current stre
 hipGraph, because the call counter lives in device memory.  Ranks must sit in one node (xGMI / same host); anything
 else, other dtypes or larger messages fall back to ``torch.distributed.all_reduce``.
 
-Opt-in (``BIGDL_XGMI_ALLREDUCE=1`` or ``shard_engine(..., fast_allreduce=True)``): the kernel is verified with two
-processes sharing one GPU (``tests/test_allreduce_gpu.py``); the default for multi-GPU runs stays RCCL.
+On by default for tensor-parallel engines (``shard_engine``; ``BIGDL_XGMI_ALLREDUCE=0`` turns it off) behind a
+self-check at start-up: ``XgmiAllReduce.create_verified`` runs both kernels on known data, compares with the process
+group's own all-reduce on every rank, and hands back None (RCCL stays in charge) unless every rank agrees that the IPC
+path set up and summed correctly.
 """
 from __future__ import annotations
 
@@ -159,6 +161,45 @@ class XgmiAllReduce:
         self.group = group
         self.small = OneShotAllReduce(group, small_bytes, device)
         self.large = TwoShotAllReduce(group, large_bytes, device)
+
+    @classmethod
+    def create_verified(cls, group=None, device=None, **kw):
+        """Set up, run a self-check against ``dist.all_reduce`` and return the object, or None when any rank failed to
+        set up or saw a wrong sum (every rank takes the same decision)."""
+        import warnings
+        ok, obj, why = 1, None, ""
+        try:
+            obj = cls(group, device=device, **kw)
+        except Exception as e:            # IPC not permitted, ranks on different hosts, allocation failure, ...
+            ok, why = 0, f"set-up failed: {e}"
+        dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        if ok:
+            try:
+                rank = dist.get_rank(group)
+                for n in (4096, 1 << 19):                     # 8 KB: one-shot; 1 MB: two-shot
+                    base = torch.arange(n, device=dev, dtype=torch.float32).remainder_(13).add_(rank + 1).to(torch.float16)
+                    want = base.clone()
+                    dist.all_reduce(want, group=group)
+                    got = base.clone()
+                    for _ in range(3):                        # repeated calls walk the epoch counters
+                        got.copy_(base)
+                        obj(got)
+                    if not torch.equal(got, want):
+                        ok, why = 0, f"wrong sum at {n} elements"
+                        break
+                if ok:
+                    obj.check()
+            except Exception as e:
+                ok, why = 0, f"self-check raised: {e}"
+        flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if int(flag.item()) == 1:
+            return obj
+        if obj is not None:
+            obj.close()
+        warnings.warn("IPC all-reduce disabled, using the process group's all-reduce"
+                      + (f" ({why})" if why else " (a peer rank failed its self-check)"))
+        return None
 
     def usable(self, t):
         return self.small.usable(t) or self.large.usable(t)

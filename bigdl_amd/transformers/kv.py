@@ -110,16 +110,15 @@ class Fp8Layer(NormalLayer):
         return src.contiguous().view(torch.float8_e5m2).to(dtype)
 
 
-def compress_kv(query_states, key_states, value_states, window_size=32, max_capacity_prompt=1024, kernel_size=7,
-                pooling="maxpool", num_key_value_groups=1):
-    """SnapKV selection.  q [B,Hq,S,D], k/v [B,Hkv,S,D] -> k/v [B,Hkv,min(S, max_capacity_prompt),D]."""
+def snapkv_indices(query_states, key_states, window_size=32, max_capacity_prompt=1024, kernel_size=7, pooling="maxpool",
+                   num_key_value_groups=1, scale=None):
+    """SnapKV vote: which ``max_capacity_prompt - window_size`` prefix positions each kv head keeps, ascending.
+    q [B,Hq,S,D], k [B,Hkv,S,D] (both already rotated) -> int64 [B,Hkv,keep]."""
     b, hq, s, d = query_states.shape
-    if s <= max_capacity_prompt:
-        return key_states, value_states
     hkv = key_states.shape[1]
     k_rep = key_states.repeat_interleave(num_key_value_groups, 1) if num_key_value_groups > 1 else key_states
     q_win = query_states[:, :, -window_size:, :].float()
-    attn = torch.matmul(q_win, k_rep.float().transpose(2, 3)) / math.sqrt(d)          # [B,Hq,W,S]
+    attn = torch.matmul(q_win, k_rep.float().transpose(2, 3)) * (scale if scale is not None else 1.0 / math.sqrt(d))  # [B,Hq,W,S]
     mask = torch.full((window_size, window_size), torch.finfo(attn.dtype).min, device=attn.device)
     mask = torch.triu(mask, diagonal=1)
     attn[:, :, :, -window_size:] += mask[None, None]
@@ -131,7 +130,17 @@ def compress_kv(query_states, key_states, value_states, window_size=32, max_capa
         pooled = F.avg_pool1d(votes, kernel_size=kernel_size, padding=kernel_size // 2, stride=1)
     else:
         pooled = F.max_pool1d(votes, kernel_size=kernel_size, padding=kernel_size // 2, stride=1)
-    keep = pooled.topk(max_capacity_prompt - window_size, dim=-1).indices.sort(dim=-1).values
+    return pooled.topk(max_capacity_prompt - window_size, dim=-1).indices.sort(dim=-1).values
+
+
+def compress_kv(query_states, key_states, value_states, window_size=32, max_capacity_prompt=1024, kernel_size=7,
+                pooling="maxpool", num_key_value_groups=1):
+    """SnapKV selection.  q [B,Hq,S,D], k/v [B,Hkv,S,D] -> k/v [B,Hkv,min(S, max_capacity_prompt),D]."""
+    b, hq, s, d = query_states.shape
+    if s <= max_capacity_prompt:
+        return key_states, value_states
+    keep = snapkv_indices(query_states, key_states, window_size, max_capacity_prompt, kernel_size, pooling,
+                          num_key_value_groups)
     idx = keep.unsqueeze(-1).expand(-1, -1, -1, d)
     k_past = key_states[:, :, :-window_size, :].gather(2, idx)
     v_past = value_states[:, :, :-window_size, :].gather(2, idx)

