@@ -265,9 +265,18 @@ class MoEWeights:
 
     def forward_a2a(self, x):
         """Tokens sharded over the expert-parallel group: dispatch routed rows to the owners of their experts,
-        compute there, return them (two ``all_to_all_single`` exchanges of [rows, hidden] with variable splits)."""
+        compute there, return them.  Three collectives per layer: the split sizes, one dispatch whose rows carry
+        their local expert id in 8 spare halves behind the hidden vector, one return.
+
+        The split sizes are read on the host once per layer, because ``all_to_all_single`` takes them as host lists.
+        The fixed-shape alternative (every rank sends a capacity-padded block to every peer) would either move
+        world/capacity_factor times the bytes over links that are the bottleneck of this exchange (xGMI is
+        point-to-point: an all-to-all is bound per link) or drop rows that overflow; at prompt sizes one host read
+        (~50 us) per layer is the cheaper of the two.  Decode steps use ``forward_gather_scatter`` (fixed shape,
+        graph-captured)."""
         import torch.distributed as dist
         t, k = x.shape[0], self.top_k
+        hdim = x.shape[1]
         per = self.n_local
         ids, w = self.route(x, local_only=False)                     # global expert ids
         flat = ids.reshape(-1).long()
@@ -277,18 +286,22 @@ class MoEWeights:
         send_counts = torch.bincount(dest, minlength=self.ep_world)
         recv_counts = torch.empty_like(send_counts)
         dist.all_to_all_single(recv_counts, send_counts, group=self.group)
-        send_n, recv_n = send_counts.tolist(), recv_counts.tolist()  # the one host round trip: split sizes
-        send_x = x[tok].contiguous()
-        send_e = (flat[order] % per).int().contiguous()
-        recv_x = x.new_empty((sum(recv_n), x.shape[1]))
-        recv_e = send_e.new_empty((sum(recv_n),))
-        dist.all_to_all_single(recv_x, send_x, recv_n, send_n, group=self.group)
-        dist.all_to_all_single(recv_e, send_e, recv_n, send_n, group=self.group)
-        if recv_x.shape[0]:
-            y = self.local_ffn(recv_x, recv_e.view(-1, 1), torch.ones(recv_e.numel(), 1, device=x.device))
+        both = torch.stack([send_counts, recv_counts]).tolist()     # the one host round trip: split sizes
+        send_n, recv_n = both
+        # payload rows: [hidden | local expert id as the raw bits of an int32 | padding to 16 bytes]
+        pad = 8 if x.element_size() == 2 else 4
+        send = x.new_zeros((tok.numel(), hdim + pad))
+        send[:, :hdim] = x[tok]
+        eid = (flat[order] % per).to(torch.int32)
+        send[:, hdim:hdim + 4 // x.element_size()] = eid.view(-1, 1).view(x.dtype)
+        recv = x.new_empty((sum(recv_n), hdim + pad))
+        dist.all_to_all_single(recv, send, recv_n, send_n, group=self.group)
+        if recv.shape[0]:
+            recv_e = recv[:, hdim:hdim + 4 // x.element_size()].contiguous().view(torch.int32).view(-1)
+            y = self.local_ffn(recv[:, :hdim].contiguous(), recv_e.view(-1, 1), torch.ones(recv_e.numel(), 1, device=x.device))
         else:
-            y = recv_x
-        back = x.new_empty(send_x.shape)
+            y = recv[:, :hdim]
+        back = x.new_empty((tok.numel(), hdim))
         dist.all_to_all_single(back, y.contiguous(), send_n, recv_n, group=self.group)
         out = torch.zeros_like(x)
         out.index_add_(0, tok, back * w.reshape(-1)[order].to(x.dtype)[:, None])

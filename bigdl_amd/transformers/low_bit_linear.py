@@ -311,9 +311,16 @@ def _all_reduce(t, group):
 class LowBitLinear(nn.Linear):
     def __init__(self, input_features, output_features, qtype, bias=True, conver_to_half=True, mp_group=None,
                  optimize_lm_head=False, act_order=False, enable_scale_search=False):
-        super().__init__(input_features, output_features, bias)
-        self.weight = FP4Params(self.weight.data, requires_grad=False, quantized=False, _shape=None, qtype=qtype,
-                                enable_scale_search=enable_scale_search)
+        # nn.Linear.__init__ would draw a full fp32 kaiming-uniform weight that the converter replaces right away
+        # (6.5e9 random numbers for a 7B model: most of the conversion / load time): allocate without initialising
+        nn.Module.__init__(self)
+        self.in_features, self.out_features = input_features, output_features
+        self.weight = FP4Params(torch.empty(output_features, input_features), requires_grad=False, quantized=False,
+                                _shape=None, qtype=qtype, enable_scale_search=enable_scale_search)
+        if bias:
+            self.bias = nn.Parameter(torch.zeros(output_features))
+        else:
+            self.register_parameter("bias", None)
         self.in_len = input_features
         self.out_len = output_features
         self.weight_shape = (self.out_len, self.in_len)
@@ -366,7 +373,13 @@ class _HalfLinear(nn.Linear):
 
     def __init__(self, input_features, output_features, bias=True, mp_group=None, weight_type=1,
                  optimize_lm_head=False):
-        super().__init__(input_features, output_features, bias)
+        nn.Module.__init__(self)          # (no random init of a weight the converter replaces)
+        self.in_features, self.out_features = input_features, output_features
+        self.weight = nn.Parameter(torch.empty(output_features, input_features, dtype=self._dtype), requires_grad=False)
+        if bias:
+            self.bias = nn.Parameter(torch.zeros(output_features, dtype=self._dtype), requires_grad=False)
+        else:
+            self.register_parameter("bias", None)
         self.in_len = input_features
         self.out_len = output_features
         self.weight_shape = (self.out_len, self.in_len)

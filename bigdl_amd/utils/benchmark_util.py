@@ -24,7 +24,8 @@ class BenchmarkWrapper:
         self.peak_memory = 0.0
         self.first_token_time = 0.0
         self.last_token_time = []
-        print(self.model.__class__)
+        if do_print:
+            print(self.model.__class__)
 
     def __getattr__(self, attr):
         if attr in self.__dict__:
