@@ -576,7 +576,7 @@ def optimize_post(model):
                 getattr(m, "experts", [])) and not hasattr(m, "num_experts"):
             seen.add(cls)
             convert_forward(model, cls, mlp_forward)
-    if getattr(cfg, "model_type", None) == "rwkv":
+    if getattr(cfg, "model_type", None) in ("rwkv", "rwkv5"):
         from .rwkv import bind_rwkv
         bind_rwkv(model)
     base = getattr(model, "model", None)

@@ -7,7 +7,7 @@ Capability map to the reference python/llm/src/ipex_llm/transformers/gguf/api.py
 The model is built from the stock HuggingFace classes on the meta device and filled tensor by tensor from the mapped
 file (dequantized to ``dtype`` by the C++ host library); ``AutoModelForCausalLM.from_gguf`` then runs the normal
 low-bit conversion.  The tokenizer is rebuilt from the gguf vocabulary with HuggingFace's own gguf tokenizer
-converters.  ``yuan2`` needs remote model code that is not part of transformers and is rejected with a clear error.
+converters.  ``yuan2`` is not part of transformers: it is served by this package's own model class (models/yuan.py).
 """
 from __future__ import annotations
 
@@ -314,6 +314,56 @@ def load_gguf_mpt(loader, dtype=torch.float, low_bit=None):
     return _finish(model, dtype), _tokenizer(loader, "gpt2")
 
 
+_YUAN_MAP = dict(_LLAMA_MAP, lf_output_norm="self_attn.lf_gate.output_layernorm", conv1="self_attn.lf_gate.conv1",
+                 conv2="self_attn.lf_gate.conv2")
+
+
+def load_gguf_yuan2(loader, dtype=torch.float, low_bit="sym_int4"):
+    """Yuan 2.0 files identify themselves as architecture ``llama`` with "yuan" in ``general.name``; next to the llama
+    tensors every block carries the localized filter (``conv1`` / ``conv2`` weight + bias, ``lf_output_norm``).  q / k
+    rows are stored in model order (no llama.cpp head permutation).  The model class is this package's own
+    (bigdl_amd/models/yuan.py); reference builder: transformers/gguf/models/yuan2.py:26-130."""
+    from ...models.yuan import YuanConfig, YuanForCausalLM
+    cfg = loader.config
+    config = YuanConfig(vocab_size=len(cfg["tokenizer.ggml.tokens"]), hidden_size=cfg["llama.embedding_length"],
+                        intermediate_size=cfg["llama.feed_forward_length"], num_hidden_layers=cfg["llama.block_count"],
+                        num_attention_heads=cfg["llama.attention.head_count"],
+                        max_position_embeddings=cfg["llama.context_length"],
+                        rms_norm_eps=cfg["llama.attention.layer_norm_rms_epsilon"],
+                        rope_theta=float(cfg.get("llama.rope.freq_base", 10000.0)),
+                        pad_token_id=cfg.get("tokenizer.ggml.padding_token_id"), bos_token_id=cfg.get("tokenizer.ggml.bos_token_id"),
+                        eos_token_id=cfg.get("tokenizer.ggml.eos_token_id"),
+                        sep_token_id=cfg.get("tokenizer.ggml.seperator_token_id"))
+    with torch.device("meta"):
+        model = YuanForCausalLM(config)
+    tl = loader.tensor_loader
+    top = {"token_embd.weight": "model.embed_tokens.weight", "output_norm.weight": "model.norm.weight",
+           "output.weight": "lm_head.weight"}
+    for name in tl.names():
+        hf = top.get(name)
+        m = re.match(r"blk\.(\d+)\.(\w+)\.(weight|bias)$", name)
+        if hf is None and m and m.group(2) in _YUAN_MAP:
+            hf = f"model.layers.{m.group(1)}.{_YUAN_MAP[m.group(2)]}.{m.group(3)}"
+        if hf is None:
+            continue
+        t = tl.load(name, torch.float32)
+        if ".conv" in hf and hf.endswith("weight") and t.dim() != 4:
+            out_c = t.shape[0]
+            t = t.reshape(out_c, -1, 2, 1)                        # files that flatten the [out, in, 2, 1] kernel
+        _fill(model, hf, t, dtype)
+    model = _finish(model, dtype)
+    # the rotary table is a buffer, not a tensor of the file
+    for layer in model.model.layers:
+        att = layer.self_attn
+        att.inv_freq = 1.0 / (config.rope_theta ** (torch.arange(0, att.head_dim, 2).float() / att.head_dim))
+    tok = _tokenizer(loader, "llama")
+    if tok is not None:
+        tok.add_tokens(["<sep>", "<pad>", "<mask>", "<predict>", "<FIM_SUFFIX>", "<FIM_PREFIX>", "<FIM_MIDDLE>",
+                        "<commit_before>", "<commit_msg>", "<commit_after>", "<jupyter_start>", "<jupyter_text>",
+                        "<jupyter_code>", "<jupyter_output>", "<empty_output>"], special_tokens=True)
+    return model, tok
+
+
 def load_gguf_model(fpath: str, dtype: torch.dtype = torch.float, low_bit: str = "sym_int4"):
     loader = GGUFFileLoader(fpath)
     family = loader.config["general.architecture"]
@@ -326,8 +376,8 @@ def load_gguf_model(fpath: str, dtype: torch.dtype = torch.float, low_bit: str =
                 return load_gguf_mixtral(loader, dtype, low_bit)
             if "mistral" in general_name:
                 return load_gguf_mistral(loader, dtype, low_bit)
-            invalidInputError("yuan" not in general_name,
-                              "yuan2 gguf files need the model's remote code, which is not available offline")
+            if "yuan" in general_name:
+                return load_gguf_yuan2(loader, dtype, low_bit)
             return load_gguf_llama(loader, dtype, low_bit)
         if family == "qwen2":
             return load_gguf_qwen2(loader, dtype, low_bit)

@@ -171,6 +171,13 @@ def _one_rank_pipeline(stages) -> bool:
         and torch.distributed.get_world_size() == 1
 
 
+def _register_builtin_families():
+    from ..models.yuan import register
+    register()
+
+
+_register_builtin_families()
+
 class _BaseAutoModelClass:
     HF_MODEL = None
 

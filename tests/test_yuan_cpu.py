@@ -1,0 +1,144 @@
+"""Yuan 2.0 (bigdl_amd/models/yuan.py): the matrix-product form of the localized filter against the literal conv2d
+formulation of the architecture (reference gguf/models/model_implement/yuan2/yuan_hf_model.py:66-86), incremental
+decoding against the full pass, and the GGUF builder on a synthetic file."""
+import torch
+
+from bigdl_amd.models.yuan import LocalizedFiltering, YuanConfig, YuanForCausalLM
+
+
+def _literal_filter(lf, x):
+    """the architecture as published: 2-tap conv2d over [B, C, T, 1] with one row of padding, truncated to T rows"""
+    b, t, c = x.shape
+    inp = x.transpose(0, 1).reshape(t, 1, b, c).permute(2, 3, 0, 1)
+    o1 = lf.conv1(inp)[:, :, :t, :]
+    o2 = lf.conv2(o1)[:, :, :t, :].permute(2, 3, 0, 1).contiguous().view(t, b, c)
+    return lf.output_layernorm(o2 + x.transpose(0, 1)).transpose(0, 1)
+
+
+def test_filter_equals_conv2d_formulation_and_streams():
+    torch.manual_seed(0)
+    lf = LocalizedFiltering(32).double()
+    x = torch.randn(2, 9, 32, dtype=torch.float64)
+    want = _literal_filter(lf, x)
+    torch.testing.assert_close(lf(x), want)
+    # streaming: after a prompt of 4 the filter continues token by token from the two-step memory
+    got = [lf(x[:, :4])]
+    for t in range(4, 9):
+        got.append(lf(x[:, t:t + 1], x[:, t - 2:t]))
+    torch.testing.assert_close(torch.cat(got, 1), want)
+    # a one-token prompt: the memory is (zero, x0), as the model keeps it
+    one = lf(x[:, :1])
+    two = lf(x[:, 1:2], torch.cat([torch.zeros_like(x[:, :1]), x[:, :1]], 1))
+    torch.testing.assert_close(torch.cat([one, two], 1), want[:, :2])
+
+
+def _tiny():
+    torch.manual_seed(1)
+    cfg = YuanConfig(vocab_size=96, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+                     max_position_embeddings=128, eos_token_id=None)
+    return YuanForCausalLM(cfg).eval()
+
+
+def test_incremental_decoding_matches_full_forward():
+    m = _tiny()
+    ids = torch.randint(0, 96, (2, 11))
+    full = m(ids).logits
+    out = m(ids[:, :5], use_cache=True)
+    steps = [out.logits]
+    past = out.past_key_values
+    for t in range(5, 11):
+        out = m(ids[:, t:t + 1], past_key_values=past, use_cache=True)
+        past = out.past_key_values
+        steps.append(out.logits)
+    torch.testing.assert_close(torch.cat(steps, 1), full, rtol=1e-4, atol=1e-4)
+    gen = m.generate(ids[:, :5], max_new_tokens=4)
+    assert gen.shape == (2, 9) and torch.equal(gen[:, :5], ids[:, :5])
+    assert torch.equal(gen[:, 5], full[:, 4].argmax(-1))
+
+
+def test_q_and_k_head_pairing():
+    """q / k are cut from [q_proj(f) | k_proj(f)] viewed as heads of width 2d: head i of q is columns [2i d, (2i+1) d) of the
+    concatenation, head i of k the d columns after them"""
+    m = _tiny()
+    att = m.model.layers[0].self_attn
+    x = torch.randn(1, 3, 64)
+    f = att.lf_gate(x)
+    cat = torch.cat([att.q_proj(f), att.k_proj(f)], -1)
+    d = att.head_dim
+    pos = torch.arange(3)[None]
+    seen = {}
+    orig = torch.nn.functional.scaled_dot_product_attention
+
+    def spy(q, k, v, **kw):
+        seen["q"], seen["k"] = q, k
+        return orig(q, k, v, **kw)
+    torch.nn.functional.scaled_dot_product_attention = spy
+    try:
+        att(x, pos)
+    finally:
+        torch.nn.functional.scaled_dot_product_attention = orig
+    # position 0 is not rotated (angle 0): compare there
+    for i in range(att.num_heads):
+        torch.testing.assert_close(seen["q"][0, i, 0], cat[0, 0, 2 * i * d:(2 * i + 1) * d])
+        torch.testing.assert_close(seen["k"][0, i, 0], cat[0, 0, (2 * i + 1) * d:(2 * i + 2) * d])
+
+
+def test_gguf_yuan2_builder(tmp_path):
+    from bigdl_amd.transformers.gguf import GGUFWriter
+    from bigdl_amd.transformers.gguf import gguf as G
+    from bigdl_amd.transformers.gguf.api import load_gguf_model
+    m = _tiny()
+    sd = m.state_dict()
+    wr = GGUFWriter()
+    wr.add("general.architecture", "llama")
+    wr.add("general.name", "Yuan2-tiny")
+    wr.add("general.file_type", 1)
+    for k, v in (("embedding_length", 64), ("feed_forward_length", 128), ("block_count", 2), ("attention.head_count", 4),
+                 ("attention.head_count_kv", 4), ("context_length", 128)):
+        wr.add("llama." + k, v)
+    wr.add("llama.attention.layer_norm_rms_epsilon", 1e-6)
+    wr.add("tokenizer.ggml.model", "llama")
+    wr.add("tokenizer.ggml.tokens", ["<unk>", "<s>", "<eod>"] + [f"▁t{i}" for i in range(93)])
+    wr.add("tokenizer.ggml.scores", [0.0] * 96)
+    wr.add("tokenizer.ggml.token_type", [2, 3, 3] + [1] * 93)
+    for k, v in (("bos_token_id", 1), ("eos_token_id", 2), ("padding_token_id", 0), ("seperator_token_id", 3)):
+        wr.add("tokenizer.ggml." + k, v)
+    wr.add_tensor("token_embd.weight", sd["model.embed_tokens.weight"], G.GGML_F16)
+    wr.add_tensor("output_norm.weight", sd["model.norm.weight"], G.GGML_F32)
+    wr.add_tensor("output.weight", sd["lm_head.weight"], G.GGML_F16)
+    names = {"attn_q": "self_attn.q_proj", "attn_k": "self_attn.k_proj", "attn_v": "self_attn.v_proj",
+             "attn_output": "self_attn.o_proj", "ffn_gate": "mlp.gate_proj", "ffn_up": "mlp.up_proj", "ffn_down": "mlp.down_proj"}
+    for i in range(2):
+        p = f"model.layers.{i}."
+        for g, h in names.items():
+            wr.add_tensor(f"blk.{i}.{g}.weight", sd[p + h + ".weight"], G.GGML_F16)
+        for g, h in (("attn_norm", "input_layernorm"), ("ffn_norm", "post_attention_layernorm"),
+                     ("lf_output_norm", "self_attn.lf_gate.output_layernorm")):
+            wr.add_tensor(f"blk.{i}.{g}.weight", sd[p + h + ".weight"], G.GGML_F32)
+        for g in ("conv1", "conv2"):
+            wr.add_tensor(f"blk.{i}.{g}.weight", sd[p + f"self_attn.lf_gate.{g}.weight"], G.GGML_F32)
+            wr.add_tensor(f"blk.{i}.{g}.bias", sd[p + f"self_attn.lf_gate.{g}.bias"], G.GGML_F32)
+    path = str(tmp_path / "yuan.gguf")
+    wr.write(path)
+    model, tok = load_gguf_model(path, dtype=torch.float32)
+    assert type(model).__name__ == "YuanForCausalLM" and model.config.num_hidden_layers == 2
+    ids = torch.randint(0, 96, (1, 7))
+    ref = m(ids).logits
+    got = model(ids).logits
+    torch.testing.assert_close(got, ref, rtol=2e-2, atol=2e-2)          # fp16 storage of the linears
+    assert model.generate(ids, max_new_tokens=3).shape == (1, 10)
+    assert tok is not None and "<FIM_MIDDLE>" in tok.get_vocab()
+
+
+def test_auto_classes_load_yuan_checkpoints_in_low_bit(tmp_path):
+    from bigdl_amd.transformers import AutoModelForCausalLM
+    m = _tiny()
+    ids = torch.randint(0, 96, (1, 6))
+    ref = m(ids).logits
+    m.save_pretrained(tmp_path)
+    q = AutoModelForCausalLM.from_pretrained(str(tmp_path), load_in_low_bit="sym_int8")
+    assert type(q).__name__ == "YuanForCausalLM" and type(q.model.layers[0].self_attn.q_proj).__name__ == "LowBitLinear"
+    assert hasattr(q.model.layers[0].self_attn, "v_proj")            # q / k / v stay separate: they read different streams
+    cos = torch.nn.functional.cosine_similarity(q(ids).logits.flatten(), ref.flatten(), dim=0)
+    assert cos > 0.999
+    assert q.generate(ids, max_new_tokens=3).shape == (1, 9)
