@@ -32,8 +32,12 @@ constexpr int PF_BN = 64;
 
 // QB = 16-query blocks per wavefront: every K / V^T fragment read from LDS feeds QB MFMAs, which is what keeps the
 // kernel off the LDS-bandwidth limit (QB = 2: 128 queries per workgroup).
-template <int D, bool HAS_MASK, bool VT, int QB>
+// DR = the model's head_dim when it is not a multiple of 32 (72: SigLIP / MiniCPM-V vision towers, 80: phi-2): the
+// tiles are D = 96 wide, loads beyond channel DR read as zero (they add nothing to q . k and their output columns
+// are not stored), so such heads need neither a padded copy of q / k / v nor a fallback path.
+template <int D, bool HAS_MASK, bool VT, int QB, int DR = D>
 __global__ __launch_bounds__(256) void attn_prefill_kernel(PrefillArgs a) {
+  static_assert(DR <= D && DR % 8 == 0, "head_dim must be a multiple of 8 within the tile width");
   constexpr int BM = 64 * QB;
   constexpr int KS = D + 8;          // halves per K row in LDS (16 B pad)
   constexpr int VS = PF_BN + 8;      // halves per V^T row
@@ -67,7 +71,8 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(PrefillArgs a) {
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
       half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-      qf[u][s] = qi[u] < a.Sq ? *(const half8*)(a.q + b * a.q_sb + hq * a.q_sh + (int64_t)qi[u] * a.q_ss + 32 * s + 8 * g) : z;
+      const bool in_head = DR == D || 32 * s + 8 * g < DR;
+      qf[u][s] = qi[u] < a.Sq && in_head ? *(const half8*)(a.q + b * a.q_sb + hq * a.q_sh + (int64_t)qi[u] * a.q_ss + 32 * s + 8 * g) : z;
     }
   float4v o[QB][DB];
   float m[QB], l[QB];
@@ -97,13 +102,16 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(PrefillArgs a) {
       const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
       {
         const int key = c / CH, dc = c % CH;
-        kreg[i] = k0 + key < a.Lk ? *(const half8*)(kbase + (int64_t)(k0 + key) * a.k_ss + 8 * dc) : z;
-        if constexpr (!VT) vreg[i] = k0 + key < a.Lk ? *(const half8*)(vbase + (int64_t)(k0 + key) * a.v_ss + 8 * dc) : z;
+        const bool live = k0 + key < a.Lk && (DR == D || 8 * dc < DR);
+        kreg[i] = live ? *(const half8*)(kbase + (int64_t)(k0 + key) * a.k_ss + 8 * dc) : z;
+        if constexpr (!VT) vreg[i] = live ? *(const half8*)(vbase + (int64_t)(k0 + key) * a.v_ss + 8 * dc) : z;
       }
       if constexpr (VT) {
         const int d = c / (PF_BN / 8), kc = c % (PF_BN / 8);
         const _Float16* vp = vbase + (int64_t)d * a.v_ss + k0 + 8 * kc;
-        if (k0 + 8 * kc + 8 <= a.Lk) {
+        if (DR != D && d >= DR) {
+          vreg[i] = z;
+        } else if (k0 + 8 * kc + 8 <= a.Lk) {
           vreg[i] = *(const half8*)vp;
         } else {
           half8 t = z;
@@ -242,9 +250,10 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(PrefillArgs a) {
   for (int u = 0; u < QB; ++u)
     if (qi[u] < a.Sq) {
       const float inv = l[u] > 0.0f ? 1.0f / l[u] : 0.0f;
-      _Float16* op = a.out + b * a.o_sb + (int64_t)qi[u] * a.o_ss + hq * D;
+      _Float16* op = a.out + b * a.o_sb + (int64_t)qi[u] * a.o_ss + hq * DR;
 #pragma unroll
       for (int db = 0; db < DB; ++db) {
+        if (DR != D && 16 * db + 4 * g >= DR) continue;
         half4 h;
 #pragma unroll
         for (int e = 0; e < 4; ++e) h[e] = (_Float16)(o[u][db][e] * inv);
@@ -479,32 +488,32 @@ extern "C" int bigdl_prefill_rope_append(void* qkv, void* kc, void* vc, void* vt
   return HIP_CHECK_LAUNCH();
 }
 
-template <int D, bool HAS_MASK, bool VT, int QB>
+template <int D, bool HAS_MASK, bool VT, int QB, int DR = D>
 static int launch_pf_one(const PrefillArgs& a, hipStream_t st) {
   const dim3 grid((a.Sq + 64 * QB - 1) / (64 * QB), a.Hq, a.B), block(256);
   constexpr size_t lds = ((size_t)PF_BN * (D + 8) + (size_t)D * (PF_BN + 8)) * 2;
   static bool attr = false;
   if (!attr && lds > 65536) {
-    if (hipFuncSetAttribute((const void*)attn_prefill_kernel<D, HAS_MASK, VT, QB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void*)attn_prefill_kernel<D, HAS_MASK, VT, QB, DR>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)
       return -5;
     attr = true;
   }
-  hipLaunchKernelGGL((attn_prefill_kernel<D, HAS_MASK, VT, QB>), grid, block, lds, st, a);
+  hipLaunchKernelGGL((attn_prefill_kernel<D, HAS_MASK, VT, QB, DR>), grid, block, lds, st, a);
   return HIP_CHECK_LAUNCH();
 }
 
-template <int D, int QB>
+template <int D, int QB, int DR = D>
 static int launch_pf_qb(const PrefillArgs& a, hipStream_t st) {
-  if (a.mask) return a.v_transposed ? launch_pf_one<D, true, true, QB>(a, st) : launch_pf_one<D, true, false, QB>(a, st);
-  return a.v_transposed ? launch_pf_one<D, false, true, QB>(a, st) : launch_pf_one<D, false, false, QB>(a, st);
+  if (a.mask) return a.v_transposed ? launch_pf_one<D, true, true, QB, DR>(a, st) : launch_pf_one<D, true, false, QB, DR>(a, st);
+  return a.v_transposed ? launch_pf_one<D, false, true, QB, DR>(a, st) : launch_pf_one<D, false, false, QB, DR>(a, st);
 }
 
-template <int D>
+template <int D, int DR = D>
 static int launch_pf(const PrefillArgs& a, hipStream_t st) {
   // QB = 2 (128 queries per workgroup) halves the LDS traffic per MFMA but needs 240 VGPRs (one wavefront per
   // SIMD); measured slower than QB = 1 from 1K to 8K tokens on MI355X, so QB = 1 is used throughout.
-  return launch_pf_qb<D, 1>(a, st);
+  return launch_pf_qb<D, 1, DR>(a, st);
 }
 
 // q [B, Hq, Sq, D], k / v [B, Hkv, Lk, D] as strided fp16 views (element strides, last dim contiguous);
@@ -529,6 +538,8 @@ extern "C" int bigdl_attn_prefill(const void* q, const void* k, const void* v, v
   a.scale = scale; a.softcap = softcap; a.causal = causal; a.window = window; a.v_transposed = v_transposed;
   switch (D) {
     case 64: return launch_pf<64>(a, st);
+    case 72: return launch_pf<96, 72>(a, st);
+    case 80: return launch_pf<96, 80>(a, st);
     case 96: return launch_pf<96>(a, st);
     case 128: return launch_pf<128>(a, st);
     case 256: return launch_pf<256>(a, st);

@@ -35,6 +35,8 @@ MERGE_QKV_TYPES = {"llama", "mistral", "qwen2", "qwen3", "gemma", "gemma2", "sta
 NATIVE_ENGINE_TYPES = {"llama", "mistral", "qwen2", "gemma", "gemma2", "phi3", "mixtral", "qwen2_moe", "yi", "granite"}
 
 
+PREFILL_HEAD_DIMS = (64, 72, 80, 96, 128, 256)      # ops/hip.py attn_prefill
+
 def _is_cuda(t):
     return t.device.type == "cuda"
 
@@ -214,10 +216,11 @@ def attention_forward(self, hidden_states, position_embeddings=None, attention_m
 
 
 def _native_attention(module, q, k, v, attention_mask, kwargs):
-    """The MFMA flash-attention kernel for the module path: fp16 tensors on the GPU, head_dim 64 / 96 / 128 / 256, inference.
+    """The MFMA flash-attention kernel for the module path: fp16 tensors on the GPU, head_dim 64 / 72 / 80 / 96 / 128 / 256,
+    inference (72 and 80 -- SigLIP-style vision towers, phi-2 -- run in 96-wide tiles without a padded copy).
     HF hands over either no mask (pure causal) or an additive / boolean [B, 1, Sq, Lk] mask that already contains the
     causal and sliding-window structure.  Returns [B, Sq, Hq*D] or None when the case is not covered."""
-    if not _is_cuda(q) or q.dtype != torch.float16 or torch.is_grad_enabled() or q.shape[-1] not in (64, 96, 128, 256) \
+    if not _is_cuda(q) or q.dtype != torch.float16 or torch.is_grad_enabled() or q.shape[-1] not in PREFILL_HEAD_DIMS \
             or kwargs.get("output_attentions") or module.training:
         return None
     if q.stride(-1) != 1 or k.stride(-1) != 1 or v.stride(-1) != 1 or any(t.stride(i) % 8 for t in (q, k, v) for i in (0, 1, 2)):
@@ -248,7 +251,7 @@ def hip_attention_interface(module, query, key, value, attention_mask, dropout=0
     {gpt2,gptneox,phi,starcoder2,whisper,bert}.py).  Cases the kernel does not cover fall through to PyTorch SDPA."""
     from transformers.integrations.sdpa_attention import sdpa_attention_forward
     d = query.shape[-1]
-    ok = (_is_cuda(query) and query.dtype == torch.float16 and not torch.is_grad_enabled() and d in (64, 96, 128, 256)
+    ok = (_is_cuda(query) and query.dtype == torch.float16 and not torch.is_grad_enabled() and d in PREFILL_HEAD_DIMS
           and not module.training and not dropout and kwargs.get("position_bias") is None
           and query.dim() == 4 and key.shape[1] > 0 and query.shape[1] % key.shape[1] == 0)
     if ok:

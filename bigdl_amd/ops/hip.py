@@ -804,7 +804,7 @@ def kv_int4_dequant(k_cache, v_cache, k_scale, v_scale, length):
     return k.reshape(b, h, length, d), v.reshape(b, h, d, length)
 
 
-PREFILL_HEAD_DIMS = (64, 96, 128, 256)
+PREFILL_HEAD_DIMS = (64, 72, 80, 96, 128, 256)
 
 
 def _check_alibi(alibi, n_heads):
@@ -823,7 +823,7 @@ def attn_prefill(q, k, v, *, scale, causal=True, mask=None, softcap=0.0, window=
     b, hq, sq, d = q.shape
     hkv, lk = k.shape[1], k.shape[2]
     if d not in PREFILL_HEAD_DIMS:
-        raise ValueError("attn_prefill supports head_dim 64, 96, 128 and 256")
+        raise ValueError("attn_prefill supports head_dim 64, 72, 80, 96, 128 and 256")
     for t in (q, k, v):
         if t.dtype != torch.float16 or t.stride(-1) != 1:
             raise ValueError("q / k / v must be fp16 with a contiguous last dim")

@@ -795,3 +795,26 @@ def test_int4_kv_cache_append_and_decode(hip, cfg, interleaved):
     exact = _ref_attention(q_rot, torch.cat([k_prompt, k_new], 2), torch.cat([v_prompt, v_new], 2), scale, past=past)
     rel = ((got - exact).abs().mean() / exact.abs().mean()).item()
     assert rel < 0.25, rel
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d", [72, 80])
+@pytest.mark.parametrize("causal,sq,lk,hq,hkv", [(False, 729, 729, 16, 16), (True, 200, 200, 8, 2), (True, 5, 133, 4, 4)])
+def test_attn_prefill_head_dim_72_80(d, causal, sq, lk, hq, hkv):
+    """SigLIP (72) and phi-2 (80) heads run in 96-wide tiles straight from the unpadded tensors."""
+    from bigdl_amd.ops import hip
+    g = torch.Generator(device="cuda").manual_seed(d + sq)
+    # views into a fused [B, S, H * D] projection output, as the module path hands them over
+    q = torch.randn(2, sq, hq * d, device="cuda", generator=g).half().view(2, sq, hq, d).transpose(1, 2)
+    k = torch.randn(2, lk, hkv * d, device="cuda", generator=g).half().view(2, lk, hkv, d).transpose(1, 2)
+    v = torch.randn(2, lk, hkv * d, device="cuda", generator=g).half().view(2, lk, hkv, d).transpose(1, 2)
+    out = hip.attn_prefill(q, k, v, scale=d ** -0.5, causal=causal)
+    kf = k.float().repeat_interleave(hq // hkv, 1)
+    vf = v.float().repeat_interleave(hq // hkv, 1)
+    s = q.float() @ kf.transpose(-1, -2) * d ** -0.5
+    if causal:
+        keep = torch.ones(sq, lk, dtype=torch.bool, device="cuda").tril(lk - sq)
+        s = s.masked_fill(~keep, float("-inf"))
+    want = (torch.softmax(s, -1) @ vf).transpose(1, 2).reshape(2, sq, hq * d)
+    assert out.shape == want.shape
+    assert (out.float() - want).abs().max().item() < 2e-2
