@@ -73,6 +73,9 @@ class DecoderConfig:
     moe_n_group: int = 1              # DeepSeek-V2 group-limited routing: expert groups, and how many of them compete
     moe_topk_group: int = 1
     logit_scale: float = 1.0
+    # Qwen2-VL multimodal rotary embedding: how many of the rot/2 frequencies take their angle from the temporal,
+    # height and width position of a token (text tokens carry the same value on all three axes)
+    mrope_section: Optional[tuple] = None
 
     @property
     def q_size(self):
@@ -405,7 +408,10 @@ class NativeDecoder:
         if self._rope_shift_buf is None:
             self._rope_shift_buf = torch.zeros_like(self.rope_table)
         n = self.rope_table.shape[0]
-        self._rope_shift_buf[: n - off].copy_(self.rope_table[off:])
+        if off > 0:                       # a compressed prompt: positions run ahead of the cache length
+            self._rope_shift_buf[: n - off].copy_(self.rope_table[off:])
+        else:                             # image tokens share positions: the cache is longer than the position count
+            self._rope_shift_buf[-off:].copy_(self.rope_table[: n + off])
         self.rope_dec = self._rope_shift_buf
 
     def _compress_plan(self, past, s, slot, nd):
@@ -468,7 +474,8 @@ class NativeDecoder:
 
     @torch.no_grad()
     def prefill(self, input_ids: Optional[torch.Tensor], last_only: bool = True, slot: Optional[int] = None,
-                with_decode: bool = False, hidden: Optional[torch.Tensor] = None):
+                with_decode: bool = False, hidden: Optional[torch.Tensor] = None,
+                inputs_embeds: Optional[torch.Tensor] = None, mrope_positions: Optional[torch.Tensor] = None):
         """input_ids [B, S] (device).  Fills the cache from position past_len and returns logits
         ([B, 1, V] if last_only else [B, S, V]).  With ``slot`` (continuous batching) input_ids is one sequence
         [1, S] that is appended to cache row ``slot`` only.
@@ -485,6 +492,9 @@ class NativeDecoder:
         if not self.stage_first:
             assert hidden is not None and not with_decode, "a later pipeline stage is fed hidden states [B, S, hidden]"
             b, s = hidden.shape[:2]
+        elif inputs_embeds is not None:
+            # multimodal prompts: the caller has merged image features into the token embeddings
+            b, s = inputs_embeds.shape[:2]
         else:
             b, s = input_ids.shape
         if slot is not None:
@@ -501,7 +511,11 @@ class NativeDecoder:
             nd = cache.batch
             st = self._get_graph(nd, 1, True)[1]         # the decode step's static buffers: tokens, workspace
         if self.stage_first:
-            h = F.embedding(input_ids, self.embed).to(torch.float16)
+            if inputs_embeds is not None:
+                assert not with_decode
+                h = inputs_embeds.to(self.device, torch.float16)
+            else:
+                h = F.embedding(input_ids, self.embed).to(torch.float16)
             if cfg.embed_scale != 1.0:
                 h = h * cfg.embed_scale
             h = h.reshape(b * s, cfg.hidden_size)
@@ -517,6 +531,24 @@ class NativeDecoder:
         snap = self._compress_plan(past, s, slot, nd)
         if past == 0 and slot is None and self._rope_shift:
             self._set_rope_shift(0)
+        rope_table, rope_pos, mrope_delta = self.rope_table, None, 0
+        if mrope_positions is not None:
+            # one table row per prompt token: frequency i takes the angle of the token's position on the axis that
+            # ``mrope_section`` assigns to i; the append / rotate kernel then indexes rows 0 .. B*S-1
+            assert past == 0 and slot is None and not nd and cfg.mrope_section and self.fused_rope and not self.no_rope, \
+                "3-axis rotary positions apply to a whole prompt on an engine built with mrope_section"
+            mp = mrope_positions.to(self.device)
+            if mp.shape[0] == 4:                       # (text, t, h, w): the text row duplicates what the engine counts
+                mp = mp[1:]
+            axis = torch.repeat_interleave(torch.arange(3, device=self.device),
+                                           torch.tensor(list(cfg.mrope_section), device=self.device))
+            assert axis.numel() == self.rope_table.shape[1], "mrope_section must cover rot_dim / 2 frequencies"
+            sel = mp[axis].permute(1, 2, 0)                                        # [B, S, rot/2]
+            rope_table = self.rope_table[sel, torch.arange(axis.numel(), device=self.device)].reshape(b * s, -1, 2).contiguous()
+            rope_pos = torch.arange(b * s, device=self.device).view(b, s)
+            top = mp.amax(dim=(0, 2))                                              # per sequence
+            assert bool((top == top[0]).all()), "sequences of one batch must end at the same rotary position"
+            mrope_delta = int(top[0]) + 1 - s
         for li, lw in enumerate(self.layers):
             x = self._norm(h, lw.input_norm, lw.input_norm_b)
             qkv = self._linear_dense(x, lw.qkv) if lw.mla is None else self._mla_qkv_dense(x, lw.mla)
@@ -541,12 +573,14 @@ class NativeDecoder:
                 ksc, vsc = cache.k_scale[li], cache.v_scale[li]
                 if slot is not None:
                     ksc, vsc = ksc[slot:slot + 1], vsc[slot:slot + 1]
-                hip.prefill_rope_append(qkv, None, None, self.rope_table, n_heads=hq, n_kv_heads=hkv, head_dim=d,
-                                        past=past, rot_dim=rot, interleaved=cfg.rope_interleaved, vt_scratch=scratch)
+                hip.prefill_rope_append(qkv, None, None, rope_table, n_heads=hq, n_kv_heads=hkv, head_dim=d,
+                                        past=past, rot_dim=rot, interleaved=cfg.rope_interleaved, vt_scratch=scratch,
+                                        position_ids=rope_pos)
                 hip.kv_int4_append(qkv, kc, vc, ksc, vsc, n_heads=hq, n_kv_heads=hkv, head_dim=d, past=past)
             else:
-                hip.prefill_rope_append(qkv, kc, vc, self.rope_table, n_heads=hq, n_kv_heads=hkv, head_dim=d, past=past,
-                                        rot_dim=rot, interleaved=cfg.rope_interleaved, vt_scratch=scratch)
+                hip.prefill_rope_append(qkv, kc, vc, rope_table, n_heads=hq, n_kv_heads=hkv, head_dim=d, past=past,
+                                        rot_dim=rot, interleaved=cfg.rope_interleaved, vt_scratch=scratch,
+                                        position_ids=rope_pos)
             vt = scratch[..., :s] if scratch is not None else vc[:, :, :, :s]
             if past == 0:
                 kk = k                       # attention reads the unquantized K / V^T of this call
@@ -587,10 +621,12 @@ class NativeDecoder:
         elif snap is not None:
             cache.past_len.fill_(snap["max_capacity_prompt"])
             cache.host_len = snap["max_capacity_prompt"]
-            self._set_rope_shift(s - snap["max_capacity_prompt"])
+            self._set_rope_shift(s - snap["max_capacity_prompt"] + mrope_delta)
         else:
             cache.past_len.add_(s)
             cache.host_len += s
+            if mrope_delta:
+                self._set_rope_shift(mrope_delta)
         if nd:
             x = self._norm(h[s - 1:], self.final_norm, self.final_norm_b)            # last prompt token + the decode rows
             logits = self._finish_logits(self._linear_dense(x, self.lm_head).float())
@@ -1076,8 +1112,10 @@ class NativeDecoder:
     @torch.no_grad()
     def generate(self, input_ids: torch.Tensor, max_new_tokens: int = 32, min_new_tokens: int = 0, do_sample=False,
                  temperature=1.0, top_k=0, top_p=1.0, repetition_penalty=1.0, eos_token_id=None, pad_token_id=None,
-                 streamer=None, kv_fp8: bool = False, stopping=None):
-        """Greedy / sampling generation with per-token timing in the reference benchmark's terms."""
+                 streamer=None, kv_fp8: bool = False, stopping=None, inputs_embeds=None, mrope_positions=None):
+        """Greedy / sampling generation with per-token timing in the reference benchmark's terms.  ``inputs_embeds``
+        [B, S, hidden] / ``mrope_positions`` [3, B, S]: a multimodal prompt as its wrapper model prepared it (the
+        token ids are still what is returned in front of the generated tokens)."""
         from ..ops import hip
         dev = self.device
         input_ids = input_ids.to(dev)
@@ -1088,7 +1126,7 @@ class NativeDecoder:
         torch.cuda.synchronize()
         torch.cuda.reset_peak_memory_stats()
         t0 = time.perf_counter()
-        logits = self.prefill(input_ids)[:, -1, :]
+        logits = self.prefill(input_ids, inputs_embeds=inputs_embeds, mrope_positions=mrope_positions)[:, -1, :]
         out = [input_ids]
         unfinished = torch.ones(b, dtype=torch.bool, device=dev)
         all_ids = input_ids

@@ -19,6 +19,7 @@ from __future__ import annotations
 import logging
 import os
 import sys
+import inspect
 import types
 
 import torch
@@ -31,7 +32,11 @@ logger = logging.getLogger("bigdl_amd")
 
 # model types whose attention modules follow the llama layout (q_proj/k_proj/v_proj/o_proj + rotary cos/sin)
 MERGE_QKV_TYPES = {"llama", "mistral", "qwen2", "qwen3", "gemma", "gemma2", "stablelm", "starcoder2", "minicpm",
-                   "mixtral", "qwen2_moe", "olmo", "cohere", "internlm3", "yi", "glm", "granite"}
+                   "mixtral", "qwen2_moe", "olmo", "cohere", "internlm3", "yi", "glm", "granite",
+                   "qwen2_vl", "qwen2_vl_text", "qwen2_5_vl", "qwen2_5_vl_text"}
+# multimodal wrappers whose language model the native engine can drive: the wrapper's own forward merges image features
+# into the token embeddings and computes the (3-axis) rotary positions, the engine takes both from there
+VL_ENGINE_TYPES = {"qwen2_vl", "qwen2_5_vl"}
 NATIVE_ENGINE_TYPES = {"llama", "mistral", "qwen2", "gemma", "gemma2", "phi3", "mixtral", "qwen2_moe", "yi", "granite"}
 
 
@@ -85,12 +90,14 @@ def optimize_pre(model, qtype=None):
         # HF divides output / value weights of deeper blocks in place at the first inference call; that has to
         # happen on the dense weights, before they become quantized byte buffers (reference convert.py:1035-1048)
         model.rwkv._rescale_layers()
-    # multimodal wrappers: recurse into the language model with its own config
-    for attr in ("language_model", "llm"):
-        sub = getattr(model, attr, None)
-        if isinstance(sub, nn.Module) and getattr(getattr(sub, "config", None), "model_type", None) in MERGE_QKV_TYPES \
-                and sub is not model:
-            optimize_pre(sub, qtype)
+    # multimodal wrappers: recurse into the language model with its own config (``model.language_model``, or
+    # ``model.model.language_model`` where the wrapper keeps towers and decoder under one base module)
+    for holder in (model, getattr(model, "model", None)):
+        for attr in ("language_model", "llm"):
+            sub = getattr(holder, attr, None) if holder is not None else None
+            if isinstance(sub, nn.Module) and getattr(getattr(sub, "config", None), "model_type", None) in MERGE_QKV_TYPES \
+                    and sub is not model and mt not in MERGE_QKV_TYPES:
+                optimize_pre(sub, qtype)
     return model
 
 
@@ -191,6 +198,8 @@ def attention_forward(self, hidden_states, position_embeddings=None, attention_m
         q, k = self.q_norm(q), self.k_norm(k)
     if position_embeddings is not None:
         cos, sin = position_embeddings
+        if cos.dim() == 4:                             # [3, B, S, D]: temporal / height / width positions (Qwen2-VL)
+            cos, sin = merge_mrope(cos, sin, _mrope_section(self))
         q, k = apply_rotary(q, k, cos, sin)
     if past_key_values is not None:
         if getattr(past_key_values, "wants_query", False):     # SnapKV selection scores the prompt with its last queries
@@ -213,6 +222,22 @@ def attention_forward(self, hidden_states, position_embeddings=None, attention_m
                                           scaling=self.scaling, **extra, **kwargs)
     attn_output = attn_output.reshape(*input_shape, -1).contiguous()
     return self.o_proj(attn_output), attn_weights
+
+
+def _mrope_section(module):
+    rp = getattr(module.config, "rope_parameters", None) or getattr(module.config, "rope_scaling", None) or {}
+    sec = rp.get("mrope_section") or getattr(module, "rope_scaling", {}).get("mrope_section")
+    if not sec:
+        raise ValueError("3-axis rotary positions without an mrope_section in the model config")
+    return list(sec)
+
+
+def merge_mrope(cos, sin, section):
+    """cos / sin [3, B, S, D] (one rotary table per position axis) -> [B, S, D]: frequency block j of each half of the
+    head takes its angles from axis j % 3 (reference models/qwen2_vl.py:268-319, HF ``apply_multimodal_rotary_pos_emb``)."""
+    sec = list(section) * 2
+    pick = lambda t: torch.cat([m[i % 3] for i, m in enumerate(t.split(sec, dim=-1))], dim=-1)   # noqa: E731
+    return pick(cos), pick(sin)
 
 
 def _native_attention(module, q, k, v, attention_mask, kwargs):
@@ -372,6 +397,10 @@ def decoder_config_from_hf(cfg):
     if mt == "mixtral":
         dc.num_experts, dc.top_k = cfg.num_local_experts, cfg.num_experts_per_tok
         dc.moe_intermediate_size = cfg.intermediate_size
+    if rope_params.get("mrope_section") or (rope_scaling or {}).get("mrope_section"):
+        dc.mrope_section = tuple(rope_params.get("mrope_section") or rope_scaling["mrope_section"])
+        if (dc.rope_scaling or {}).get("rope_type", (dc.rope_scaling or {}).get("type")) in ("mrope", "default", None):
+            dc.rope_scaling = None             # "mrope" only says how positions are assigned, the frequencies are plain
     if mt == "qwen2_moe":
         dc.num_experts, dc.top_k = cfg.num_experts, cfg.num_experts_per_tok
         dc.moe_intermediate_size = cfg.moe_intermediate_size
@@ -410,14 +439,23 @@ def _split_lin_rows(module, sizes):
     return outs
 
 
+def _text_parts(model):
+    """(decoder stack module, text config) of a causal LM or of a multimodal wrapper around one."""
+    cfg = model.config
+    base = getattr(model, "model", None)
+    if getattr(cfg, "model_type", None) in VL_ENGINE_TYPES:
+        lm = getattr(base, "language_model", None) or getattr(model, "language_model", None)
+        return lm, getattr(cfg, "text_config", None) or cfg.get_text_config()
+    return base, cfg
+
+
 def build_native_decoder(model):
     """Wrap the (already converted, already on the GPU) HF model's weights in a ``NativeDecoder``.  No copies for
     T16 weights: the engine reads the same device buffers as the LowBitLinear modules."""
     from .decoder import LayerWeights, NativeDecoder
-    cfg = model.config
+    base, cfg = _text_parts(model)
     mt = cfg.model_type
     dc = decoder_config_from_hf(cfg)
-    base = model.model
     dev = base.embed_tokens.weight.device
     f16 = lambda t: t.detach().to(torch.float16).contiguous()  # noqa: E731
     layers = []
@@ -459,11 +497,12 @@ def build_native_decoder(model):
 
 def native_engine_supported(model) -> bool:
     cfg = getattr(model, "config", None)
-    if cfg is None or getattr(cfg, "model_type", None) not in NATIVE_ENGINE_TYPES:
+    if cfg is None or getattr(cfg, "model_type", None) not in NATIVE_ENGINE_TYPES | VL_ENGINE_TYPES:
         return False
-    if not hasattr(model, "model") or not hasattr(model.model, "layers") or not hasattr(model, "lm_head"):
+    base, cfg = _text_parts(model)
+    if base is None or not hasattr(base, "layers") or not hasattr(model, "lm_head"):
         return False
-    first = model.model.layers[0].self_attn
+    first = base.layers[0].self_attn
     if not (hasattr(first, "qkv_proj")):
         return False
     from ..transformers.hybrid import HostResident
@@ -476,7 +515,10 @@ def native_engine_supported(model) -> bool:
         return False          # the engine adds projection outputs to the residual stream unscaled
     from .decoder import SUPPORTED_ROPE_TYPES
     rs = getattr(cfg, "rope_scaling", None) or getattr(cfg, "rope_parameters", None) or {}
-    if rs.get("rope_type", rs.get("type")) not in SUPPORTED_ROPE_TYPES:
+    rope_type = rs.get("rope_type", rs.get("type"))
+    if rope_type == "mrope":
+        rope_type = "default"  # plain frequencies; the 3-axis position assignment is handled at prefill
+    if rope_type not in SUPPORTED_ROPE_TYPES:
         return False          # e.g. dynamic NTK: HF's own forward handles it
     if getattr(cfg, "model_type") in ("mixtral", "qwen2_moe"):
         try:
@@ -520,9 +562,11 @@ def native_generate(self, inputs=None, **kwargs):
         return self.speculative_generate(input_ids, **kwargs)
     for k in SPEC_ONLY_KWARGS:
         kwargs.pop(k, None)
+    vl_inputs = {k: kwargs[k] for k in _VL_INPUT_KEYS if kwargs.get(k) is not None}
+    plain_keys = set(kwargs) - set(_VL_INPUT_KEYS) if getattr(self.config, "model_type", None) in VL_ENGINE_TYPES else set(kwargs)
     try_native = (is_ids
                   and next(self.parameters()).device.type == "cuda"
-                  and set(kwargs) <= _PLAIN_GENERATE_KEYS and kwargs.get("num_beams", 1) == 1
+                  and plain_keys <= _PLAIN_GENERATE_KEYS and kwargs.get("num_beams", 1) == 1
                   and not kwargs.get("return_dict_in_generate", False) and native_engine_supported(self))
     am = kwargs.get("attention_mask")
     if try_native and am is not None and not bool(am.all()):
@@ -538,6 +582,10 @@ def native_generate(self, inputs=None, **kwargs):
         max_new = max(1, ml - input_ids.shape[1])
     from ..transformers.utils import engine_kv_mode, should_use_compresskv
     eng = get_native_engine(self)
+    extra = {}
+    if vl_inputs:
+        embeds, pos = language_model_inputs(self, input_ids, vl_inputs, am)
+        extra = dict(inputs_embeds=embeds, mrope_positions=pos if pos is not None and pos.dim() == 3 else None)
     # IPEX_LLM_COMPRESS_KV_CACHE=1: SnapKV selection at the end of every layer's prompt pass (engine prefill)
     eng.compress_kv = dict(window_size=32, max_capacity_prompt=1024, kernel_size=7, pooling="maxpool") \
         if should_use_compresskv(None, input_ids.shape[1]) else None
@@ -550,10 +598,54 @@ def native_generate(self, inputs=None, **kwargs):
         repetition_penalty=kwargs.get("repetition_penalty", getattr(gc, "repetition_penalty", 1.0)) or 1.0,
         eos_token_id=kwargs.get("eos_token_id", getattr(gc, "eos_token_id", None)),
         pad_token_id=kwargs.get("pad_token_id", getattr(gc, "pad_token_id", None)),
-        streamer=kwargs.get("streamer"), kv_fp8=engine_kv_mode())
+        streamer=kwargs.get("streamer"), kv_fp8=engine_kv_mode(), **extra)
     for attr in ("first_cost", "rest_cost_mean", "first_token_time", "last_token_time", "peak_memory"):
         object.__setattr__(self, attr, getattr(eng, attr))
     return out
+
+
+_VL_INPUT_KEYS = ("pixel_values", "image_grid_thw", "pixel_values_videos", "video_grid_thw", "mm_token_type_ids",
+                  "second_per_grid_ts")
+
+
+class _LanguageModelCall(Exception):
+    def __init__(self, kwargs):
+        super().__init__("captured")
+        self.kwargs = kwargs
+
+
+@torch.no_grad()
+def language_model_inputs(model, input_ids, vl_inputs, attention_mask=None):
+    """What a multimodal wrapper hands to its language model for this prompt: (inputs_embeds [B, S, hidden] with the
+    image / video features scattered over their placeholder tokens, position_ids -- [3, B, S] for Qwen2-VL's 3-axis
+    rotary embedding).  The wrapper's own forward (vision tower, merger, placeholder mask, position index) runs
+    unchanged up to the point where it calls the language model; that call is intercepted instead of executed, so
+    nothing here re-implements family-specific preprocessing (reference models/qwen2_vl.py:58-185 re-binds the wrapper's
+    forward for the same purpose)."""
+    base = getattr(model, "model", model)
+    lm = getattr(base, "language_model", None) or getattr(model, "language_model")
+    original = lm.forward
+    vl_inputs = dict(vl_inputs)
+    if "mm_token_type_ids" not in vl_inputs and "mm_token_type_ids" in inspect.signature(base.forward).parameters:
+        # the processor's token-type row (0 text, 1 image, 2 video), rebuilt from the placeholder ids
+        cfg = model.config
+        tt = torch.zeros_like(input_ids)
+        if getattr(cfg, "image_token_id", None) is not None:
+            tt = tt.masked_fill(input_ids == cfg.image_token_id, 1)
+        if getattr(cfg, "video_token_id", None) is not None:
+            tt = tt.masked_fill(input_ids == cfg.video_token_id, 2)
+        vl_inputs["mm_token_type_ids"] = tt
+
+    def intercept(*args, **kw):
+        raise _LanguageModelCall(kw)
+    lm.forward = intercept
+    try:
+        base(input_ids=input_ids, attention_mask=attention_mask, **vl_inputs)
+    except _LanguageModelCall as call:
+        return call.kwargs.get("inputs_embeds"), call.kwargs.get("position_ids")
+    finally:
+        lm.forward = original
+    raise RuntimeError("the multimodal wrapper did not call its language model")
 
 
 def optimize_post(model):

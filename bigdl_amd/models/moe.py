@@ -196,7 +196,11 @@ class MoEWeights:
 
     def _reduce(self, t):
         if self.group is not None or (self.expert_range is not None and torch.distributed.is_initialized()):
-            torch.distributed.all_reduce(t, group=self.group)
+            fast = getattr(self, "fast_allreduce", None)
+            if fast is not None and fast.usable(t):
+                fast(t)                   # IPC kernel: one launch, capturable in the decode graph
+            else:
+                torch.distributed.all_reduce(t, group=self.group)
         return t
 
     # ------------------------------------------------------------------ decode

@@ -16,6 +16,8 @@ once -- the reason to prefer it over a ring all-reduce of the full [tokens, hidd
 """
 from __future__ import annotations
 
+import os
+
 import torch.distributed as dist
 
 
@@ -33,6 +35,15 @@ def shard_engine_experts(engine, rank: int, world: int, group=None, mode: str = 
             n += 1
     if n == 0:
         raise ValueError("the model has no mixture-of-experts layers to shard")
+    if mode == "allreduce" and engine.device.type == "cuda" and os.environ.get("BIGDL_XGMI_ALLREDUCE", "1") != "0":
+        # the per-layer sum of the experts' partial outputs goes through the IPC all-reduce kernels once their start-up
+        # self-check has passed on every rank (parallel/xgmi_allreduce.py); otherwise the process group's all-reduce
+        from .xgmi_allreduce import XgmiAllReduce
+        fast = XgmiAllReduce.create_verified(group, device=engine.device)
+        engine.tp_fast_allreduce = fast            # generate() checks its error word after the last step
+        for lw in engine.layers:
+            if lw.moe is not None:
+                lw.moe.fast_allreduce = fast
     engine._graphs.clear()
     engine._static.clear()
     return engine

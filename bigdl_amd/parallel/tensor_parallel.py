@@ -254,8 +254,16 @@ def shard_engine(engine, rank: int, world: int, group=None, fast_allreduce=None)
     q, kv = cfg.q_size, cfg.kv_size
     for lw in engine.layers:
         if lw.mla is not None:
-            raise NotImplementedError("tensor-parallel sharding of latent-attention (MLA) layers")
-        lw.qkv = _shard_lin(lw.qkv, rank, world, "column", parts=[q, kv, kv], unit=hd)
+            # latent attention: the latents (``a`` and the norms) are shared by all heads and stay whole on every rank;
+            # what expands them into heads is sharded by head -- q (or q_b) and both halves [K heads | V heads] of kv_b
+            m = lw.mla
+            if m.q is not None:
+                m.q = _shard_lin(m.q, rank, world, "column", unit=hd)
+            else:
+                m.q_b = _shard_lin(m.q_b, rank, world, "column", unit=hd)
+            m.kv_b = _shard_lin(m.kv_b, rank, world, "column", parts=[q, q], unit=hd)
+        else:
+            lw.qkv = _shard_lin(lw.qkv, rank, world, "column", parts=[q, kv, kv], unit=hd)
         lw.o = _shard_lin(lw.o, rank, world, "row")
         if lw.moe is not None:
             lw.moe.shard_experts(rank, world, group)

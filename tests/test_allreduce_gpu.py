@@ -107,7 +107,7 @@ def test_two_shot_all_reduce_two_processes_one_gpu(tmp_path):
         assert int(torch.load(tmp_path / f"ok{r}.pt")) == WORLD
 
 
-def _tp_engine_worker(rank, port, out_dir):
+def _tp_engine_worker(rank, port, out_dir, mla=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD),
                       HSA_ENABLE_IPC_MODE_LEGACY="0")
     torch.cuda.set_device(0)
@@ -117,6 +117,10 @@ def _tp_engine_worker(rank, port, out_dir):
     from bigdl_amd.parallel.tensor_parallel import shard_engine
     cfg = DecoderConfig(vocab_size=320, hidden_size=256, intermediate_size=512, num_layers=2, num_heads=4, num_kv_heads=2,
                         head_dim=64, max_position=512)
+    if mla:     # latent attention (MiniCPM3 layout): 64 rotary + 32 plain channels per head, q and kv latents
+        cfg = DecoderConfig(vocab_size=320, hidden_size=256, intermediate_size=512, num_layers=2, num_heads=8, num_kv_heads=8,
+                            head_dim=96, max_position=512, rot_dim=32, rope_interleaved=True, mla_q_lora=128, mla_kv_lora=64,
+                            attn_scale=96 ** -0.5)
     ids = torch.randint(3, 320, (1, 20), generator=torch.Generator().manual_seed(0)).cuda()
     full = build_random_decoder(cfg, Q.SYM_INT4, device="cuda", seed=3)        # same seed: same weights on both ranks
     want = full.generate(ids, max_new_tokens=10)
@@ -124,7 +128,7 @@ def _tp_engine_worker(rank, port, out_dir):
     full.cache.reset()
     want_logits = full.prefill(ids, last_only=False).float().cpu()
     tp = shard_engine(build_random_decoder(cfg, Q.SYM_INT4, device="cuda", seed=3), rank, WORLD, fast_allreduce=True)
-    assert tp.tp_fast_allreduce is not None and tp.cfg.num_heads == 2
+    assert tp.tp_fast_allreduce is not None and tp.cfg.num_heads == (4 if mla else 2)
     got = tp.generate(ids, max_new_tokens=10)                                  # graph decode with the one-shot all-reduce
     tp.tp_fast_allreduce.check()
     tp.cache.reset()
@@ -137,11 +141,50 @@ def _tp_engine_worker(rank, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_tensor_parallel_engine_two_processes_one_gpu(tmp_path):
+@pytest.mark.parametrize("mla", [False, True])
+def test_tensor_parallel_engine_two_processes_one_gpu(tmp_path, mla):
     """TP = 2 native engine (column / row sharded T16 weights, hipGraph decode with the one-shot all-reduce inside)
-    against the unsharded engine."""
+    against the unsharded engine; ``mla``: latent-attention layers (heads of q_b / kv_b sharded, latents replicated)."""
     port = _free_port()
-    mp.spawn(_tp_engine_worker, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
+    mp.spawn(_tp_engine_worker, args=(port, str(tmp_path), mla), nprocs=WORLD, join=True)
     for r in range(WORLD):
         ok, rel = torch.load(tmp_path / f"tp{r}.pt").tolist()
+        assert ok == 1, f"rank {r}: rel diff {rel / 1e6}"
+
+
+def _ep_engine_worker(rank, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    from bigdl_amd import qtypes as Q
+    from bigdl_amd.models.decoder import DecoderConfig, build_random_decoder
+    from bigdl_amd.parallel.expert_parallel import shard_engine_experts
+    cfg = DecoderConfig(vocab_size=320, hidden_size=256, intermediate_size=512, num_layers=2, num_heads=4, num_kv_heads=2,
+                        head_dim=64, max_position=512, model_type="mixtral", num_experts=4, top_k=2, moe_intermediate_size=256)
+    ids = torch.randint(3, 320, (2, 24), generator=torch.Generator().manual_seed(0)).cuda()
+    full = build_random_decoder(cfg, Q.SYM_INT4, device="cuda", seed=5)
+    want = full.generate(ids, max_new_tokens=8)
+    full.cache.reset()
+    want_logits = full.prefill(ids, last_only=False).float().cpu()
+    # experts split over the ranks, tokens replicated: every rank adds its experts' share, one all-reduce per MoE layer
+    ep = shard_engine_experts(build_random_decoder(cfg, Q.SYM_INT4, device="cuda", seed=5), rank, WORLD, mode="allreduce")
+    assert ep.layers[0].moe.n_local == 2 and ep.layers[0].moe.expert_range == (2 * rank, 2 * rank + 2)
+    got = ep.generate(ids, max_new_tokens=8)
+    ep.cache.reset()
+    got_logits = ep.prefill(ids, last_only=False).float().cpu()
+    rel = ((got_logits - want_logits).abs().mean() / want_logits.abs().mean()).item()
+    ok = rel < 2e-2 and (got == want).float().mean().item() >= 0.8
+    torch.save(torch.tensor([int(ok), int(rel * 1e6)]), os.path.join(out_dir, f"ep{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_expert_parallel_engine_two_processes_one_gpu(tmp_path):
+    """Expert-parallel engine (experts sharded, partial sums all-reduced inside the decode step) against the whole
+    engine.  The all-to-all form of the exchange needs one GPU per rank (RCCL); its arithmetic is covered on the host
+    in tests/test_parallel_cpu.py."""
+    port = _free_port()
+    mp.spawn(_ep_engine_worker, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
+    for r in range(WORLD):
+        ok, rel = torch.load(tmp_path / f"ep{r}.pt").tolist()
         assert ok == 1, f"rank {r}: rel diff {rel / 1e6}"

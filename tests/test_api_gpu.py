@@ -317,3 +317,98 @@ def test_granite_multipliers_and_streamed_prompt(tmp_path):
     q2 = AutoModelForCausalLM.from_pretrained(d2, load_in_low_bit="sym_int8").half().to("cuda")
     assert not native_engine_supported(q2)
     assert q2.generate(ids, max_new_tokens=3, do_sample=False).shape == (1, 15)
+
+
+def test_qwen2_vl_prompt_with_image_on_the_engine():
+    """Image features + 3-axis rotary positions reach the engine: prompt logits and the following decode steps agree
+    with the HuggingFace forward of the same (low-bit) model."""
+    import copy
+    from transformers import Qwen2VLConfig, Qwen2VLForConditionalGeneration
+    from bigdl_amd.models.hf_patch import get_native_engine, language_model_inputs, native_engine_supported
+    from bigdl_amd.optimize import optimize_model
+    cfg = Qwen2VLConfig(
+        text_config=dict(vocab_size=512, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                         num_key_value_heads=2, max_position_embeddings=2048, bos_token_id=1, eos_token_id=2,
+                         rope_parameters=dict(rope_type="default", mrope_section=[8, 12, 12], rope_theta=10000.0)),
+        vision_config=dict(depth=2, embed_dim=64, hidden_size=256, num_heads=4, mlp_ratio=2, patch_size=14,
+                           spatial_merge_size=2, temporal_patch_size=2, in_channels=3),
+        image_token_id=500, video_token_id=501, vision_start_token_id=502, vision_end_token_id=503)
+    torch.manual_seed(0)
+    model = Qwen2VLForConditionalGeneration(cfg).eval()
+    model = optimize_model(model, low_bit="sym_int8").half().cuda()
+    assert native_engine_supported(model)
+    grid = torch.tensor([[1, 8, 8]], device="cuda")
+    n_img = 8 * 8 // 4
+    ids = torch.tensor([[5, 6, 502] + [500] * n_img + [503, 7, 8, 9, 10, 11]], device="cuda")
+    pix = torch.randn(64, 3 * 2 * 14 * 14, device="cuda", dtype=torch.float16)
+    with torch.no_grad():
+        ref = model(input_ids=ids, pixel_values=pix, image_grid_thw=grid, use_cache=True,
+                    mm_token_type_ids=(ids == 500).long())
+    embeds, pos = language_model_inputs(model, ids, dict(pixel_values=pix, image_grid_thw=grid))
+    assert embeds.shape == (1, ids.shape[1], 256) and pos.shape == (3, 1, ids.shape[1])
+    assert int(pos.max()) + 1 < ids.shape[1]                     # image tokens share positions: a negative shift follows
+    eng = get_native_engine(model)
+    assert eng.cfg.mrope_section == (8, 12, 12)
+    eng.ensure_cache(1, 256)
+    eng.cache.reset()
+    logits = eng.prefill(ids, inputs_embeds=embeds, mrope_positions=pos)[:, -1].float()
+    want = ref.logits[:, -1].float()
+    assert torch.nn.functional.cosine_similarity(logits.flatten(), want.flatten(), dim=0) > 0.999
+    assert eng._rope_shift == int(pos.max()) + 1 - ids.shape[1]
+    # two decode steps on both sides, fed the same tokens
+    past, tok = ref.past_key_values, want.argmax(-1).view(1, 1)
+    for _ in range(2):
+        with torch.no_grad():
+            step = model(input_ids=tok, past_key_values=past, use_cache=True)
+        past = step.past_key_values
+        lg, _ = eng.decode(tok, 1)
+        assert torch.nn.functional.cosine_similarity(lg.float().flatten(), step.logits[:, -1].float().flatten(), dim=0) > 0.999
+        tok = step.logits[:, -1].argmax(-1).view(1, 1)
+    # and through the front door
+    out = model.generate(input_ids=ids, pixel_values=pix, image_grid_thw=grid, max_new_tokens=4, do_sample=False)
+    assert out.shape == (1, ids.shape[1] + 4) and model.first_cost > 0
+
+
+def test_mllama_cross_attention_runs_on_the_flash_kernel():
+    """Cross-attention layers of Mllama (queries from text, keys / values from the vision tower, additive
+    cross-attention mask) go through ``attn_prefill``; logits agree with the eager attention of the same weights."""
+    import copy
+    from transformers import MllamaConfig, MllamaForConditionalGeneration
+    from bigdl_amd.ops import hip
+    from bigdl_amd.optimize import optimize_model
+    cfg = MllamaConfig(
+        vision_config=dict(hidden_size=64, attention_heads=4, num_hidden_layers=2, num_global_layers=1, intermediate_size=128,
+                           image_size=28, patch_size=14, max_num_tiles=1, vision_output_dim=128,
+                           intermediate_layers_indices=[0], supported_aspect_ratios=[[1, 1]]),
+        text_config=dict(vocab_size=320, hidden_size=256, intermediate_size=512, num_hidden_layers=4, num_attention_heads=4,
+                         num_key_value_heads=2, cross_attention_layers=[1, 3], max_position_embeddings=512,
+                         rope_parameters=dict(rope_type="default", rope_theta=10000.0), pad_token_id=0, bos_token_id=1,
+                         eos_token_id=2),
+        image_token_index=300)
+    torch.manual_seed(0)
+    plain = MllamaForConditionalGeneration(cfg).eval()
+    eager = copy.deepcopy(plain).half().cuda()
+    eager.config._attn_implementation = "eager"
+    eager.config.text_config._attn_implementation = "eager"
+    model = optimize_model(plain, low_bit="bf16").half().cuda()
+    ids = torch.tensor([[1, 300, 5, 6, 7, 8, 9, 10]], device="cuda")
+    kw = dict(pixel_values=torch.randn(1, 1, 1, 3, 28, 28, device="cuda", dtype=torch.float16),
+              aspect_ratio_ids=torch.tensor([[1]], device="cuda"), aspect_ratio_mask=torch.ones(1, 1, 1, dtype=torch.long, device="cuda"),
+              cross_attention_mask=torch.ones(1, 8, 1, 1, dtype=torch.long, device="cuda"))
+    calls = []
+    orig = hip.attn_prefill
+
+    def spy(q, k, v, **k2):
+        calls.append((q.shape[2], k.shape[2], k2.get("causal")))
+        return orig(q, k, v, **k2)
+    hip.attn_prefill = spy
+    try:
+        with torch.no_grad():
+            got = model(input_ids=ids, **kw).logits.float()
+    finally:
+        hip.attn_prefill = orig
+    with torch.no_grad():
+        want = eager(input_ids=ids, **kw).logits.float()
+    cross = [c for c in calls if c[1] != c[0]]
+    assert len(cross) == 2 and all(c[2] is False for c in cross), calls      # two cross-attention layers, non-causal
+    assert torch.nn.functional.cosine_similarity(got.flatten(), want.flatten(), dim=0) > 0.999
