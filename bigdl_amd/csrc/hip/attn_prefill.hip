@@ -26,6 +26,7 @@ struct PrefillArgs {
   float scale, softcap;
   int causal, window;
   int v_transposed;                  // v is [B, Hkv, D, Lk] (v_ss = stride of d, keys contiguous)
+  int kv_e5m2;                       // k / v hold e5m2 bytes (strides in bytes); needs v_transposed
 };
 
 constexpr int PF_BN = 64;
@@ -35,8 +36,12 @@ constexpr int PF_BN = 64;
 // DR = the model's head_dim when it is not a multiple of 32 (72: SigLIP / MiniCPM-V vision towers, 80: phi-2): the
 // tiles are D = 96 wide, loads beyond channel DR read as zero (they add nothing to q . k and their output columns
 // are not stored), so such heads need neither a padded copy of q / k / v nor a fallback path.
-template <int D, bool HAS_MASK, bool VT, int QB, int DR = D>
+// KV8: k and v are e5m2 bytes (the engine's fp8 KV cache, V transposed): a later chunk of a long prompt attends to the
+// cached prefix where it lies, the bytes widen to fp16 on their way into LDS (an e5m2 code is the top byte of an
+// fp16), instead of a dequantized fp16 copy of the whole prefix per layer and chunk.
+template <int D, bool HAS_MASK, bool VT, int QB, int DR = D, bool KV8 = false>
 __global__ __launch_bounds__(256) void attn_prefill_kernel(PrefillArgs a) {
+  static_assert(!KV8 || VT, "byte caches store V transposed");
   static_assert(DR <= D && DR % 8 == 0, "head_dim must be a multiple of 8 within the tile width");
   constexpr int BM = 64 * QB;
   constexpr int KS = D + 8;          // halves per K row in LDS (16 B pad)
@@ -91,6 +96,9 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(PrefillArgs a) {
   if (a.window > 0) kbeg = max(0, q0 + offset - a.window + 1) / PF_BN * PF_BN;
   const _Float16* kbase = a.k + b * a.k_sb + hkv * a.k_sh;
   const _Float16* vbase = a.v + b * a.v_sb + hkv * a.v_sh;
+  // (byte caches: the same strides count bytes)
+  const uint8_t* kbase8 = (const uint8_t*)a.k + b * a.k_sb + hkv * a.k_sh;
+  const uint8_t* vbase8 = (const uint8_t*)a.v + b * a.v_sb + hkv * a.v_sh;
 
   // global -> registers for one K/V tile (issued one tile ahead of its use)
   constexpr int NCH = PF_BN * CH / 256;
@@ -100,6 +108,32 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(PrefillArgs a) {
     for (int i = 0; i < NCH; ++i) {
       const int c = threadIdx.x + 256 * i;
       const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+      if constexpr (KV8) {
+        const int key = c / CH, dc = c % CH;
+        const bool live = k0 + key < a.Lk && (DR == D || 8 * dc < DR);
+        kreg[i] = z;
+        if (live) {
+          const uint2v w = *(const uint2v*)(kbase8 + (int64_t)(k0 + key) * a.k_ss + 8 * dc);
+          kreg[i] = dec_e5m2(w.x, w.y);
+        }
+        const int d = c / (PF_BN / 8), kc = c % (PF_BN / 8);
+        const uint8_t* vp = vbase8 + (int64_t)d * a.v_ss + k0 + 8 * kc;
+        vreg[i] = z;
+        if (DR == D || d < DR) {
+          if (k0 + 8 * kc + 8 <= a.Lk) {
+            const uint2v w = *(const uint2v*)vp;
+            vreg[i] = dec_e5m2(w.x, w.y);
+          } else {
+            H8 t;
+            t.v = z;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (k0 + 8 * kc + e < a.Lk) t.u[e >> 1] |= (uint32_t)vp[e] << (16 * (e & 1) + 8);
+            vreg[i] = t.v;
+          }
+        }
+        continue;
+      }
       {
         const int key = c / CH, dc = c % CH;
         const bool live = k0 + key < a.Lk && (DR == D || 8 * dc < DR);
@@ -488,23 +522,31 @@ extern "C" int bigdl_prefill_rope_append(void* qkv, void* kc, void* vc, void* vt
   return HIP_CHECK_LAUNCH();
 }
 
-template <int D, bool HAS_MASK, bool VT, int QB, int DR = D>
+template <int D, bool HAS_MASK, bool VT, int QB, int DR = D, bool KV8 = false>
 static int launch_pf_one(const PrefillArgs& a, hipStream_t st) {
   const dim3 grid((a.Sq + 64 * QB - 1) / (64 * QB), a.Hq, a.B), block(256);
   constexpr size_t lds = ((size_t)PF_BN * (D + 8) + (size_t)D * (PF_BN + 8)) * 2;
   static bool attr = false;
   if (!attr && lds > 65536) {
-    if (hipFuncSetAttribute((const void*)attn_prefill_kernel<D, HAS_MASK, VT, QB, DR>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void*)attn_prefill_kernel<D, HAS_MASK, VT, QB, DR, KV8>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)
       return -5;
     attr = true;
   }
-  hipLaunchKernelGGL((attn_prefill_kernel<D, HAS_MASK, VT, QB, DR>), grid, block, lds, st, a);
+  hipLaunchKernelGGL((attn_prefill_kernel<D, HAS_MASK, VT, QB, DR, KV8>), grid, block, lds, st, a);
   return HIP_CHECK_LAUNCH();
 }
 
 template <int D, int QB, int DR = D>
 static int launch_pf_qb(const PrefillArgs& a, hipStream_t st) {
+  if (a.kv_e5m2) {
+    if constexpr (DR == D) {
+      if (!a.v_transposed) return -6;
+      return a.mask ? launch_pf_one<D, true, true, QB, DR, true>(a, st) : launch_pf_one<D, false, true, QB, DR, true>(a, st);
+    } else {
+      return -6;
+    }
+  }
   if (a.mask) return a.v_transposed ? launch_pf_one<D, true, true, QB, DR>(a, st) : launch_pf_one<D, true, false, QB, DR>(a, st);
   return a.v_transposed ? launch_pf_one<D, false, true, QB, DR>(a, st) : launch_pf_one<D, false, false, QB, DR>(a, st);
 }
@@ -524,18 +566,18 @@ extern "C" int bigdl_attn_prefill(const void* q, const void* k, const void* v, v
                                   int Hkv, int Sq, int Lk, int D, int64_t q_sb, int64_t q_sh, int64_t q_ss, int64_t k_sb,
                                   int64_t k_sh, int64_t k_ss, int64_t v_sb, int64_t v_sh, int64_t v_ss, int64_t o_sb,
                                   int64_t o_ss, int64_t m_sb, int64_t m_sq, int64_t m_sh, const float* alibi, float scale,
-                                  float softcap, int causal, int window, int v_transposed, hipStream_t st) {
+                                  float softcap, int causal, int window, int v_transposed, int kv_e5m2, hipStream_t st) {
   if (B <= 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv || Sq <= 0 || Lk <= 0 || B > 65535 || Hq > 65535) return -1;
   if (causal && Lk < Sq) return -1;
   if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15) || ((uintptr_t)out & 7)) return -1;
-  if ((q_sb | q_sh | q_ss | k_sb | k_sh | k_ss | v_sb | v_sh | v_ss) & 7) return -1;    // 16-byte row starts
+  if ((q_sb | q_sh | q_ss | k_sb | k_sh | k_ss | v_sb | v_sh | v_ss) & 7) return -1;    // 16-byte (8-byte: e5m2) row starts
   if ((o_sb | o_ss) & 3) return -1;
   PrefillArgs a;
   a.q = (const _Float16*)q; a.k = (const _Float16*)k; a.v = (const _Float16*)v; a.out = (_Float16*)out;
   a.mask = (const _Float16*)mask; a.B = B; a.Hq = Hq; a.Hkv = Hkv; a.Sq = Sq; a.Lk = Lk;
   a.q_sb = q_sb; a.q_sh = q_sh; a.q_ss = q_ss; a.k_sb = k_sb; a.k_sh = k_sh; a.k_ss = k_ss;
   a.v_sb = v_sb; a.v_sh = v_sh; a.v_ss = v_ss; a.o_sb = o_sb; a.o_ss = o_ss; a.m_sb = m_sb; a.m_sq = m_sq; a.m_sh = m_sh; a.alibi = alibi;
-  a.scale = scale; a.softcap = softcap; a.causal = causal; a.window = window; a.v_transposed = v_transposed;
+  a.scale = scale; a.softcap = softcap; a.causal = causal; a.window = window; a.v_transposed = v_transposed; a.kv_e5m2 = kv_e5m2;
   switch (D) {
     case 64: return launch_pf<64>(a, st);
     case 72: return launch_pf<96, 72>(a, st);

@@ -582,11 +582,17 @@ class NativeDecoder:
                                         rot_dim=rot, interleaved=cfg.rope_interleaved, vt_scratch=scratch,
                                         position_ids=rope_pos)
             vt = scratch[..., :s] if scratch is not None else vc[:, :, :, :s]
+            kv8 = False
             if past == 0:
                 kk = k                       # attention reads the unquantized K / V^T of this call
+            elif cache.fp8 and d in (64, 96, 128, 256):
+                # a later chunk of the prompt: the kernel reads the e5m2 prefix (and this chunk's freshly appended
+                # keys) straight from the cache
+                rows_ = slice(None) if slot is None else slice(slot, slot + 1)
+                kk, vt, kv8 = cache.k[li][rows_, :, :past + s], cache.v[li][rows_, :, :, :past + s], True
             else:
                 kk, vt = self._read_cache(li, past + s, slot)
-            attn = self._sdpa(q, kk, vt, past, lw.window).reshape(b * s, hq * d)
+            attn = self._sdpa(q, kk, vt, past, lw.window, kv_e5m2=kv8).reshape(b * s, hq * d)
             if snap is not None:
                 # the prompt has attended to all of its keys; what later tokens will see is the voted subset + the window
                 from ..transformers.kv import snapkv_indices
@@ -853,13 +859,15 @@ class NativeDecoder:
             return kf, vf
         return k, vt
 
-    def _sdpa(self, q, k, vt, past, window):
-        """q [B,Hq,S,D], k [B,Hkv,past+S,D], vt = V^T [B,Hkv,D,past+S] -> [B, S, Hq*D]"""
+    def _sdpa(self, q, k, vt, past, window, kv_e5m2=False):
+        """q [B,Hq,S,D], k [B,Hkv,past+S,D], vt = V^T [B,Hkv,D,past+S] -> [B, S, Hq*D]; with ``kv_e5m2`` k / vt are
+        views of the fp8 cache (bytes)"""
         cfg = self.cfg
         if cfg.head_dim in (64, 96, 128, 256) and vt.stride(2) % 8 == 0 and vt.data_ptr() % 16 == 0:
             from ..ops import hip
             return hip.attn_prefill(q, k, vt, scale=self.attn_scale, causal=True, softcap=cfg.attn_softcap, window=window,
-                                    v_transposed=True, alibi=self.alibi)
+                                    v_transposed=True, alibi=self.alibi, kv_e5m2=kv_e5m2)
+        assert not kv_e5m2
         if self.alibi is not None:
             raise NotImplementedError("ALiBi attention needs head_dim 64, 96 or 128")
         return self._sdpa_torch(q, k, vt.transpose(-1, -2), past, window).transpose(1, 2).reshape(q.shape[0], q.shape[2], -1)

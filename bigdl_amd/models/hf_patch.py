@@ -80,9 +80,53 @@ def _attention_classes(model):
     return out
 
 
+def pad_mlp_intermediate(module, multiple: int = 128):
+    """Zero-pad the intermediate dimension of a gated MLP (gate_proj / up_proj rows, down_proj columns) to a multiple
+    of ``multiple`` so that its three linears qualify for the tiled low-bit formats.  Exact: a padded channel computes
+    act(0) * 0 = 0 and meets a zero column of down_proj.  (Reference: models/qwen2.py:199-230 ``padding_mlp`` for
+    Qwen1.5-14B's 13696 channels.)"""
+    g, u, d = (getattr(module, n, None) for n in ("gate_proj", "up_proj", "down_proj"))
+    if not all(type(x) is nn.Linear for x in (g, u, d)):
+        return
+    inter = g.out_features
+    if inter % multiple == 0 or u.out_features != inter or d.in_features != inter:
+        return
+    new = (inter + multiple - 1) // multiple * multiple
+
+    def grown(t, shape, fill):
+        out = torch.zeros(shape, dtype=t.dtype, device=t.device)       # (meta skeletons of load_low_bit: shapes only)
+        if t.device.type != "meta":
+            fill(out, t)
+        return nn.Parameter(out, requires_grad=False)
+    for lin in (g, u):
+        lin.weight = grown(lin.weight.data, (new, lin.in_features), lambda o, t: o[:inter].copy_(t))
+        if lin.bias is not None:
+            lin.bias = grown(lin.bias.data, (new,), lambda o, t: o[:inter].copy_(t))
+        lin.out_features = new
+    d.weight = grown(d.weight.data, (d.out_features, new), lambda o, t: o[:, :inter].copy_(t))
+    d.in_features = new
+
+
+def fold_norm_head(model):
+    """Baichuan2's ``NormHead`` L2-normalises the rows of the output embedding on the fly; at inference the weights are
+    fixed, so the normalisation is applied once and the module becomes a plain linear that the low-bit converter
+    can take (reference convert.py:908-925)."""
+    head = getattr(model, "lm_head", None)
+    if head is None or head.__class__.__name__ != "NormHead" or not hasattr(head, "weight"):
+        return
+    w = head.weight.data
+    lin = nn.Linear(w.shape[1], w.shape[0], bias=False, device=w.device, dtype=w.dtype)
+    if w.device.type != "meta":
+        lin.weight.data = F.normalize(w.float()).to(w.dtype)
+    model.lm_head = lin
+
+
 def optimize_pre(model, qtype=None):
     cfg = getattr(model, "config", None)
     mt = getattr(cfg, "model_type", None)
+    fold_norm_head(model)
+    if qtype is None or qtype in Q.T16_QTYPES:
+        model.apply(pad_mlp_intermediate)
     if mt in MERGE_QKV_TYPES:
         for cls in _attention_classes(model):
             model.apply(lambda m, c=cls: merge_qkv_base(m, c))

@@ -68,7 +68,7 @@ def lib():
         L.bigdl_rwkv4_wkv.argtypes = [vp] * 8 + [ci] * 5 + [vp]
         L.bigdl_rwkv5_wkv.argtypes = [vp] * 7 + [ci] * 4 + [vp]
         L.bigdl_prefill_rope_append.argtypes = [vp, vp, vp, vp, vp, vp] + [ci] * 10 + [i64, i64, ci, vp]
-        L.bigdl_attn_prefill.argtypes = [vp, vp, vp, vp, vp] + [ci] * 6 + [i64] * 14 + [vp, cf, cf, ci, ci, ci, vp]
+        L.bigdl_attn_prefill.argtypes = [vp, vp, vp, vp, vp] + [ci] * 6 + [i64] * 14 + [vp, cf, cf, ci, ci, ci, ci, vp]
         _LIB = L
     return _LIB
 
@@ -814,7 +814,7 @@ def _check_alibi(alibi, n_heads):
 
 
 def attn_prefill(q, k, v, *, scale, causal=True, mask=None, softcap=0.0, window=0, out=None, v_transposed=False,
-                 alibi=None):
+                 alibi=None, kv_e5m2=False):
     """Flash-style attention for many query tokens.  q [B, Hq, Sq, D], k / v [B, Hkv, Lk, D]: fp16, any strides with
     a contiguous last dim (views into a fused qkv buffer or a KV cache are fine); with ``v_transposed`` v is
     [B, Hkv, D, Lk] (the engine's V^T cache layout, row stride multiple of 8).  mask: optional additive fp16
@@ -824,9 +824,13 @@ def attn_prefill(q, k, v, *, scale, causal=True, mask=None, softcap=0.0, window=
     hkv, lk = k.shape[1], k.shape[2]
     if d not in PREFILL_HEAD_DIMS:
         raise ValueError("attn_prefill supports head_dim 64, 72, 80, 96, 128 and 256")
-    for t in (q, k, v):
+    if kv_e5m2 and (not v_transposed or k.dtype != torch.uint8 or v.dtype != torch.uint8 or d in (72, 80)):
+        raise ValueError("kv_e5m2 takes uint8 K [B, Hkv, Lk, D] and V^T [B, Hkv, D, Lk] (the engine's fp8 cache layout)")
+    for t in (q,) if kv_e5m2 else (q, k, v):
         if t.dtype != torch.float16 or t.stride(-1) != 1:
             raise ValueError("q / k / v must be fp16 with a contiguous last dim")
+    if kv_e5m2 and (k.stride(-1) != 1 or v.stride(-1) != 1):
+        raise ValueError("cache views must have a contiguous last dim")
     vshape = (b, hkv, d, lk) if v_transposed else (b, hkv, lk, d)
     if tuple(v.shape) != vshape or k.shape[0] != b or k.shape[3] != d or hq % hkv:
         raise ValueError("inconsistent q / k / v shapes")
@@ -853,7 +857,7 @@ def attn_prefill(q, k, v, *, scale, causal=True, mask=None, softcap=0.0, window=
                                   q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
                                   v.stride(0), v.stride(1), v.stride(2), out.stride(0), out.stride(1), m_sb, m_sq, m_sh,
                                   _ptr(alibi), float(scale), float(softcap or 0.0), int(bool(causal)), int(window or 0),
-                                  int(bool(v_transposed)), _stream())
+                                  int(bool(v_transposed)), int(bool(kv_e5m2)), _stream())
     _check(rc, "attn_prefill")
     return out
 

@@ -314,3 +314,45 @@ def test_npu_model_import_path_takes_the_npu_keywords(tiny_llama, tmp_path):
     conv = AutoModelForCausalLM.optimize_npu_model(model=LlamaForCausalLM.from_pretrained(d), qtype="sym_int8_rtn",
                                                    max_context_len=256, device="cpu")
     assert conv.model.layers[0].mlp.up_proj.qtype == Q.SYM_INT8
+
+
+def test_mlp_padding_and_norm_head_folding(tmp_path):
+    """An intermediate size that is not a multiple of 128 (Qwen1.5-14B: 13696 is; a 200-channel test model is not) is
+    zero-padded before conversion, exactly, and survives save_low_bit / load_low_bit; a NormHead output layer is folded
+    into a plain linear."""
+    import torch
+    from torch import nn
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from bigdl_amd.models.hf_patch import fold_norm_head
+    from bigdl_amd.optimize import optimize_model
+    from bigdl_amd.transformers import AutoModelForCausalLM
+    torch.manual_seed(0)
+    cfg = LlamaConfig(vocab_size=128, hidden_size=128, intermediate_size=200, num_hidden_layers=2, num_attention_heads=4,
+                      num_key_value_heads=2, max_position_embeddings=128)
+    ref = LlamaForCausalLM(cfg).eval()
+    ids = torch.randint(0, 128, (1, 9))
+    want = ref(ids).logits
+    import copy
+    model = optimize_model(copy.deepcopy(ref), low_bit="sym_int8")
+    mlp = model.model.layers[0].mlp
+    assert mlp.gate_proj.out_len == 256 and mlp.down_proj.in_len == 256 and type(mlp.down_proj).__name__ == "LowBitLinear"
+    got = model(ids).logits
+    assert torch.nn.functional.cosine_similarity(got.flatten(), want.flatten(), dim=0) > 0.999
+    model.save_low_bit(str(tmp_path))
+    again = AutoModelForCausalLM.load_low_bit(str(tmp_path))
+    torch.testing.assert_close(again(ids).logits, got)
+
+    class NormHead(nn.Module):
+        def __init__(self, hidden, vocab):
+            super().__init__()
+            self.weight = nn.Parameter(torch.randn(vocab, hidden))
+
+        def forward(self, x):
+            return nn.functional.linear(x, nn.functional.normalize(self.weight))
+    holder = nn.Module()
+    holder.lm_head = NormHead(16, 40)
+    x = torch.randn(3, 16)
+    want = holder.lm_head(x)
+    fold_norm_head(holder)
+    assert type(holder.lm_head) is nn.Linear
+    torch.testing.assert_close(holder.lm_head(x), want)

@@ -818,3 +818,25 @@ def test_attn_prefill_head_dim_72_80(d, causal, sq, lk, hq, hkv):
     want = (torch.softmax(s, -1) @ vf).transpose(1, 2).reshape(2, sq, hq * d)
     assert out.shape == want.shape
     assert (out.float() - want).abs().max().item() < 2e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,hq,hkv,sq,lk", [(128, 8, 8, 96, 1000), (64, 8, 2, 130, 387), (256, 4, 4, 17, 80)])
+def test_attn_prefill_reads_the_e5m2_cache_directly(d, hq, hkv, sq, lk):
+    """A later chunk of a prompt attends to the fp8 cache where it lies: same result as attention over the dequantized
+    copy of those bytes."""
+    from bigdl_amd.ops import hip
+    g = torch.Generator(device="cuda").manual_seed(d + sq)
+    cap = 1024
+    q = torch.randn(2, hq, sq, d, device="cuda", generator=g).half()
+    kc = torch.randn(2, hkv, cap, d, device="cuda", generator=g).half().view(torch.int16).bitwise_right_shift(8).to(torch.uint8)
+    vc = torch.randn(2, hkv, d, cap, device="cuda", generator=g).half().view(torch.int16).bitwise_right_shift(8).to(torch.uint8)
+    k8, v8 = kc[:, :, :lk], vc[:, :, :, :lk]
+    kf = torch.empty(k8.shape, dtype=torch.float16, device="cuda")
+    vf = torch.empty(v8.shape, dtype=torch.float16, device="cuda")
+    hip.from_e5m2(k8, kf)
+    hip.from_e5m2(v8, vf)
+    want = hip.attn_prefill(q, kf, vf, scale=d ** -0.5, causal=True, v_transposed=True)
+    got = hip.attn_prefill(q, k8, v8, scale=d ** -0.5, causal=True, v_transposed=True, kv_e5m2=True)
+    assert torch.isfinite(got.float()).all()
+    assert (got.float() - want.float()).abs().max().item() < 2e-3
