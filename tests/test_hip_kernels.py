@@ -832,10 +832,11 @@ def test_attn_prefill_reads_the_e5m2_cache_directly(d, hq, hkv, sq, lk):
     kc = torch.randn(2, hkv, cap, d, device="cuda", generator=g).half().view(torch.int16).bitwise_right_shift(8).to(torch.uint8)
     vc = torch.randn(2, hkv, d, cap, device="cuda", generator=g).half().view(torch.int16).bitwise_right_shift(8).to(torch.uint8)
     k8, v8 = kc[:, :, :lk], vc[:, :, :, :lk]
-    kf = torch.empty(k8.shape, dtype=torch.float16, device="cuda")
-    vf = torch.empty(v8.shape, dtype=torch.float16, device="cuda")
-    hip.from_e5m2(k8, kf)
-    hip.from_e5m2(v8, vf)
+    kf_all = torch.empty(kc.shape, dtype=torch.float16, device="cuda")
+    vf_all = torch.empty(vc.shape, dtype=torch.float16, device="cuda")
+    hip.from_e5m2(kc, kf_all)
+    hip.from_e5m2(vc, vf_all)
+    kf, vf = kf_all[:, :, :lk], vf_all[:, :, :, :lk]
     want = hip.attn_prefill(q, kf, vf, scale=d ** -0.5, causal=True, v_transposed=True)
     got = hip.attn_prefill(q, k8, v8, scale=d ** -0.5, causal=True, v_transposed=True, kv_e5m2=True)
     assert torch.isfinite(got.float()).all()
