@@ -62,37 +62,95 @@ class NativeModel:
 
     def generate(self, tokens: List[int], top_k: int = 40, top_p: float = 0.95, temp: float = 0.8,
                  repeat_penalty: float = 1.1, max_tokens: int = 128, **kwargs) -> Iterator[int]:
+        """Token ids as they are produced (generation runs on a worker thread and hands tokens over a queue, so a
+        caller that stops iterating early does not wait for the whole budget)."""
+        import queue
+        import threading
         ids = torch.tensor([tokens], device=self.device)
         do_sample = temp is not None and temp > 0
-        out = self.model.generate(ids, max_new_tokens=max_tokens, do_sample=do_sample, temperature=temp if do_sample else None,
-                                  top_k=top_k if do_sample else None, top_p=top_p if do_sample else None,
-                                  repetition_penalty=repeat_penalty)
-        for t in out[0, len(tokens):].tolist():
-            yield t
+        q: "queue.Queue" = queue.Queue()
+        done = object()
+
+        class _Tokens:                       # the streamer protocol of ``generate``: put(prompt), put(token)..., end()
+            first = True
+
+            def put(self, value):
+                if self.first:
+                    self.first = False
+                    return
+                for t in value.reshape(-1).tolist():
+                    q.put(t)
+
+            def end(self):
+                q.put(done)
+
+        def run():
+            try:
+                self.model.generate(ids, max_new_tokens=max_tokens, do_sample=do_sample, temperature=temp if do_sample else None,
+                                    top_k=top_k if do_sample else None, top_p=top_p if do_sample else None,
+                                    repetition_penalty=repeat_penalty, streamer=_Tokens())
+            except Exception as e:           # surface the failure to the consumer instead of leaving it blocked
+                q.put(e)
+                q.put(done)
+        threading.Thread(target=run, daemon=True).start()
+        while True:
+            item = q.get()
+            if item is done:
+                return
+            if isinstance(item, Exception):
+                raise item
+            yield item
+
+    def _completion_chunks(self, prompt, toks, max_tokens, temperature, top_p, top_k, stop, repeat_penalty):
+        """(text delta, finish_reason or None, tokens so far) per generated token, honouring EOS and stop strings"""
+        eos = self.token_eos()
+        new: List[int] = []
+        sent = ""
+        finish = "length"
+        for t in self.generate(toks, top_k=top_k, top_p=top_p, temp=temperature, repeat_penalty=repeat_penalty,
+                               max_tokens=max_tokens):
+            if eos is not None and t == eos:
+                finish = "stop"
+                break
+            new.append(t)
+            text = self.detokenize(new).decode("utf-8", errors="ignore")
+            cut = min((text.find(s) for s in (stop or []) if s and s in text), default=-1)
+            if cut >= 0:
+                if cut > len(sent):
+                    yield text[len(sent):cut], None, len(new)
+                finish = "stop"
+                break
+            if text.endswith("\ufffd"):     # half of a multi-byte character: wait for the rest
+                continue
+            if len(text) > len(sent):
+                yield text[len(sent):], None, len(new)
+                sent = text
+        yield "", finish, len(new)
 
     def __call__(self, prompt: str, max_tokens: int = 128, temperature: float = 0.8, top_p: float = 0.95, top_k: int = 40,
                  stop: Optional[List[str]] = None, stream: bool = False, repeat_penalty: float = 1.1, echo: bool = False,
                  **kwargs):
         toks = self.tokenize(prompt)
-        t0 = time.time()
-        new = list(self.generate(toks, top_k=top_k, top_p=top_p, temp=temperature, repeat_penalty=repeat_penalty,
-                                 max_tokens=max_tokens))
-        eos = self.token_eos()
-        finish = "length"
-        if eos is not None and eos in new:
-            new = new[:new.index(eos)]
-            finish = "stop"
-        text = self.detokenize(new).decode("utf-8", errors="ignore")
-        for s in stop or []:
-            if s in text:
-                text, finish = text[:text.index(s)], "stop"
-        if echo:
-            text = prompt + text
-        res = {"id": f"cmpl-{uuid.uuid4()}", "object": "text_completion", "created": int(t0), "model": self.model_path,
-               "choices": [{"text": text, "index": 0, "logprobs": None, "finish_reason": finish}],
-               "usage": {"prompt_tokens": len(toks), "completion_tokens": len(new), "total_tokens": len(toks) + len(new)}}
+        cid, t0 = f"cmpl-{uuid.uuid4()}", int(time.time())
+        chunks = self._completion_chunks(prompt, toks, max_tokens, temperature, top_p, top_k, stop, repeat_penalty)
+
+        def piece(text, finish):
+            return {"id": cid, "object": "text_completion", "created": t0, "model": self.model_path,
+                    "choices": [{"text": text, "index": 0, "logprobs": None, "finish_reason": finish}]}
         if stream:
-            return iter([res])
+            def gen():
+                if echo:
+                    yield piece(prompt, None)
+                for delta, finish, _ in chunks:
+                    if delta or finish:
+                        yield piece(delta, finish)
+            return gen()
+        text, finish, n = "", "length", 0
+        for delta, fin, n in chunks:
+            text += delta
+            finish = fin or finish
+        res = piece((prompt if echo else "") + text, finish)
+        res["usage"] = {"prompt_tokens": len(toks), "completion_tokens": n, "total_tokens": len(toks) + n}
         return res
 
     def embed(self, text: str) -> List[float]:
@@ -101,24 +159,75 @@ class NativeModel:
             h = self.model.model(input_ids=ids).last_hidden_state
         return h[0].float().mean(0).cpu().tolist()
 
+    def create_embedding(self, input: Union[str, List[str]], model: Optional[str] = None):
+        """OpenAI-style embedding response (mean of the last hidden states per input)."""
+        inputs = [input] if isinstance(input, str) else list(input)
+        data, n = [], 0
+        for i, text in enumerate(inputs):
+            data.append({"object": "embedding", "embedding": self.embed(text), "index": i})
+            n += len(self.tokenize(text))
+        return {"object": "list", "data": data, "model": model or self.model_path,
+                "usage": {"prompt_tokens": n, "total_tokens": n}}
+
+    def eval(self, tokens: List[int]) -> torch.Tensor:
+        """Logits [len(tokens), n_vocab] of one forward pass over ``tokens`` (no cache kept)."""
+        with torch.no_grad():
+            return self.model(input_ids=torch.tensor([tokens], device=self.device)).logits[0].float().cpu()
+
+    #: how a chat turn is rendered when the tokenizer brings no template of its own (subclasses override)
+    chat_format = "{role}: {content}\n"
+    chat_suffix = "assistant:"
+
+    def _chat_prompt(self, messages: List[dict]) -> str:
+        tpl = getattr(self.tokenizer, "chat_template", None)
+        if tpl:
+            return self.tokenizer.apply_chat_template(messages, tokenize=False, add_generation_prompt=True)
+        return "".join(self.chat_format.format(role=m["role"], content=m["content"]) for m in messages) + self.chat_suffix
+
+    def create_chat_completion(self, messages: List[dict], max_tokens: int = 256, temperature: float = 0.2,
+                               top_p: float = 0.95, top_k: int = 40, stop: Optional[List[str]] = None, stream: bool = False,
+                               repeat_penalty: float = 1.1, **kwargs):
+        """OpenAI-style chat completion over the plain completion call."""
+        prompt = self._chat_prompt(messages)
+        out = self(prompt, max_tokens=max_tokens, temperature=temperature, top_p=top_p, top_k=top_k, stop=stop,
+                   stream=stream, repeat_penalty=repeat_penalty)
+        if stream:
+            def gen():
+                first = True
+                for c in out:
+                    ch = c["choices"][0]
+                    delta = {"content": ch["text"]}
+                    if first:
+                        delta["role"], first = "assistant", False
+                    yield {"id": c["id"].replace("cmpl", "chatcmpl"), "object": "chat.completion.chunk", "created": c["created"],
+                           "model": c["model"], "choices": [{"index": 0, "delta": delta, "finish_reason": ch["finish_reason"]}]}
+            return gen()
+        ch = out["choices"][0]
+        return {"id": out["id"].replace("cmpl", "chatcmpl"), "object": "chat.completion", "created": out["created"],
+                "model": out["model"], "usage": out["usage"],
+                "choices": [{"index": 0, "message": {"role": "assistant", "content": ch["text"]},
+                             "finish_reason": ch["finish_reason"]}]}
+
     create_completion = __call__
 
 
-class Llama(NativeModel):
-    pass
+def _family(name: str, architectures, chat_format=None, chat_suffix=None):
+    """A family class in the reference's naming: refuses files of another architecture instead of mis-loading them."""
+
+    def __init__(self, model_path: str, *args, **kwargs):
+        from ...transformers.gguf.gguf import GGUFFileLoader
+        arch = GGUFFileLoader(model_path).config.get("general.architecture")
+        if arch not in architectures:
+            raise ValueError(f"{name} loads {' / '.join(architectures)} files; {model_path} is a {arch} file")
+        NativeModel.__init__(self, model_path, *args, **kwargs)
+    ns = {"__init__": __init__, "__doc__": f"{name}: single-file native model of the {' / '.join(architectures)} family."}
+    if chat_format:
+        ns["chat_format"], ns["chat_suffix"] = chat_format, chat_suffix
+    return type(name, (NativeModel,), ns)
 
 
-class Gptneox(NativeModel):
-    pass
-
-
-class Bloom(NativeModel):
-    pass
-
-
-class Starcoder(NativeModel):
-    pass
-
-
-class ChatGLM(NativeModel):
-    pass
+Llama = _family("Llama", ("llama", "mistral", "qwen2", "baichuan"), "[INST] {content} [/INST]", "")
+Gptneox = _family("Gptneox", ("gptneox", "gpt_neox"))
+Bloom = _family("Bloom", ("bloom",))
+Starcoder = _family("Starcoder", ("starcoder", "gpt_bigcode", "starcoder2"))
+ChatGLM = _family("ChatGLM", ("chatglm", "glm"), "<|{role}|>\n{content}", "<|assistant|>\n")

@@ -228,6 +228,19 @@ def test_llm_convert_and_native_wrappers(tmp_path):
     res = llm("w1 w2 w3", max_tokens=5, temperature=0.0)
     assert res["usage"]["completion_tokens"] <= 5 and isinstance(res["choices"][0]["text"], str)
     assert len(llm.embed("w4 w5")) == 256
+    # streaming yields the same text piece by piece; chat / embedding responses follow the OpenAI shapes
+    pieces = list(llm("w1 w2 w3", max_tokens=5, temperature=0.0, stream=True))
+    assert "".join(p["choices"][0]["text"] for p in pieces) == res["choices"][0]["text"]
+    assert pieces[-1]["choices"][0]["finish_reason"] in ("stop", "length")
+    chat = llm.create_chat_completion([{"role": "user", "content": "w7 w8"}], max_tokens=3, temperature=0.0)
+    assert chat["object"] == "chat.completion" and chat["choices"][0]["message"]["role"] == "assistant"
+    emb = llm.create_embedding(["w1", "w2 w3"])
+    assert [d["index"] for d in emb["data"]] == [0, 1] and len(emb["data"][1]["embedding"]) == 256
+    toks = llm.tokenize("w1 w2")
+    assert llm.eval(toks).shape == (len(toks), 320)
+    from bigdl_amd.ggml.model import Bloom
+    with pytest.raises(ValueError, match="bloom"):
+        Bloom(out)
 
 
 def test_gptq_checkpoint_loads_without_auto_gptq(tmp_path):
