@@ -7,11 +7,14 @@ template serves several projections of a layer (qkv, o_proj, down_proj launch th
 grids), and averaging them into one line hides how many bytes each one really moves -- and a few derived figures are
 added: MFMA busy share of the busy cycles, LDS bank-conflict share of the LDS-active cycles, bytes fetched.
 
-Bytes: the derived FETCH_SIZE metric prices a read request at the request sizes of older parts, so on this GPU its
-unit is not a KiB.  Instead of guessing the factor it is calibrated: `bench.py` run with BIGDL_PMC_CALIBRATE=1 ends
-with three sums over a 1 GiB fp32 tensor (a `reduce_kernel` that reads exactly 2**30 bytes), and every kernel's
-FETCH_SIZE is scaled by (1 GiB / the calibration dispatch's FETCH_SIZE).  Without a calibration dispatch in the dump
-the raw value is reported and marked as uncalibrated."""
+Bytes: ``TCC_EA0_RDREQ_DRAM_32B_sum`` counts the read traffic between L2 and memory in 32-byte units (a 128-byte
+request counts 4), so bytes = 32 x counter.  The derived FETCH_SIZE metric is NOT used: its expression prices every
+request that is not flagged as a 32-byte one at 64 bytes and takes the 128-byte requests from TCC_BUBBLE, which stays 0
+on this GPU, where all requests of a streaming kernel are 128 bytes wide -- it reads low by 2x.  Check built into the
+dump: `bench.py` run with BIGDL_PMC_CALIBRATE=1 ends with three sums over a 1 GiB fp32 tensor; the summary reports what
+the counter says for those launches (`calibration_GiB_measured`, expected 1.0).  Measured on MI355X for the decode step
+of Llama-2-7B sym_int4: qkv 27.2 MiB, o_proj 9.9, gate+up 48.6, down 24.5 per launch -- the weight bytes (+ x and the
+attention partials for o_proj)."""
 import csv
 import glob
 import json
@@ -37,14 +40,14 @@ def main():
                 k = (short(row["Kernel_Name"]), row.get("Grid_Size", "?"), row.get("Workgroup_Size", "?"))
                 agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
                 calls[k].add((f, row["Dispatch_Id"]))
-                if row["Counter_Name"] == "FETCH_SIZE" and "reduce_kernel" in k[0]:
-                    per_dispatch_fetch[(f, row["Dispatch_Id"])] += float(row["Counter_Value"])
+                if row["Counter_Name"] == "TCC_EA0_RDREQ_DRAM_32B_sum" and "reduce_kernel" in k[0]:
+                    per_dispatch_fetch[(f, row["Dispatch_Id"])] += 32.0 * float(row["Counter_Value"])
     # the calibration dispatches are the largest reduce_kernel launches of the run
-    factor = None
+    check = None
     if per_dispatch_fetch:
         top = sorted(per_dispatch_fetch.values())[-3:]
         if top[0] > 0 and top[-1] / top[0] < 1.2:       # three equal launches: that is the calibration tail
-            factor = CAL_BYTES / (sum(top) / len(top))
+            check = round(sum(top) / len(top) / CAL_BYTES, 4)
     out = []
     for k, c in agg.items():
         n = max(1, len(calls[k]))
@@ -55,14 +58,15 @@ def main():
             rec["mfma_busy_over_sq_busy"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / c["SQ_BUSY_CYCLES"], 4)
         if c.get("SQ_LDS_IDX_ACTIVE"):
             rec["lds_bank_conflict_share"] = round(c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"], 4)
-        if "FETCH_SIZE" in c:
-            if factor is not None:
-                rec["fetch_MiB_per_dispatch"] = round(c["FETCH_SIZE"] * factor / n / 2 ** 20, 3)
-            else:
-                rec["fetch_size_raw_per_dispatch_uncalibrated"] = round(c["FETCH_SIZE"] / n, 3)
+        if "TCC_EA0_RDREQ_DRAM_32B_sum" in c:
+            rec["fetch_MiB_per_dispatch"] = round(32.0 * c["TCC_EA0_RDREQ_DRAM_32B_sum"] / n / 2 ** 20, 3)
+        elif "TCC_EA0_RDREQ_sum" in c:
+            rec["fetch_MiB_per_dispatch"] = round(128.0 * c["TCC_EA0_RDREQ_sum"] / n / 2 ** 20, 3)   # all requests 128 B wide
+        if c.get("TCC_HIT_sum") is not None and c.get("TCC_MISS_sum"):
+            rec["l2_hit_rate"] = round(c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 4)
         out.append(rec)
-    out.sort(key=lambda r: -r.get("SQ_WAVE_CYCLES", r.get("FETCH_SIZE", 0)))
-    json.dump({"fetch_bytes_per_FETCH_SIZE_unit": factor, "kernels": out}, sys.stdout, indent=1)
+    out.sort(key=lambda r: -r.get("SQ_WAVE_CYCLES", r.get("TCC_EA0_RDREQ_sum", 0)))
+    json.dump({"calibration_GiB_measured": check, "kernels": out}, sys.stdout, indent=1)
 
 
 if __name__ == "__main__":
