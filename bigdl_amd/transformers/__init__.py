@@ -5,6 +5,7 @@ _LAZY = {
     "AutoModelForSequenceClassification": "model", "AutoModelForMaskedLM": "model",
     "AutoModelForNextSentencePrediction": "model", "AutoModelForMultipleChoice": "model",
     "AutoModelForTokenClassification": "model", "Qwen2VLForConditionalGeneration": "model",
+    "AutoModelForImageTextToText": "model", "AutoModelForVision2Seq": "model",
     "ggml_convert_low_bit": "convert", "get_enable_ipex": "convert",
     "init_pipeline_parallel": "pipeline_parallel", "PPModelWorker": "pipeline_parallel",
     "LlamaForCausalLM": "modelling_bigdl", "ChatGLMForCausalLM": "modelling_bigdl",

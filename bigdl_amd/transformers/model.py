@@ -600,3 +600,7 @@ if _optional_hf("Qwen2VLForConditionalGeneration") is not None:
 if _optional_hf("AutoModelForImageTextToText") is not None:
     class AutoModelForImageTextToText(_BaseAutoModelClass):
         HF_Model = transformers.AutoModelForImageTextToText
+
+if _optional_hf("AutoModelForVision2Seq") is not None:
+    class AutoModelForVision2Seq(_BaseAutoModelClass):
+        HF_Model = transformers.AutoModelForVision2Seq

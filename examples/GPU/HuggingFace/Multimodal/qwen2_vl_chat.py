@@ -11,7 +11,7 @@ import time
 import torch
 from transformers import AutoProcessor
 
-from ipex_llm.transformers import AutoModelForVision2Seq
+from ipex_llm.transformers import Qwen2VLForConditionalGeneration
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
@@ -23,8 +23,9 @@ if __name__ == "__main__":
     a = ap.parse_args()
     from PIL import Image
     # the vision tower stays in fp16 (it is a small part of the weights and sensitive to quantization)
-    model = AutoModelForVision2Seq.from_pretrained(a.repo_id_or_model_path, load_in_low_bit=a.low_bit, optimize_model=True,
-                                                   modules_to_not_convert=["visual"], use_cache=True)
+    model = Qwen2VLForConditionalGeneration.from_pretrained(a.repo_id_or_model_path, load_in_low_bit=a.low_bit,
+                                                            optimize_model=True, modules_to_not_convert=["visual"],
+                                                            use_cache=True)
     model = model.half().to("cuda")
     processor = AutoProcessor.from_pretrained(a.repo_id_or_model_path)
     messages = [{"role": "user", "content": [{"type": "image"}, {"type": "text", "text": a.prompt}]}]
