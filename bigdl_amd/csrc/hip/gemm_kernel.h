@@ -19,6 +19,35 @@
 #pragma once
 #include "gemv_kernel.h"
 
+// Hooks of benchmark/gemm_probe.hip (all 0 in the library build):
+// GEMM_STAMP = 1: every wavefront writes 100 MHz wall-clock stamps to g_gemm_stamps ([workgroup][wavefront][32]:
+// 0 entry, 1 first x tile staged, 2 + i after k iteration i, 31 exit).
+// GEMM_ABL (results are wrong): 1 = no MFMA, 2 = no dequantization, 4 = no LDS fragment reads, 8 = no x loads in the
+// k loop, 16 = no weight loads in the k loop.
+#ifndef GEMM_STAMP
+#define GEMM_STAMP 0
+#endif
+#ifndef GEMM_ABL
+#define GEMM_ABL 0
+#endif
+#if GEMM_STAMP
+__device__ unsigned long long* g_gemm_stamps = nullptr;      // [2048 workgroups][16][32], set by the probe
+#define GEMM_STAMP_AT(i)                                                                                        \
+  do {                                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                          \
+    const unsigned long long t_ = __builtin_amdgcn_s_memrealtime();                                             \
+    if (lane == 0 && (i) < 32 && g_gemm_stamps != nullptr && blockIdx.x + gridDim.x * blockIdx.y < 2048)        \
+      g_gemm_stamps[((size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 16 + wave) * 32 + (i)] = t_;               \
+    __builtin_amdgcn_sched_barrier(0);                                                                          \
+  } while (0)
+#else
+#define GEMM_STAMP_AT(i)
+#endif
+// look-ahead of the weight stream in k-tiles (even)
+#ifndef GEMM_DEPTH
+#define GEMM_DEPTH 4
+#endif
+
 namespace bigdl {
 
 struct GemmArgs {
@@ -51,6 +80,7 @@ __global__ __launch_bounds__(256, 2) void gemm_t16_kernel(GemmArgs a) {
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  GEMM_STAMP_AT(0);
   const int r = lane & 15, g = lane >> 4;
   const int KT = (a.K + 127) >> 7;
   const int nblocks = (a.N + BN - 1) / BN;
@@ -133,7 +163,8 @@ __global__ __launch_bounds__(256, 2) void gemm_t16_kernel(GemmArgs a) {
 
   // weight tiles: a ring of DEPTH k-tiles per wavefront in flight (HBM latency under load is several k-tiles of
   // MFMA work at small M; one tile of look-ahead left the MFMA pipe waiting on vmcnt)
-  constexpr int DEPTH = 4;
+  constexpr int DEPTH = GEMM_DEPTH;
+  static_assert(DEPTH % 2 == 0, "the x stage index is taken from the unrolled position");
   Tile<QT> tt[DEPTH][NT];
   auto fetch_b = [&](Tile<QT> (&t)[NT], int kt) {
 #pragma unroll
@@ -146,6 +177,10 @@ __global__ __launch_bounds__(256, 2) void gemm_t16_kernel(GemmArgs a) {
       half8 bf[NT];
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
+        if constexpr (GEMM_ABL & 2) {
+          bf[n] = __builtin_bit_cast(half8, uint4v{t[n].lo0[s], t[n].lo0[(s + 1) & 3], __builtin_bit_cast(uint32_t, half2v{t[n].d[s], t[n].d[s]}), 0x3c003c00u});
+          continue;
+        }
         const half8 code = decode_step<QT>(t[n], s, lut);
         _Float16 d = t[n].d[s];
         if constexpr (post_scale<QT>() != 1.0f) d = (_Float16)fminf((float)d * post_scale<QT>(), 65504.0f);
@@ -155,9 +190,18 @@ __global__ __launch_bounds__(256, 2) void gemm_t16_kernel(GemmArgs a) {
       const int aoff = (((4 * s + g) ^ r) & 15) << 4;
 #pragma unroll
       for (int j = 0; j < MT; ++j) {
-        const half8 af = *(const half8*)(abase + j * 16 * 256 + aoff);
+        half8 af;
+        if constexpr (GEMM_ABL & 4) af = __builtin_bit_cast(half8, uint4v{(uint32_t)(aoff + j + stage), 0x3c003c00u, 0x3c003c00u, 0x3c003c00u});
+        else af = *(const half8*)(abase + j * 16 * 256 + aoff);
 #pragma unroll
-        for (int n = 0; n < NT; ++n) acc[j][n] = mfma16(af, bf[n], acc[j][n]);
+        for (int n = 0; n < NT; ++n) {
+          if constexpr (GEMM_ABL & 1) {
+            const uint4v x = __builtin_bit_cast(uint4v, af) ^ __builtin_bit_cast(uint4v, bf[n]);
+            acc[j][n][0] += __uint_as_float((x[0] ^ x[1] ^ x[2] ^ x[3]) & 0x3f800000u);
+          } else {
+            acc[j][n] = mfma16(af, bf[n], acc[j][n]);
+          }
+        }
       }
     }
   };
@@ -171,16 +215,18 @@ __global__ __launch_bounds__(256, 2) void gemm_t16_kernel(GemmArgs a) {
   store_a(areg[0], 0);
   gload_a(areg[1], min(kt0 + 1, klast));
   __syncthreads();
+  GEMM_STAMP_AT(1);
   for (int kt = kt0; kt < kt1; kt += DEPTH) {
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
       const int k = kt + d;                 // block-uniform
       if (k >= kt1) break;
-      gload_a(areg[d & 1], min(k + 2, klast));           // (k - kt0) & 1 == d & 1: DEPTH is even
+      if constexpr (!(GEMM_ABL & 8)) gload_a(areg[d & 1], min(k + 2, klast));           // (k - kt0) & 1 == d & 1: DEPTH is even
       compute(tt[d], d & 1);
-      fetch_b(tt[d], min(k + DEPTH, klast));
-      store_a(areg[(d + 1) & 1], (d + 1) & 1);
+      if constexpr (!(GEMM_ABL & 16)) fetch_b(tt[d], min(k + DEPTH, klast));
+      if constexpr (!(GEMM_ABL & 8)) store_a(areg[(d + 1) & 1], (d + 1) & 1);
       __syncthreads();
+      GEMM_STAMP_AT(2 + k - kt0);
     }
   }
 
@@ -220,6 +266,7 @@ __global__ __launch_bounds__(256, 2) void gemm_t16_kernel(GemmArgs a) {
       }
     }
   }
+  GEMM_STAMP_AT(31);
 }
 
 template <int QT, int MT, int NT>
