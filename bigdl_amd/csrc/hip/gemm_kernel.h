@@ -67,10 +67,25 @@ struct GemmArgs {
   const int* x_rows;
   const float* row_scale;  // [Mtot] multiplied into the output rows (routing weights), or null
   int n_total;             // rows of the stacked weight buffer
+  // RMSNorm folded into the product: x is multiplied by gamma (+ gamma_offset) while it is staged and the result rows by
+  // rsqrt(row_ssq[m] / K + eps) before bias / activation; row_ssq holds the sums of squares of the rows of x (written by
+  // the reduce kernel of the product that produced x: ssq_out)
+  const _Float16* gamma;
+  float gamma_offset, eps;
+  const float* row_ssq;
+  float* ssq_out;          // [Mtot], accumulated (atomics) by the reduce kernel from the rows it writes; zeroed by the caller
+  // pair form (gate / up): blockIdx.z = 1 multiplies by w2 and writes its partials `pair_stride` floats further on; the
+  // reduce kernel then writes act(first + bias) * (second + bias2)
+  const void* w2;
+  const void* bias2;
+  int64_t pair_stride;
+  int force_partial;       // write fp32 partials even with one K split (pair form, ssq_out)
 };
 
 // MT = 16-row tiles of x per workgroup, NT = 16-column weight tiles per wavefront (4 wavefronts side by side)
-template <int QT, int MT, int NT>
+// NORM: x is multiplied by gamma while it is staged (compile-time, so that the gamma load is unconditional: a load
+// under a run-time condition costs the counted waits of the whole loop)
+template <int QT, int MT, int NT, bool NORM = false>
 __global__ __launch_bounds__(256, 2) void gemm_t16_kernel(GemmArgs a) {
   constexpr int BM = MT * 16;
   constexpr int BN = 4 * NT * 16;  // 4 wavefronts side by side along N
@@ -99,7 +114,8 @@ __global__ __launch_bounds__(256, 2) void gemm_t16_kernel(GemmArgs a) {
     n_planes = a.n_total;
   }
   const int kt0 = sp * a.kt_per_split, kt1 = min(KT, kt0 + a.kt_per_split);
-  const T16Planes pl = t16_planes(a.w, QT, n_planes, a.K);
+  const bool second = a.w2 != nullptr && blockIdx.z == 1;
+  const T16Planes pl = t16_planes(second ? a.w2 : a.w, QT, n_planes, a.K);
 
   const _Float16* lut = nullptr;
   if constexpr (QT == Q_NF4) {
@@ -137,7 +153,8 @@ __global__ __launch_bounds__(256, 2) void gemm_t16_kernel(GemmArgs a) {
   // x tiles travel global -> registers -> LDS two k-tiles ahead of their use: tile t sits in register set t & 1
   // from iteration t - 2 and is written to LDS stage t & 1 at the end of iteration t - 1
   uint4v areg[2][MT];
-  auto gload_a = [&](uint4v (&dst)[MT], int kt) {
+  uint4v greg[2];                              // NORM: gamma of the k slot of the tile in the same register set
+  auto gload_a = [&](uint4v (&dst)[MT], uint4v& gdst, int kt) {
     const int k = kt * 128 + sslot * 8;
     const int kc = min(k, a.K - 8);           // K % 32 == 0: the clamped address is a whole valid 16-byte slot
     const bool kin = k < a.K;
@@ -148,11 +165,20 @@ __global__ __launch_bounds__(256, 2) void gemm_t16_kernel(GemmArgs a) {
       const uint4v v = *(const uint4v*)(a.x + xsrc[p] + kc);
       dst[p] = v & uint4v{keep, keep, keep, keep};
     }
+    // gamma of the tile's k slot travels with the tile and is applied when the tile is written to LDS (using it here
+    // would make this the point where the x loads are waited for)
+    if constexpr (NORM) gdst = *(const uint4v*)(a.gamma + kc);
   };
-  auto store_a = [&](uint4v (&src)[MT], int stage) {
+  auto store_a = [&](uint4v (&src)[MT], const uint4v& gsrc, int stage) {
     char* base = As + stage * BM * 256 + srow * 256 + swz;
+    if constexpr (NORM) {
+      const half8 g8 = __builtin_bit_cast(half8, gsrc) + (_Float16)a.gamma_offset;
 #pragma unroll
-    for (int p = 0; p < MT; ++p) *(uint4v*)(base + p * 16 * 256) = src[p];
+      for (int p = 0; p < MT; ++p) *(half8*)(base + p * 16 * 256) = __builtin_bit_cast(half8, src[p]) * g8;
+    } else {
+#pragma unroll
+      for (int p = 0; p < MT; ++p) *(uint4v*)(base + p * 16 * 256) = src[p];
+    }
   };
 
   float4v acc[MT][NT];
@@ -209,11 +235,11 @@ __global__ __launch_bounds__(256, 2) void gemm_t16_kernel(GemmArgs a) {
   // prologue.  Tile indices past the end are clamped to the last tile of the range (a redundant load of data that
   // is already on its way) so that the number of loads per iteration is fixed.
   const int klast = max(kt1 - 1, kt0);
-  gload_a(areg[0], kt0);
+  gload_a(areg[0], greg[0], kt0);
 #pragma unroll
   for (int d = 0; d < DEPTH; ++d) fetch_b(tt[d], min(kt0 + d, klast));
-  store_a(areg[0], 0);
-  gload_a(areg[1], min(kt0 + 1, klast));
+  store_a(areg[0], greg[0], 0);
+  gload_a(areg[1], greg[1], min(kt0 + 1, klast));
   __syncthreads();
   GEMM_STAMP_AT(1);
   for (int kt = kt0; kt < kt1; kt += DEPTH) {
@@ -221,10 +247,10 @@ __global__ __launch_bounds__(256, 2) void gemm_t16_kernel(GemmArgs a) {
     for (int d = 0; d < DEPTH; ++d) {
       const int k = kt + d;                 // block-uniform
       if (k >= kt1) break;
-      if constexpr (!(GEMM_ABL & 8)) gload_a(areg[d & 1], min(k + 2, klast));           // (k - kt0) & 1 == d & 1: DEPTH is even
+      if constexpr (!(GEMM_ABL & 8)) gload_a(areg[d & 1], greg[d & 1], min(k + 2, klast));           // (k - kt0) & 1 == d & 1: DEPTH is even
       compute(tt[d], d & 1);
       if constexpr (!(GEMM_ABL & 16)) fetch_b(tt[d], min(k + DEPTH, klast));
-      if constexpr (!(GEMM_ABL & 8)) store_a(areg[(d + 1) & 1], (d + 1) & 1);
+      if constexpr (!(GEMM_ABL & 8)) store_a(areg[(d + 1) & 1], greg[(d + 1) & 1], (d + 1) & 1);
       __syncthreads();
       GEMM_STAMP_AT(2 + k - kt0);
     }
@@ -237,7 +263,8 @@ __global__ __launch_bounds__(256, 2) void gemm_t16_kernel(GemmArgs a) {
     const int ncol = nt_idx[n] * 16 + r;
     if (nt_idx[n] >= ntiles || ncol >= a.N) continue;
     float bias = 0.0f;
-    if (a.bias != nullptr && a.splitk == 1) bias = (float)((const _Float16*)a.bias)[ncol];
+    const bool partial_out = a.splitk > 1 || a.force_partial;
+    if (a.bias != nullptr && !partial_out) bias = (float)((const _Float16*)a.bias)[ncol];
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
 #pragma unroll
@@ -246,10 +273,11 @@ __global__ __launch_bounds__(256, 2) void gemm_t16_kernel(GemmArgs a) {
         if (m >= rows) continue;
         const int64_t orow = row0 + m;
         float v = acc[j][n][q];
-        if (a.splitk > 1) {
-          a.partial[((int64_t)sp * mtot + orow) * a.N + ncol] = v;
+        if (partial_out) {
+          a.partial[(second ? a.pair_stride : 0) + ((int64_t)sp * mtot + orow) * a.N + ncol] = v;
           continue;
         }
+        if (a.row_ssq != nullptr) v *= rsqrtf(a.row_ssq[orow] / (float)a.K + a.eps);
         v = act_apply(a.act, v + bias);
         if (a.row_scale != nullptr) v *= a.row_scale[orow];
         const int64_t oi = orow * a.ldo + ncol;
@@ -269,20 +297,20 @@ __global__ __launch_bounds__(256, 2) void gemm_t16_kernel(GemmArgs a) {
   GEMM_STAMP_AT(31);
 }
 
-template <int QT, int MT, int NT>
+template <int QT, int MT, int NT, bool NORM = false>
 static int gemm_launch_mt(const GemmArgs& a, int mblocks, hipStream_t st) {
   constexpr int BM = MT * 16;
   const size_t lds = 2 * BM * 256 + (QT == Q_NF4 ? 64 * 16 * 2 : 0);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm_t16_kernel<QT, MT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)gemm_t16_kernel<QT, MT, NT, NORM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return -101;
     attr_set = true;
   }
   const int bn = 64 * NT;
   const int nblocks = (a.N + bn - 1) / bn;
-  const dim3 grid(nblocks * a.splitk, mblocks);
-  hipLaunchKernelGGL((gemm_t16_kernel<QT, MT, NT>), grid, dim3(256), lds, st, a);
+  const dim3 grid(nblocks * a.splitk, mblocks, a.w2 != nullptr ? 2 : 1);
+  hipLaunchKernelGGL((gemm_t16_kernel<QT, MT, NT, NORM>), grid, dim3(256), lds, st, a);
   return HIP_CHECK_LAUNCH();
 }
 
@@ -291,6 +319,11 @@ static int gemm_launch_mt(const GemmArgs& a, int mblocks, hipStream_t st) {
 template <int QT>
 static int gemm_launch_qt(const GemmArgs& a, int bm, int bn, int mblocks, hipStream_t st) {
   if (bn != 128) return -4;
+  if (a.gamma != nullptr) {
+    if (bm == 64) return gemm_launch_mt<QT, 4, 2, true>(a, mblocks, st);
+    if (bm == 128) return gemm_launch_mt<QT, 8, 2, true>(a, mblocks, st);
+    return -4;
+  }
   if (bm == 64) return gemm_launch_mt<QT, 4, 2>(a, mblocks, st);
   if (bm == 128) return gemm_launch_mt<QT, 8, 2>(a, mblocks, st);
   return -4;

@@ -17,29 +17,113 @@ int gemm_launch_sym_int8(const GemmArgs& a, int bm, int bn, int mblocks, hipStre
 int gemm_launch_fp8_e4m3(const GemmArgs& a, int bm, int bn, int mblocks, hipStream_t st);
 int gemm_launch_fp8_e5m2(const GemmArgs& a, int bm, int bn, int mblocks, hipStream_t st);
 
-// out[m][n] = epilogue(sum_s partial[s][m][n])
+// out[m][n] = epilogue(sum_s partial[s][m][n]); pair form: act(first) * second; optional folded RMSNorm factor of the
+// row (row_ssq) and sum of squares of the rows written (ssq_out, for the norm folded into the next product).
+// V = elements per thread (4: N % 4 == 0, rows of out / residual 8-byte aligned; else 1).  A workgroup covers 256 * V
+// consecutive elements; with ssq_out it adds ONE value per row it touches (LDS reduction first: same-address atomics
+// from every wavefront of a row cost more than the rest of the kernel).
+template <int V>
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs a) {
   const int64_t total = (int64_t)a.M * a.N;
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= total) return;
-  const int64_t m = i / a.N;
-  const int n = (int)(i - m * a.N);
-  float v = 0.0f;
-  for (int s = 0; s < a.splitk; ++s) v += a.partial[(int64_t)s * total + i];
-  if (a.bias != nullptr) v += (float)((const _Float16*)a.bias)[n];
-  v = act_apply(a.act, v);
-  if (a.row_scale != nullptr) v *= a.row_scale[m];
-  const int64_t oi = m * a.ldo + n;
-  if (a.out_type == OUT_F16) {
-    if (a.residual) v += load_out<OUT_F16>(a.residual, oi);
-    store_out<OUT_F16>(a.out, oi, v);
-  } else if (a.out_type == OUT_BF16) {
-    if (a.residual) v += load_out<OUT_BF16>(a.residual, oi);
-    store_out<OUT_BF16>(a.out, oi, v);
-  } else {
-    if (a.residual) v += load_out<OUT_F32>(a.residual, oi);
-    store_out<OUT_F32>(a.out, oi, v);
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * V;
+  const bool in = i < total;
+  const int64_t ic = in ? i : total - V;
+  const int m = (int)(ic / a.N);
+  const int n = (int)(ic - (int64_t)m * a.N);
+  typedef float fvec __attribute__((ext_vector_type(V)));
+  float v[V], u[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) v[e] = u[e] = 0.0f;
+  for (int s = 0; s < a.splitk; ++s) {
+    const fvec p = *(const fvec*)(a.partial + (int64_t)s * total + ic);
+#pragma unroll
+    for (int e = 0; e < V; ++e) v[e] += p[e];
   }
+  if (a.w2 != nullptr) {
+    for (int s = 0; s < a.splitk; ++s) {
+      const fvec p = *(const fvec*)(a.partial + a.pair_stride + (int64_t)s * total + ic);
+#pragma unroll
+      for (int e = 0; e < V; ++e) u[e] += p[e];
+    }
+  }
+  const float rs = a.row_ssq != nullptr ? rsqrtf(a.row_ssq[m] / (float)a.K + a.eps) : 1.0f;
+  const float rsc = a.row_scale != nullptr ? a.row_scale[m] : 1.0f;
+  const int64_t oi = (int64_t)m * a.ldo + n;
+  float q = 0.0f;
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    float x = v[e] * rs;
+    if (a.bias != nullptr) x += (float)((const _Float16*)a.bias)[n + e];
+    x = act_apply(a.act, x);
+    if (a.w2 != nullptr) {
+      float y = u[e] * rs;
+      if (a.bias2 != nullptr) y += (float)((const _Float16*)a.bias2)[n + e];
+      x *= y;
+    }
+    x *= rsc;
+    if (a.residual) {
+      if (a.out_type == OUT_F16) x += load_out<OUT_F16>(a.residual, oi + e);
+      else if (a.out_type == OUT_BF16) x += load_out<OUT_BF16>(a.residual, oi + e);
+      else x += load_out<OUT_F32>(a.residual, oi + e);
+    }
+    // what is stored, rounded (the next norm sees the rounded values)
+    if (a.out_type == OUT_F16) x = (float)(_Float16)x;
+    else if (a.out_type == OUT_BF16) x = bf16_bits_to_f32(f32_to_bf16_bits(x));
+    v[e] = x;
+    q += x * x;
+  }
+  if (in) {
+    if (a.out_type == OUT_F16) {
+      _Float16 h[V];
+#pragma unroll
+      for (int e = 0; e < V; ++e) h[e] = (_Float16)v[e];
+      if constexpr (V == 4) *(uint2v*)((_Float16*)a.out + oi) = *(const uint2v*)h;
+      else ((_Float16*)a.out)[oi] = h[0];
+    } else if (a.out_type == OUT_BF16) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) store_out<OUT_BF16>(a.out, oi + e, v[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < V; ++e) store_out<OUT_F32>(a.out, oi + e, v[e]);
+    }
+  }
+  if (a.ssq_out != nullptr) {
+    __shared__ float part[4];
+    __shared__ int rowof[4];
+    if (!in) q = 0.0f;
+    const int wave = threadIdx.x >> 6;
+    const int m_first = __shfl(m, 0), m_last = __shfl(m, 63);
+    const bool uniform = m_first == m_last;            // (N % (64 V) == 0 makes every wavefront single-row)
+    if (uniform) {
+      q = wave_sum(q);
+      if ((threadIdx.x & 63) == 0) { part[wave] = q; rowof[wave] = m; }
+    } else {
+      if (in) unsafeAtomicAdd(a.ssq_out + m, q);
+      if ((threadIdx.x & 63) == 0) { part[wave] = 0.0f; rowof[wave] = -1; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      // merge the wavefronts that share a row: at most one add per row and workgroup
+      for (int w = 0; w < 4; ++w) {
+        if (rowof[w] < 0) continue;
+        float t = part[w];
+        for (int y = w + 1; y < 4; ++y)
+          if (rowof[y] == rowof[w]) { t += part[y]; rowof[y] = -1; }
+        // hardware fp32 add (plain atomicAdd compiles to a compare-and-swap loop)
+        unsafeAtomicAdd(a.ssq_out + rowof[w], t);
+      }
+    }
+  }
+}
+
+static int launch_reduce(const GemmArgs& a, hipStream_t stream) {
+  const int64_t total = (int64_t)a.M * a.N;
+  const bool vec = (a.N % 4 == 0) && (a.ldo % 4 == 0) && (((uintptr_t)a.out & 7) == 0) &&
+                   (a.residual == nullptr || ((uintptr_t)a.residual & 7) == 0) && (a.pair_stride % 4 == 0) &&
+                   (((uintptr_t)a.partial & 15) == 0);
+  if (vec) hipLaunchKernelGGL(gemm_splitk_reduce_kernel<4>, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(gemm_splitk_reduce_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
+  return HIP_CHECK_LAUNCH();
 }
 
 // counts[e] rows of expert e, rows sorted by expert -> table of m-blocks of at most bm rows; unused entries get
@@ -135,9 +219,46 @@ extern "C" int bigdl_gemm_lowbit(const void* x, const void* w, void* out, const 
   if (a.splitk > 1 && (workspace == nullptr || workspace_floats < (int64_t)a.splitk * M * N)) return -5;
   const int rc = dispatch(a, qtype, bm, bn, mblocks, stream);
   if (rc != 0 || a.splitk == 1) return rc;
-  const int64_t total = (int64_t)M * N;
-  hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
-  return HIP_CHECK_LAUNCH();
+  return launch_reduce(a, stream);
+}
+
+// Extended dense form for batched decode: RMSNorm folded in (gamma + row_ssq of x, see GemmArgs), gate / up pair in one
+// launch (w2: out = act(x W^T + bias) * (x W2^T + bias2)), and the sums of squares of the output rows (ssq_out, after
+// the residual add) for the norm folded into the next product.  workspace: fp32, >= (w2 ? 2 : 1) * splitk * M * N.
+extern "C" int bigdl_gemm_lowbit_ex(const void* x, const void* w, const void* w2, void* out, const void* bias, const void* bias2,
+                                    const void* residual, const void* gamma, float gamma_offset, float eps,
+                                    const float* row_ssq, float* ssq_out, float* workspace, int64_t workspace_floats, int M,
+                                    int N, int K, int ldx, int ldo, int qtype, int act, int out_type, hipStream_t stream) {
+  qtype = t16_kernel_qtype(qtype);
+  if (M <= 0 || N <= 0 || K <= 0 || (K & 31) || (ldx & 7) || ((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return -1;
+  if (w2 != nullptr && ((uintptr_t)w2 & 15)) return -1;
+  if (gamma != nullptr && (((uintptr_t)gamma & 15) || row_ssq == nullptr)) return -1;
+  if (out_type < 0 || out_type > 2) return -3;
+  if ((int64_t)M * ldx >= (1ll << 31)) return -6;
+  GemmArgs a = {};
+  a.x = (const _Float16*)x; a.w = w; a.out = out; a.bias = bias; a.residual = residual; a.partial = workspace;
+  a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldo = ldo; a.act = act; a.out_type = out_type;
+  a.gamma = (const _Float16*)gamma; a.gamma_offset = gamma_offset; a.eps = eps; a.row_ssq = gamma != nullptr ? row_ssq : nullptr;
+  a.ssq_out = ssq_out; a.w2 = w2; a.bias2 = bias2;
+  const int bm = bigdl_gemm_lowbit_bm(M);
+  const int bn = pick_bn(M);
+  const int mblocks = (M + bm - 1) / bm;
+  plan(mblocks * (w2 != nullptr ? 2 : 1), bn, N, K, &a.splitk, &a.kt_per_split);
+  a.force_partial = (w2 != nullptr || ssq_out != nullptr) ? 1 : 0;
+  a.pair_stride = (int64_t)a.splitk * M * N;
+  const bool partial_out = a.splitk > 1 || a.force_partial;
+  if (partial_out && (workspace == nullptr || workspace_floats < (w2 != nullptr ? 2 : 1) * (int64_t)a.splitk * M * N)) return -5;
+  const int rc = dispatch(a, qtype, bm, bn, mblocks, stream);
+  if (rc != 0 || !partial_out) return rc;
+  return launch_reduce(a, stream);
+}
+
+// splits the extended form will use (workspace sizing): pair = 1 when w2 is given
+extern "C" int bigdl_gemm_lowbit_ex_splitk(int M, int N, int K, int pair) {
+  int sk, per;
+  const int bm = bigdl_gemm_lowbit_bm(M);
+  plan(((M + bm - 1) / bm) * (pair ? 2 : 1), pick_bn(M), N, K, &sk, &per);
+  return sk;
 }
 
 // Grouped form: `rows` sorted rows in total; row i uses the weights of the expert that the block table assigns

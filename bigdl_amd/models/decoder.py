@@ -338,6 +338,10 @@ class NativeDecoder:
         self.cache: Optional[KVCache] = None
         self._graphs = {}
         self._static = {}
+        self._ssq_ring = {}             # rows -> [slots, rows] fp32 (see _ssq_reset)
+        self._ssq_owner = None
+        self._ssq_next = 0
+        self.fold_batched_norm = False
         self.attn_scale = cfg.attn_scale if cfg.attn_scale is not None else 1.0 / math.sqrt(cfg.head_dim)
         # ALiBi slopes of this rank's heads (tensor parallelism re-slices them)
         self.alibi = None
@@ -950,6 +954,24 @@ class NativeDecoder:
                                           bias=lin.bias, bias2=None if w2 is None else w2.bias, residual=residual,
                                           eps=cfg.rms_eps, act=act, out=out)
             x, gamma = hip.layer_norm(x, gamma, beta, cfg.rms_eps), None
+        if (lin.fused and w2 is not None and w2.fused and m > GEMV_MAX_ROWS and not self.fold_batched_norm
+                and w2.qtype == lin.qtype and w2.n == lin.n and not os.environ.get("BIGDL_NO_PAIR_GEMM")):
+            # batched decode (17 .. 256 rows): gate and up in one launch, act(g) * u in its reduce kernel (three launches
+            # fewer than two products + activation kernel: 10 us per layer at 64 rows)
+            xin = x if gamma is None else hip.rms_norm(x, gamma, cfg.rms_eps, offset=cfg.norm_offset)
+            return hip.gemm_lowbit_ex(xin, lin.w, lin.qtype, lin.n, lin.k, w2=w2.w, bias=lin.bias, bias2=w2.bias, act=act, out=out)
+        if (lin.fused and (w2 is None or w2.fused) and m > GEMV_MAX_ROWS and att_partials is None and self.fold_batched_norm
+                and (w2 is None or (w2.qtype == lin.qtype and w2.n == lin.n))):
+            # BIGDL_FOLD_NORM=1 (measured slower, kept for experiments): the norm folded into the product (gamma while x
+            # is staged: +7 us per product at 64 rows, more than the norm kernel it saves; 1 / rms from the row sums of
+            # squares that the producer of x left behind), and a product that adds to the residual stream leaves the sums
+            # of squares for the next norm
+            ssq = None if gamma is None else self._row_ssq_of(x)
+            ssq_out = self._row_ssq_for(out) if residual is not None and out.shape[1] == cfg.hidden_size else None
+            return hip.gemm_lowbit_ex(x, lin.w, lin.qtype, lin.n, lin.k, w2=None if w2 is None else w2.w, bias=lin.bias,
+                                      bias2=None if w2 is None else w2.bias, residual=residual, gamma=gamma,
+                                      gamma_offset=cfg.norm_offset, eps=cfg.rms_eps, row_ssq=ssq, ssq_out=ssq_out,
+                                      act=act, out=out)
         if lin.fused and (w2 is None or w2.fused) and m > GEMV_MAX_ROWS and att_partials is None:
             # batched decode (17 .. 64 rows): RMSNorm kernel + MFMA GEMM with the epilogue fused
             xin = x if gamma is None else hip.rms_norm(x, gamma, cfg.rms_eps, offset=cfg.norm_offset)
@@ -983,6 +1005,39 @@ class NativeDecoder:
         out.copy_(y)
         return out
 
+    # ---- row sums of squares handed from the product that wrote a tensor to the folded norm of the next product ----
+    def _ssq_reset(self, rows: int):
+        """start of a decode step: zero the ring of [rows] fp32 accumulators and forget who owns what"""
+        ring = self._ssq_ring.get(rows)
+        if ring is None:
+            ring = self._ssq_ring[rows] = torch.zeros(6 * len(self.layers) + 8, rows, dtype=torch.float32, device=self.device)
+        else:
+            ring.zero_()
+        self._ssq_next = 0
+        self._ssq_owner = None          # (data_ptr, width of the tensor the current sums belong to, buffer)
+
+    def _ssq_slot(self, rows: int):
+        ring = self._ssq_ring[rows]
+        assert self._ssq_next < ring.shape[0], "row-sum ring exhausted within one decode step"
+        slot = ring[self._ssq_next]             # every slot is used once per step: it has to start from zero
+        self._ssq_next += 1
+        return slot
+
+    def _row_ssq_for(self, out):
+        """accumulator for the rows about to be written to ``out`` (the product's reduce kernel fills it)"""
+        slot = self._ssq_slot(out.shape[0])
+        self._ssq_owner = (out.data_ptr(), out.shape[1], slot)
+        return slot
+
+    def _row_ssq_of(self, x):
+        """sums of squares of the rows of x: left behind by the product that wrote x, else computed here"""
+        if self._ssq_owner is not None and self._ssq_owner[:2] == (x.data_ptr(), x.shape[1]):
+            return self._ssq_owner[2]
+        slot = self._ssq_slot(x.shape[0])
+        torch.sum(x.float().square(), dim=1, out=slot)
+        self._ssq_owner = (x.data_ptr(), x.shape[1], slot)
+        return slot
+
     def _mlp_in(self, h, lw, a, gamma, beta):
         """a = act(gate(norm(h))) * up(norm(h))  or  act(up(norm(h)))"""
         cfg = self.cfg
@@ -995,6 +1050,10 @@ class NativeDecoder:
         from ..ops import hip
         cfg, cache = self.cfg, self.cache
         h, qkv, attn, act, tmp = st["h"], st["qkv"], st["attn"], st["act"], st["tmp"]
+        self.fold_batched_norm = (batch * q_len > GEMV_MAX_ROWS and cfg.norm != "layer" and self.tp_group is None
+                                  and os.environ.get("BIGDL_FOLD_NORM") == "1")
+        if self.fold_batched_norm:
+            self._ssq_reset(batch * q_len)
         if not self.stage_first:
             pass                              # st["h"] holds the previous stage's output
         elif cfg.embed_scale != 1.0 or self.embed.dtype != h.dtype:
@@ -1039,9 +1098,11 @@ class NativeDecoder:
                 if lw.post_attn_out_norm is not None:
                     hip.rms_norm(tmp, lw.post_attn_out_norm, cfg.rms_eps, offset=cfg.norm_offset, out=tmp)
                 h.add_(tmp)
+                self._ssq_owner = None
             ffn_norm = lw.pre_ffn_norm if lw.pre_ffn_norm is not None else lw.post_norm
             if lw.moe is not None:
                 lw.moe.forward_decode(self, h, ffn_norm)
+                self._ssq_owner = None
                 continue
             a = act[:, : lw.up.n]
             if not (layer_norm and cfg.parallel_residual):
@@ -1053,6 +1114,7 @@ class NativeDecoder:
                 if lw.post_ffn_out_norm is not None:
                     hip.rms_norm(tmp, lw.post_ffn_out_norm, cfg.rms_eps, offset=cfg.norm_offset, out=tmp)
                 h.add_(tmp)
+                self._ssq_owner = None
         if not self.stage_last:
             cache.past_len.add_(cache.active, alpha=q_len)
             return

@@ -59,6 +59,8 @@ def lib():
         L.bigdl_gemv_lowbit_moe.argtypes = [vp, vp, vp, vp, vp, vp, vp, cf, cf, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp]
         L.bigdl_gemm_lowbit.argtypes = [vp, vp, vp, vp, vp, vp, i64, ci, ci, ci, ci, ci, ci, ci, ci, vp]
         L.bigdl_gemm_lowbit_splitk.argtypes = [ci, ci, ci]
+        L.bigdl_gemm_lowbit_ex.argtypes = [vp] * 8 + [cf, cf, vp, vp, vp, i64] + [ci] * 8 + [vp]
+        L.bigdl_gemm_lowbit_ex_splitk.argtypes = [ci, ci, ci, ci]
         L.bigdl_gemm_lowbit_bm.argtypes = [ci]
         L.bigdl_gemm_lowbit_grouped.argtypes = [vp] * 8 + [ci] * 12 + [vp]
         L.bigdl_moe_block_table.argtypes = [vp, ci, ci, ci, vp, vp, vp, vp]
@@ -275,6 +277,56 @@ def gemm_lowbit(x, w, qtype, out_features, in_features, *, bias=None, residual=N
     rc = L.bigdl_gemm_lowbit(_ptr(x), _ptr(w), _ptr(out), _ptr(bias), _ptr(residual), _ptr(ws), ws_n, m, out_features, k,
                              x.stride(0), out.stride(0), qtype, ACT[act], _out_type(out_dtype), _stream())
     _check(rc, "gemm_lowbit")
+    return out
+
+
+def gemm_lowbit_ex(x, w, qtype, out_features, in_features, *, w2=None, bias=None, bias2=None, residual=None, gamma=None,
+                   gamma_offset=0.0, eps=1e-6, row_ssq=None, ssq_out=None, act=None, out=None):
+    """The MFMA GEMM with the fusions of a batched decode step (17 .. 256 rows):
+
+    * ``gamma`` + ``row_ssq`` [M] fp32: RMSNorm(x) folded in (x is scaled by gamma while it is staged, the result rows by
+      ``rsqrt(row_ssq / K + eps)``); ``row_ssq`` holds the sums of squares of the rows of x;
+    * ``w2``: gate / up pair in one launch, ``out = act(x W^T + bias) * (x W2^T + bias2)``;
+    * ``ssq_out`` [M] fp32 (zeroed by the caller): receives the sums of squares of the rows written to ``out`` (after the
+      residual add), i.e. the ``row_ssq`` of the next product."""
+    _need_cuda(x, w, w2, bias, bias2, residual, gamma, row_ssq, ssq_out, out)
+    if x.dim() != 2 or x.dtype != torch.float16 or x.stride(1) != 1:
+        raise ValueError("x must be a 2-D fp16 tensor with contiguous rows")
+    m, k = x.shape
+    if k != in_features:
+        raise ValueError(f"x has {k} features, weight expects {in_features}")
+    if qtype not in Q.T16_QTYPES:
+        raise ValueError(f"qtype {qtype} has no fused GEMM kernel")
+    from .host import device_nbytes
+    nb = device_nbytes(qtype, out_features, in_features)
+    if w.numel() * w.element_size() != nb or (w2 is not None and w2.numel() * w2.element_size() != nb):
+        raise ValueError("weight buffer size does not match the tiled layout")
+    if out is None:
+        out = torch.empty((m, out_features), dtype=torch.float16, device=x.device)
+    if out.shape != (m, out_features) or out.stride(1) != 1:
+        raise ValueError("bad out tensor")
+    for b_ in (bias, bias2):
+        if b_ is not None and (b_.dtype != torch.float16 or b_.numel() != out_features or not b_.is_contiguous()):
+            raise ValueError("bias must be contiguous fp16 [out_features]")
+    if residual is not None and (residual.shape != out.shape or residual.dtype != out.dtype or residual.stride() != out.stride()):
+        raise ValueError("residual must match out")
+    if gamma is not None:
+        if gamma.dtype != torch.float16 or gamma.numel() != k or not gamma.is_contiguous():
+            raise ValueError("gamma must be contiguous fp16 [in_features]")
+        if row_ssq is None or row_ssq.dtype != torch.float32 or row_ssq.numel() < m or not row_ssq.is_contiguous():
+            raise ValueError("the folded norm needs row_ssq: contiguous fp32 [M]")
+    if ssq_out is not None and (ssq_out.dtype != torch.float32 or ssq_out.numel() < m or not ssq_out.is_contiguous()):
+        raise ValueError("ssq_out must be contiguous fp32 [M]")
+    L = lib()
+    sk = L.bigdl_gemm_lowbit_ex_splitk(m, out_features, k, 1 if w2 is not None else 0)
+    ws, ws_n = None, 0
+    if sk > 1 or w2 is not None or ssq_out is not None:
+        ws = _gemm_workspace(x.device, (2 if w2 is not None else 1) * sk * m * out_features)
+        ws_n = ws.numel()
+    rc = L.bigdl_gemm_lowbit_ex(_ptr(x), _ptr(w), _ptr(w2), _ptr(out), _ptr(bias), _ptr(bias2), _ptr(residual), _ptr(gamma),
+                                float(gamma_offset), float(eps), _ptr(row_ssq), _ptr(ssq_out), _ptr(ws), ws_n, m, out_features, k,
+                                x.stride(0), out.stride(0), qtype, ACT[act], _out_type(out.dtype), _stream())
+    _check(rc, "gemm_lowbit_ex")
     return out
 
 

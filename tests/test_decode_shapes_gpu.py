@@ -197,3 +197,36 @@ def test_fp16_engine_decode_matches_its_prefill():
     logits = eng.prefill(out[:, :-1], last_only=False)
     pred = logits[0, 39:].argmax(-1)
     assert (pred == out[0, 40:]).float().mean().item() >= 0.9
+
+
+@pytest.mark.parametrize("mode", ["pair", "fold"])
+@pytest.mark.parametrize("batch", [24, 64])
+def test_batched_decode_fused_forms_match_separate_kernels(batch, mode, monkeypatch):
+    """Decode at 17+ rows: gate / up as one launch with the activation in its reduce kernel (default), and the
+    experimental form with the norm folded into the GEMM (BIGDL_FOLD_NORM=1), against separate kernels."""
+    import torch
+    from bigdl_amd import qtypes as Q
+    from bigdl_amd.models.decoder import DecoderConfig, build_random_decoder
+    cfg = DecoderConfig(vocab_size=512, hidden_size=512, intermediate_size=1408, num_layers=3, num_heads=8, num_kv_heads=4,
+                        head_dim=64, max_position=256)
+    eng = build_random_decoder(cfg, Q.SYM_INT4, device="cuda", seed=3)
+    eng.use_graph = False
+    ids = torch.randint(3, 512, (batch, 12)).cuda()
+    outs = []
+    for fused in (True, False):
+        monkeypatch.delenv("BIGDL_FOLD_NORM", raising=False)
+        monkeypatch.delenv("BIGDL_NO_PAIR_GEMM", raising=False)
+        if fused and mode == "fold":
+            monkeypatch.setenv("BIGDL_FOLD_NORM", "1")
+        if not fused:
+            monkeypatch.setenv("BIGDL_NO_PAIR_GEMM", "1")
+        eng.ensure_cache(batch, 32)
+        eng.cache.reset()
+        logits = eng.prefill(ids)
+        tok = logits[:, -1].argmax(-1).view(batch, 1)
+        lg, _ = eng.decode(tok)
+        lg2, _ = eng.decode(lg.view(batch, -1).argmax(-1).view(batch, 1))
+        outs.append((lg.clone(), lg2.clone()))
+        assert eng.fold_batched_norm is (fused and mode == "fold")
+    for a, b in zip(outs[0], outs[1]):
+        torch.testing.assert_close(a, b, rtol=2e-2, atol=2e-2)

@@ -95,3 +95,47 @@ def test_grouped_gemm_matches_per_expert_reference(hip, bm):
     exp_sorted = flat[order].cpu()
     ref = torch.stack([x[tok[i]].cpu().float() @ refs[int(exp_sorted[i])].t() * float(scale[order][i]) for i in range(rows)])
     torch.testing.assert_close(out.cpu().float(), ref, rtol=5e-3, atol=5e-3)
+
+
+@pytest.mark.parametrize("shape", [(64, 1024, 384), (24, 512, 2048), (100, 4096, 512)])     # (rows, K, N)
+@pytest.mark.parametrize("name", ["sym_int4", "asym_int4", "fp8_e5m2"])
+def test_gemm_ex_folded_norm_residual_and_row_sums(hip, name, shape):
+    """RMSNorm folded into the product (gamma at x staging, 1 / rms from row sums of squares), residual add, and the
+    sums of squares of the rows written, against fp32 PyTorch."""
+    torch.manual_seed(5)
+    m, k, n = shape
+    qt = Q.ggml_tensor_qtype[name]
+    w = torch.randn(n, k) * 0.03
+    x = torch.randn(m, k).half()
+    gamma = (1.0 + 0.1 * torch.randn(k)).half()
+    bias = (torch.randn(n) * 0.1).half()
+    res = torch.randn(m, n).half()
+    dev, ref_w = _quant_dev(w, qt)
+    eps = 1e-5
+    xn = x.float() * torch.rsqrt(x.float().square().mean(-1, keepdim=True) + eps) * gamma.float()
+    ref = xn @ ref_w.t() + bias.float() + res.float()
+    ssq_in = x.float().square().sum(-1).cuda()
+    ssq_out = torch.zeros(m, dtype=torch.float32, device="cuda")
+    out = hip.gemm_lowbit_ex(x.cuda(), dev, qt, n, k, bias=bias.cuda(), residual=res.cuda(), gamma=gamma.cuda(), eps=eps,
+                             row_ssq=ssq_in, ssq_out=ssq_out)
+    torch.testing.assert_close(out.cpu().float(), ref, rtol=6e-3, atol=6e-3)
+    torch.testing.assert_close(ssq_out.cpu(), out.cpu().float().square().sum(-1), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("m", [20, 64, 130])
+def test_gemm_ex_gate_up_pair(hip, m):
+    """gate and up in one launch: act(norm(x) Wg^T) * (norm(x) Wu^T), with the folded norm's gemma-style offset"""
+    torch.manual_seed(6)
+    k, n = 768, 1408
+    qt = Q.SYM_INT4
+    wg, wu = torch.randn(n, k) * 0.03, torch.randn(n, k) * 0.03
+    x = torch.randn(m, k).half()
+    gamma = (0.1 * torch.randn(k)).half()
+    dg, rg = _quant_dev(wg, qt)
+    du, ru = _quant_dev(wu, qt)
+    eps = 1e-6
+    xn = x.float() * torch.rsqrt(x.float().square().mean(-1, keepdim=True) + eps) * (1.0 + gamma.float())
+    ref = torch.nn.functional.silu(xn @ rg.t()) * (xn @ ru.t())
+    out = hip.gemm_lowbit_ex(x.cuda(), dg, qt, n, k, w2=du, gamma=gamma.cuda(), gamma_offset=1.0, eps=eps,
+                             row_ssq=x.float().square().sum(-1).cuda(), act="silu")
+    torch.testing.assert_close(out.cpu().float(), ref, rtol=8e-3, atol=8e-3)
