@@ -365,6 +365,10 @@ def register_hip_attention(model):
         # masks are built as for SDPA: None for pure causal, additive / boolean [B, 1, Sq, Lk] otherwise
         ALL_MASK_ATTENTION_FUNCTIONS.register(HIP_ATTENTION, ALL_MASK_ATTENTION_FUNCTIONS["sdpa"])
     done = False
+    if any(getattr(m, "sinks", None) is not None for m in model.modules()):
+        # attention sinks (GPT-OSS: one extra logit per head in the softmax): neither the kernel nor SDPA has them, the
+        # model keeps the attention implementation it was loaded with
+        return False
     for m in model.modules():
         cfg = getattr(m, "config", None)
         if cfg is not None and getattr(cfg, "_attn_implementation", None) in ("sdpa", "eager", None) \

@@ -27,7 +27,11 @@ GROUPED_GEMM = os.environ.get("BIGDL_MOE_GROUPED_GEMM", "1") != "0"
 
 def is_fused_experts(module) -> bool:
     g, d = getattr(module, "gate_up_proj", None), getattr(module, "down_proj", None)
-    return isinstance(g, nn.Parameter) and isinstance(d, nn.Parameter) and g.dim() == 3 and d.dim() == 3
+    if not (isinstance(g, nn.Parameter) and isinstance(d, nn.Parameter) and g.dim() == 3 and d.dim() == 3):
+        return False
+    # the [E, 2I, H] / [E, H, I] layout with a plain activation; experts with biases, interleaved gate / up columns or a
+    # clamped activation of their own (GPT-OSS) keep their dense parameters
+    return hasattr(module, "act_fn") and getattr(module, "gate_up_proj_bias", None) is None
 
 
 class LowBitExperts(nn.Module):

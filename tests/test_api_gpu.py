@@ -412,3 +412,44 @@ def test_mllama_cross_attention_runs_on_the_flash_kernel():
     cross = [c for c in calls if c[1] != c[0]]
     assert len(cross) == 2 and all(c[2] is False for c in cross), calls      # two cross-attention layers, non-causal
     assert torch.nn.functional.cosine_similarity(got.flatten(), want.flatten(), dim=0) > 0.999
+
+
+def test_siglip_tower_72_wide_heads_and_internvl_wrapper_on_gpu(monkeypatch):
+    """The image encoders of MiniCPM-V (SigLIP, 72-channel heads: reference models/minicpmv.py:44-90) and InternVL
+    (models/internvl.py:170) on the GPU module path: attention through the flash kernel (72-wide tiles included), logits
+    equal to the CPU run of the same quantized model."""
+    import copy
+    from transformers import AutoModelForImageTextToText, InternVLConfig, SiglipVisionConfig, SiglipVisionModel
+    from bigdl_amd.ops import hip
+    from bigdl_amd.optimize import optimize_model
+    calls = {"n": 0, "dims": set()}
+    real = hip.attn_prefill
+
+    def counted(q, *a, **k):
+        calls["n"] += 1
+        calls["dims"].add(q.shape[-1])
+        return real(q, *a, **k)
+    monkeypatch.setattr(hip, "attn_prefill", counted)
+    torch.manual_seed(0)
+    tower = SiglipVisionModel(SiglipVisionConfig(hidden_size=288, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                                                 image_size=56, patch_size=14)).eval()
+    q = optimize_model(tower, low_bit="sym_int8")
+    x = torch.randn(2, 3, 56, 56)
+    with torch.no_grad():
+        ref = q(pixel_values=x).last_hidden_state.float()
+        out = copy.deepcopy(q).half().to("cuda")(pixel_values=x.half().cuda()).last_hidden_state.float().cpu()
+    assert 72 in calls["dims"], "the 72-wide flash kernel was not used"
+    assert _rel(out, ref) < 0.03
+    text = dict(vocab_size=320, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                num_key_value_heads=2, max_position_embeddings=256)
+    cfg = InternVLConfig(vision_config=dict(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                                            image_size=[28, 28], patch_size=[14, 14]),
+                         text_config=dict(model_type="qwen2", **text), image_token_id=319, downsample_ratio=0.5)
+    m = optimize_model(AutoModelForImageTextToText.from_config(cfg).eval(), low_bit="sym_int8")
+    ids, px = torch.tensor([[1, 5, 319, 7, 8, 9]]), torch.randn(1, 3, 28, 28)
+    n0 = calls["n"]
+    with torch.no_grad():
+        ref = m(input_ids=ids, pixel_values=px).logits.float()
+        out = copy.deepcopy(m).half().to("cuda")(input_ids=ids.cuda(), pixel_values=px.half().cuda()).logits.float().cpu()
+    assert calls["n"] > n0
+    assert _rel(out, ref) < 0.03

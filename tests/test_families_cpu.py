@@ -41,6 +41,27 @@ FAMILIES = {
     "deepseek_v2": dict(intermediate_size=256, moe_intermediate_size=64, num_key_value_heads=4, n_routed_experts=4,
                         n_shared_experts=1, q_lora_rank=32, kv_lora_rank=16, qk_nope_head_dim=16, qk_rope_head_dim=16,
                         v_head_dim=16, first_k_dense_replace=1, num_experts_per_tok=2),
+    "deepseek_v3": dict(intermediate_size=256, moe_intermediate_size=64, num_key_value_heads=4, n_routed_experts=4,
+                        n_shared_experts=1, q_lora_rank=32, kv_lora_rank=16, qk_nope_head_dim=16, qk_rope_head_dim=16,
+                        v_head_dim=16, first_k_dense_replace=1, num_experts_per_tok=2, n_group=2, topk_group=1),
+    "qwen3_moe": dict(intermediate_size=256, moe_intermediate_size=64, num_key_value_heads=2, head_dim=32, num_experts=4,
+                      num_experts_per_tok=2),
+    "glm4_moe": dict(intermediate_size=256, moe_intermediate_size=64, num_key_value_heads=2, head_dim=32, n_routed_experts=4,
+                     n_shared_experts=1, num_experts_per_tok=2, first_k_dense_replace=1, n_group=1, topk_group=1,
+                     pad_token_id=0),
+    # (experts with biases and a clamped activation of their own: they stay dense, attention is converted)
+    "gpt_oss": dict(intermediate_size=128, num_key_value_heads=2, head_dim=32, num_local_experts=4, num_experts_per_tok=2,
+                    sliding_window=64, layer_types=["sliding_attention", "full_attention"]),
+    "olmo2": dict(intermediate_size=256, num_key_value_heads=2),
+    "olmoe": dict(intermediate_size=128, num_key_value_heads=4, num_experts=4, num_experts_per_tok=2),
+    "mixtral": dict(intermediate_size=128, num_key_value_heads=2, num_local_experts=4),
+    "qwen2_moe": dict(intermediate_size=256, moe_intermediate_size=64, shared_expert_intermediate_size=128,
+                      num_key_value_heads=2, num_experts=4, num_experts_per_tok=2),
+    "exaone4": dict(intermediate_size=256, num_key_value_heads=2, head_dim=32),
+    "gemma3_text": dict(intermediate_size=256, num_key_value_heads=2, head_dim=32),
+    "nemotron": dict(intermediate_size=256, num_key_value_heads=2),
+    "codegen": dict(n_embd=128, n_layer=2, n_head=4, n_positions=256, rotary_dim=16),
+    "xglm": dict(d_model=128, num_layers=2, attention_heads=4, ffn_dim=256),
 }
 
 
@@ -60,7 +81,7 @@ def test_causal_lm_family_keeps_logits(family):
         out = q(ids).logits.float()
         gen = q.generate(ids[:1], max_new_tokens=3, do_sample=False)
     n_low = sum(1 for m in q.modules() if type(m).__name__ in ("LowBitLinear", "LowBitExperts"))
-    assert n_low >= 2 * cfg.num_hidden_layers, "projections were not converted"
+    assert n_low >= 2 * getattr(cfg, "num_hidden_layers", 2), "projections were not converted"
     assert _rel(out, ref) < 0.05
     assert gen.shape == (1, 12)
 
@@ -119,3 +140,64 @@ def test_vision_language_model_converts_every_tower():
         assert _rel(got, want) < tol, (low_bit, _rel(got, want))
         out = q.generate(input_ids=ids, pixel_values=px, max_new_tokens=4, do_sample=False)
         assert out.shape == (1, ids.shape[1] + 4)
+
+
+# ---- multimodal wrappers and vision towers (reference: models/{internvl,chatglm4v,minicpmv}.py and the nested-model
+# handling of convert.py:1301-1400): tiny random-init models keep their logits after optimize_model ----
+_TEXT = dict(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=4,
+             num_key_value_heads=2, max_position_embeddings=256)
+
+
+def _llava():
+    from transformers import CLIPVisionConfig, LlamaConfig, LlavaConfig
+    cfg = LlavaConfig(vision_config=CLIPVisionConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+                                                     image_size=28, patch_size=14),
+                      text_config=LlamaConfig(**_TEXT), image_token_index=319, vision_feature_layer=-1,
+                      vision_feature_select_strategy="full")
+    n_img = (28 // 14) ** 2 + 1
+    return cfg, dict(input_ids=torch.tensor([[1, 5] + [319] * n_img + [7, 8, 9]]), pixel_values=torch.randn(1, 3, 28, 28))
+
+
+def _internvl():
+    from transformers import InternVLConfig
+    cfg = InternVLConfig(vision_config=dict(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+                                            image_size=[28, 28], patch_size=[14, 14]),
+                         text_config=dict(model_type="qwen2", **_TEXT), image_token_id=319, downsample_ratio=0.5)
+    return cfg, dict(input_ids=torch.tensor([[1, 5, 319, 7, 8, 9]]), pixel_values=torch.randn(1, 3, 28, 28))
+
+
+def _glm4v():
+    from transformers import Glm4vConfig
+    cfg = Glm4vConfig(text_config=dict(rope_parameters={"rope_type": "default", "mrope_section": [4, 6, 6], "rope_theta": 10000.0},
+                                       **_TEXT),
+                      vision_config=dict(hidden_size=64, depth=2, num_heads=4, intermediate_size=128, out_hidden_size=128,
+                                         patch_size=14, image_size=28, spatial_merge_size=2, temporal_patch_size=2),
+                      image_token_id=319, video_token_id=318, image_start_token_id=317, image_end_token_id=316)
+    return cfg, dict(input_ids=torch.tensor([[1, 5, 7, 8, 9, 10]]))      # text-only turn through the 3-axis rotary path
+
+
+@pytest.mark.parametrize("build", [_llava, _internvl, _glm4v], ids=["llava", "internvl", "glm4v"])
+def test_multimodal_wrapper_keeps_logits(build):
+    from transformers import AutoModelForImageTextToText
+    torch.manual_seed(0)
+    cfg, inputs = build()
+    model = AutoModelForImageTextToText.from_config(cfg).eval().float()
+    with torch.no_grad():
+        ref = model(**inputs).logits.float()
+        q = optimize_model(copy.deepcopy(model), low_bit="sym_int8")
+        out = q(**inputs).logits.float()
+    assert sum(1 for m in q.modules() if type(m).__name__ == "LowBitLinear") >= 8      # text and vision projections
+    assert _rel(out, ref) < 0.05
+
+
+def test_siglip_vision_tower_with_72_wide_heads():
+    """MiniCPM-V's image encoder shape (reference models/minicpmv.py:44-90: heads of 72 channels)"""
+    from transformers import SiglipVisionConfig, SiglipVisionModel
+    torch.manual_seed(0)
+    m = SiglipVisionModel(SiglipVisionConfig(hidden_size=144, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+                                             image_size=28, patch_size=14)).eval().float()
+    x = torch.randn(2, 3, 28, 28)
+    with torch.no_grad():
+        ref = m(pixel_values=x).last_hidden_state
+        out = optimize_model(copy.deepcopy(m), low_bit="sym_int8")(pixel_values=x).last_hidden_state
+    assert _rel(out, ref) < 0.05
