@@ -315,6 +315,29 @@ def convert_deepseek_v2(cfg: dict, sd: StateDict):
     return dc, out
 
 
+def _probe_deepseek_v3(cfg):
+    dc = _probe_deepseek_v2(cfg)
+    dc.model_type = "deepseek_v3"
+    dc.moe_score, dc.moe_group_score = "sigmoid", "top2sum"
+    dc.norm_topk_prob = bool(_get(cfg, "norm_topk_prob", default=True))
+    dc.moe_n_group, dc.moe_topk_group = int(_get(cfg, "n_group", default=1) or 1), int(_get(cfg, "topk_group", default=1) or 1)
+    dc.rope_interleaved = bool(_get(cfg, "rope_interleave", default=True))
+    return dc
+
+
+def convert_deepseek_v3(cfg: dict, sd: StateDict):
+    """DeepSeek-V3 / R1 (the reference runs it through its DeepSeek-V2 forwards plus ``moe_group_topk``, models/deepseek.py;
+    example GPU/CPU-GPU-Hybrid-DeepSeek-R1-Inference): the V2 layout with sigmoid router scores, a learned selection bias
+    (``e_score_correction_bias``), groups ranked by the sum of their two best experts, renormalized weights."""
+    dc, out = convert_deepseek_v2(cfg, sd)
+    v3 = _probe_deepseek_v3(cfg)
+    for i in range(dc.num_layers):
+        b = sd.get(f"model.layers.{i}.mlp.gate.e_score_correction_bias")
+        if b is not None:
+            out[f"L{i}.router_bias"] = b
+    return v3, out
+
+
 def convert_llama_like(cfg: dict, sd: StateDict):
     """Aquila / Aquila2, Yi and other checkpoints that use llama's tensor names under another ``model_type``
     (reference models/aquila.py)."""
@@ -739,7 +762,7 @@ LN_CONFIGS = {"gpt_neox": _cfg_gpt_neox, "bloom": _cfg_bloom, "mpt": _cfg_mpt, "
 
 ARCH_CONVERTERS: Dict[str, Callable[[dict, StateDict], Tuple[DecoderConfig, StateDict]]] = {
     "chatglm": convert_chatglm, "baichuan": convert_baichuan, "qwen": convert_qwen, "internlm": convert_internlm,
-    "internlm2": convert_internlm2, "minicpm": convert_minicpm, "minicpm3": convert_minicpm3, "deepseek_v2": convert_deepseek_v2, "aquila": convert_llama_like, "yi": convert_llama_like,
+    "internlm2": convert_internlm2, "minicpm": convert_minicpm, "minicpm3": convert_minicpm3, "deepseek_v2": convert_deepseek_v2, "deepseek_v3": convert_deepseek_v3, "aquila": convert_llama_like, "yi": convert_llama_like,
     **LN_CONVERTERS,
 }
 
@@ -788,14 +811,18 @@ def reference_forward(dc: DecoderConfig, sd: StateDict, ids: torch.Tensor, past=
     def mlp(i, x):
         if f"L{i}.router" in sd:
             t = x.reshape(-1, x.shape[-1])
-            p = torch.softmax(t @ sd[f"L{i}.router"].float().t(), -1)
+            logits = t @ sd[f"L{i}.router"].float().t()
+            p = torch.sigmoid(logits) if dc.moe_score == "sigmoid" else torch.softmax(logits, -1)
+            choice = p + sd[f"L{i}.router_bias"].float() if f"L{i}.router_bias" in sd else p
             if dc.moe_n_group > 1:                  # only the experts of the best groups compete
-                gs = p.view(p.shape[0], dc.moe_n_group, -1).amax(-1)
+                grouped = choice.view(choice.shape[0], dc.moe_n_group, -1)
+                gs = grouped.topk(2, dim=-1).values.sum(-1) if dc.moe_group_score == "top2sum" else grouped.amax(-1)
                 keep = torch.zeros_like(gs).scatter_(1, gs.topk(dc.moe_topk_group, dim=-1).indices, 1.0)
-                p = p * keep.repeat_interleave(dc.num_experts // dc.moe_n_group, 1)
-            w, idx = torch.topk(p, dc.top_k, dim=-1)
+                choice = choice.masked_fill(keep.repeat_interleave(dc.num_experts // dc.moe_n_group, 1) == 0, 0.0)
+            idx = torch.topk(choice, dc.top_k, dim=-1).indices
+            w = p.gather(1, idx)
             if dc.norm_topk_prob:
-                w = w / w.sum(-1, keepdim=True)
+                w = w / (w.sum(-1, keepdim=True) + 1e-20)
             e, inter, hd = dc.num_experts, dc.moe_intermediate_size, t.shape[-1]
             y = torch.zeros_like(t)
             for j in range(e):
@@ -939,6 +966,9 @@ def build_engine(dc: DecoderConfig, qsd: dict, device="cuda"):
         mw = MoEWeights(qsd[f"L{i}.router"].to(dev), ws[0], ws[1], ws[2], qt, e, dc.top_k, hid, inter, act=dc.act,
                         normalize=dc.norm_topk_prob, shared=shared)
         mw.n_group, mw.topk_group = dc.moe_n_group, dc.moe_topk_group
+        mw.score, mw.group_score = dc.moe_score, dc.moe_group_score
+        if f"L{i}.router_bias" in qsd:
+            mw.route_bias = qsd[f"L{i}.router_bias"].to(dev, torch.float32)
         return mw
 
     def opt_lin(name):
@@ -1089,7 +1119,7 @@ def arch_config_only(cfg: dict, padded: bool = False) -> DecoderConfig:
     if padded:
         return pad_head_dim(arch_config_only(cfg), {})[0] if _needs_pad(arch_config_only(cfg)) else arch_config_only(cfg)
     mt = cfg.get("model_type")
-    probe = {"chatglm": _probe_chatglm, "minicpm": _probe_minicpm, "minicpm3": _probe_minicpm3, "deepseek_v2": _probe_deepseek_v2}.get(mt)
+    probe = {"chatglm": _probe_chatglm, "minicpm": _probe_minicpm, "minicpm3": _probe_minicpm3, "deepseek_v2": _probe_deepseek_v2, "deepseek_v3": _probe_deepseek_v3}.get(mt)
     if probe is not None:
         return probe(cfg)
     if mt in LN_CONFIGS:

@@ -72,6 +72,8 @@ class DecoderConfig:
     norm_topk_prob: bool = True
     moe_n_group: int = 1              # DeepSeek-V2 group-limited routing: expert groups, and how many of them compete
     moe_topk_group: int = 1
+    moe_score: str = "softmax"        # "sigmoid": DeepSeek-V3 (scores = sigmoid(logits), selection on scores + a learned bias)
+    moe_group_score: str = "max"      # how a group is ranked: its best expert, or "top2sum" (DeepSeek-V3)
     logit_scale: float = 1.0
     # Qwen2-VL multimodal rotary embedding: how many of the rot/2 frequencies take their angle from the temporal,
     # height and width position of a token (text tokens carry the same value on all three axes)

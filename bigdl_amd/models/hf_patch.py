@@ -544,6 +544,10 @@ def build_native_decoder(model):
 
 
 def native_engine_supported(model) -> bool:
+    """(the answer is cached on the model once an engine exists: the checks below walk every module, which is a
+    millisecond per ``generate`` call on a 7B model)"""
+    if getattr(model, "_native_engine", None) is not None:
+        return True
     cfg = getattr(model, "config", None)
     if cfg is None or getattr(cfg, "model_type", None) not in NATIVE_ENGINE_TYPES | VL_ENGINE_TYPES:
         return False

@@ -81,6 +81,9 @@ class MoEWeights:
         self.ep_rank, self.ep_world = 0, 1
         # group-limited routing (DeepSeek-V2): experts in n_group groups, only the topk_group best groups compete
         self.n_group, self.topk_group = 1, 1
+        # DeepSeek-V3: sigmoid scores; experts are CHOSEN by score + route_bias (a learned load-balancing correction),
+        # groups ranked by the sum of their two best; the weights are the unbiased scores of the chosen experts
+        self.score, self.group_score, self.route_bias = "softmax", "max", None
 
     # ------------------------------------------------------------------ builders
     @classmethod
@@ -137,17 +140,22 @@ class MoEWeights:
         and local ones are rebased to this rank's slice."""
         logits = F.linear(x, self.router.to(x.dtype))
         rng = self.expert_range if local_only else None
-        if self.n_group > 1:
-            # softmax over all experts, experts outside the topk_group best groups (by their best expert) drop out,
-            # weights are the unrenormalized scores (reference models/deepseek.py ``moe_group_topk``); plain tensor ops,
-            # replayable inside the decode graph
-            p = torch.softmax(logits.float(), -1)
-            gs = p.view(p.shape[0], self.n_group, -1).amax(-1)
-            keep = torch.zeros_like(gs).scatter_(1, gs.topk(self.topk_group, dim=-1).indices, 1.0)
-            p = p * keep.repeat_interleave(self.num_experts // self.n_group, 1)
-            w, ids = torch.topk(p, self.top_k, dim=-1)
+        if self.n_group > 1 or self.score == "sigmoid":
+            # scores over all experts, experts outside the topk_group best groups drop out, weights are the scores of the
+            # chosen experts (reference models/deepseek.py ``moe_group_topk``); plain tensor ops, replayable inside the
+            # decode graph
+            p = torch.sigmoid(logits.float()) if self.score == "sigmoid" else torch.softmax(logits.float(), -1)
+            choice = p if self.route_bias is None else p + self.route_bias.float()
+            if self.n_group > 1:
+                grouped = choice.view(choice.shape[0], self.n_group, -1)
+                gs = grouped.topk(2, dim=-1).values.sum(-1) if self.group_score == "top2sum" else grouped.amax(-1)
+                keep = torch.zeros_like(gs).scatter_(1, gs.topk(self.topk_group, dim=-1).indices, 1.0)
+                # (masked to 0, not -inf, as the model's own router does)
+                choice = choice.masked_fill(keep.repeat_interleave(self.num_experts // self.n_group, 1) == 0, 0.0)
+            ids = torch.topk(choice, self.top_k, dim=-1).indices
+            w = p.gather(1, ids)
             if self.normalize:
-                w = w / w.sum(-1, keepdim=True)
+                w = w / (w.sum(-1, keepdim=True) + 1e-20)
             ids = ids.int()
             if rng is not None:
                 inside = (ids >= rng[0]) & (ids < rng[1])

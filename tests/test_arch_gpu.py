@@ -38,7 +38,7 @@ def test_engine_matches_cpu_forward(case):
 
 LN_FAMILIES = ["gpt_neox", "gpt_neox_serial", "bloom", "bloom_6heads", "mpt_6heads", "falcon_7b", "falcon_40b", "falcon_rw",
                "gpt2", "gpt_bigcode", "opt", "phi", "starcoder2", "stablelm", "gptj",
-               "minicpm3", "minicpm3_plain_q", "deepseek_v2", "deepseek_v2_grouped"]        # latent attention (MLA), + routed / shared experts
+               "minicpm3", "minicpm3_plain_q", "deepseek_v2", "deepseek_v2_grouped", "deepseek_v3"]        # latent attention (MLA), + routed / shared experts
 
 
 @pytest.mark.parametrize("family", LN_FAMILIES)

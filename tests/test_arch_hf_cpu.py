@@ -87,9 +87,25 @@ FAMILIES = {
                                        num_experts_per_tok=4, n_shared_experts=1, first_k_dense_replace=0,
                                        topk_method="group_limited_greedy", n_group=4, topk_group=2,
                                        routed_scaling_factor=2.0, max_position_embeddings=64, tie_word_embeddings=False),
+    # sigmoid router scores, learned selection bias, groups ranked by their two best experts, renormalized weights
+    "deepseek_v3": lambda: _mk_v3(),
     "gptj": lambda: _mk(T.GPTJConfig, T.GPTJForCausalLM, vocab_size=V, n_embd=64, n_layer=2, n_head=4, rotary_dim=8,
                         n_positions=64),
 }
+
+
+def _mk_v3():
+    cfg, model = _mk(T.DeepseekV3Config, T.DeepseekV3ForCausalLM, vocab_size=V, hidden_size=64, num_hidden_layers=3,
+                     intermediate_size=128, moe_intermediate_size=64, num_attention_heads=4, num_key_value_heads=4,
+                     q_lora_rank=64, kv_lora_rank=64, qk_nope_head_dim=32, qk_rope_head_dim=32, v_head_dim=32,
+                     n_routed_experts=16, num_experts_per_tok=4, n_shared_experts=1, first_k_dense_replace=1, n_group=4,
+                     topk_group=2, routed_scaling_factor=2.5, norm_topk_prob=True, max_position_embeddings=64,
+                     tie_word_embeddings=False)
+    with torch.no_grad():
+        for m in model.modules():                       # the correction bias is zero at initialisation: make it matter
+            if hasattr(m, "e_score_correction_bias"):
+                m.e_score_correction_bias.copy_(torch.randn_like(m.e_score_correction_bias) * 0.2)
+    return cfg, model
 
 
 @pytest.mark.parametrize("family", sorted(FAMILIES))
