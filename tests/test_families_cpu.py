@@ -201,3 +201,33 @@ def test_siglip_vision_tower_with_72_wide_heads():
         ref = m(pixel_values=x).last_hidden_state
         out = optimize_model(copy.deepcopy(m), low_bit="sym_int8")(pixel_values=x).last_hidden_state
     assert _rel(out, ref) < 0.05
+
+
+def test_idefics2_and_qwen2_audio_wrappers_keep_logits():
+    """Idefics2 (SigLIP tower + perceiver resampler + mistral) and Qwen2-Audio (whisper-style encoder + qwen2): the other
+    two multimodal families HuggingFace ships that the reference converts (convert.py: "idefics2", "qwen2_audio")"""
+    from transformers import (Idefics2Config, Idefics2ForConditionalGeneration, Qwen2AudioConfig,
+                              Qwen2AudioForConditionalGeneration)
+    torch.manual_seed(0)
+    cfg = Idefics2Config(vision_config=dict(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+                                            image_size=28, patch_size=14),
+                         perceiver_config=dict(hidden_size=128, resampler_n_latents=4, resampler_depth=1, resampler_n_heads=4,
+                                               resampler_head_dim=32, num_key_value_heads=2),
+                         text_config=dict(model_type="mistral", **_TEXT), image_token_id=319)
+    m = Idefics2ForConditionalGeneration(cfg).eval().float()
+    ids, px = torch.tensor([[1, 5] + [319] * 4 + [7, 8, 9]]), torch.randn(1, 1, 3, 28, 28)
+    with torch.no_grad():
+        ref = m(input_ids=ids, pixel_values=px).logits.float()
+        q = optimize_model(copy.deepcopy(m), low_bit="sym_int8")
+        out = q(input_ids=ids, pixel_values=px).logits.float()
+    assert sum(1 for x in q.modules() if type(x).__name__ == "LowBitLinear") >= 20
+    assert _rel(out, ref) < 0.05
+    cfg = Qwen2AudioConfig(audio_config=dict(d_model=64, encoder_layers=2, encoder_attention_heads=4, encoder_ffn_dim=128,
+                                             num_mel_bins=16, max_source_positions=16),
+                           text_config=dict(model_type="qwen2", **_TEXT), audio_token_index=319)
+    m = Qwen2AudioForConditionalGeneration(cfg).eval().float()
+    ids = torch.tensor([[1, 5, 7, 8, 9]])
+    with torch.no_grad():
+        ref = m(input_ids=ids).logits.float()
+        out = optimize_model(copy.deepcopy(m), low_bit="sym_int8")(input_ids=ids).logits.float()
+    assert _rel(out, ref) < 0.05
