@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--rccl-allreduce", action="store_true", help="tp: RCCL all-reduce instead of the one-shot IPC kernel")
     ap.add_argument("--prefill-dense-cache", action="store_true",
                     help="keep fp16 copies of the weights for prefill GEMMs (off in the headline number)")
+    ap.add_argument("--prefill-fp8", action="store_true",
+                    help="prompt GEMMs on hipBLASLt's fp8 path, activations and weights quantized per row to e4m3: lower "
+                         "precision than the headline configuration, reported as such (off in the headline number)")
     return ap.parse_args()
 
 
@@ -128,12 +131,15 @@ def report(args, world, par, label, stats, floor_ms=None, extra=None):
         "value": round(rest, 4), "unit": "ms/token", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": False,
         "scaling": "strong" if strong else "weak", "vs_baseline": None,
-        "dtype": f"fp16 activations, {args.low_bit} weights, {args.kv} KV", "data": "synthetic",
+        "dtype": f"fp16 activations, {args.low_bit} weights, {args.kv} KV" + (", e4m3 x e4m3 prompt GEMMs (reduced precision)"
+                                                                              if getattr(args, "prefill_fp8", False) else ""),
+        "data": "synthetic",
         "first_token_latency_ms": round(first, 3), "next_token_latency_ms": round(rest, 4), "peak_mem_gb": round(peak, 3),
         "aggregate_tokens_per_s": round(streams * 1000.0 / rest, 1),
         "config": {"model": label, "low_bit": args.low_bit, "global_batch": streams, "seq_len": args.in_len,
                    "new_tokens": args.out_len, "parallelism": f"{par}{world}" if world > 1 else "single",
-                   "hip_graph": not args.no_graph, "prefill_dense_cache": bool(args.prefill_dense_cache)}}
+                   "hip_graph": not args.no_graph, "prefill_dense_cache": bool(args.prefill_dense_cache),
+                   "prefill_fp8": bool(getattr(args, "prefill_fp8", False))}}
     if floor_ms is not None:
         out["weight_read_floor_ms"] = round(floor_ms, 3)
     out.update(extra or {})
@@ -200,6 +206,8 @@ def native_engine(args, rank, local_rank, world, dist):
     if args.prefill_dense_cache:
         from bigdl_amd.models.decoder import Lin
         Lin.cache_dense = True
+    if args.prefill_fp8:
+        model.prefill_fp8 = True
     g = torch.Generator().manual_seed(0 if par in ("tp", "pp") else rank)
     prompt = torch.randint(3, cfg.vocab_size, (1, args.in_len), generator=g).to(dev)
 

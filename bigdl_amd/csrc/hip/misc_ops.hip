@@ -343,6 +343,83 @@ using namespace bigdl;
 
 static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
+// ---------------------------------------------------------------------------------------------
+// Row-wise dynamic quantization of activations to OCP e4m3 for the opt-in fp8 prompt pass: per row
+// scale = max|x| / 448, codes = round(x / scale).  One workgroup per row, the row stays in registers between the
+// maximum and the conversion (K <= 256 threads x QR_V vectors x 8 halves = 16384).  The codes feed hipBLASLt's fp8 GEMM
+// (torch._scaled_mm with row-wise scales), whose MFMA rate on gfx950 is twice the fp16 one.
+// ---------------------------------------------------------------------------------------------
+constexpr int QR_V = 8;
+__global__ __launch_bounds__(256) void quant_rows_e4m3_kernel(const _Float16* __restrict__ x, uint8_t* __restrict__ q,
+                                                               float* __restrict__ scale, int K, int64_t ldx, int64_t ldq) {
+  __shared__ float red[4];
+  const int64_t row = blockIdx.x;
+  const _Float16* xr = x + row * ldx;
+  const int nvec = K >> 3;
+  half8 v[QR_V];
+  float amax = 0.0f;
+#pragma unroll
+  for (int i = 0; i < QR_V; ++i) {
+    const int vi = threadIdx.x + 256 * i;
+    v[i] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+    if (vi < nvec) v[i] = *(const half8*)(xr + 8 * vi);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf((float)v[i][e]));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
+  __syncthreads();
+  amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const float sc = amax > 0.0f ? amax * (1.0f / 448.0f) : 1.0f;
+  const float inv = 1.0f / sc;
+  if (threadIdx.x == 0) scale[row] = sc;
+#pragma unroll
+  for (int i = 0; i < QR_V; ++i) {
+    const int vi = threadIdx.x + 256 * i;
+    if (vi >= nvec) continue;
+    uint32_t w0 = 0, w1 = 0;
+    // v_cvt_pk_fp8_f32: two floats -> two e4m3 bytes in the low / high half of the destination word
+    w0 = __builtin_amdgcn_cvt_pk_fp8_f32((float)v[i][0] * inv, (float)v[i][1] * inv, w0, false);
+    w0 = __builtin_amdgcn_cvt_pk_fp8_f32((float)v[i][2] * inv, (float)v[i][3] * inv, w0, true);
+    w1 = __builtin_amdgcn_cvt_pk_fp8_f32((float)v[i][4] * inv, (float)v[i][5] * inv, w1, false);
+    w1 = __builtin_amdgcn_cvt_pk_fp8_f32((float)v[i][6] * inv, (float)v[i][7] * inv, w1, true);
+    *(uint2v*)(q + row * ldq + 8 * vi) = uint2v{w0, w1};
+  }
+}
+
+// x fp16 [rows, K] (K % 8 == 0, K <= 16384, 16-byte aligned rows) -> q e4m3 bytes [rows, K] (8-byte aligned rows), scale fp32 [rows]
+extern "C" int bigdl_quant_rows_e4m3(const void* x, void* q, float* scale, int64_t rows, int K, int64_t ldx, int64_t ldq,
+                                     hipStream_t st) {
+  if (rows <= 0 || K <= 0 || (K & 7) || K > 256 * QR_V * 8 || (ldx & 7) || (ldq & 7) || ((uintptr_t)x & 15) || ((uintptr_t)q & 7)) return -1;
+  hipLaunchKernelGGL(quant_rows_e4m3_kernel, dim3((unsigned)rows), dim3(256), 0, st, (const _Float16*)x, (uint8_t*)q, scale, K, ldx, ldq);
+  return HIP_CHECK_LAUNCH();
+}
+
+// bf16 -> fp16, 8 values per thread (the row-wise fp8 GEMM of hipBLASLt only writes bf16; PyTorch's own conversion
+// kernel for this pair of types is not vectorized and took longer than the GEMM it followed)
+__global__ __launch_bounds__(256) void bf16_to_f16_kernel(const uint4v* __restrict__ src, uint4v* __restrict__ dst, int64_t nvec) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nvec) return;
+  const uint4v v = src[i];
+  uint4v o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float lo = __uint_as_float(v[e] << 16), hi = __uint_as_float(v[e] & 0xffff0000u);
+    const half2v h = {(_Float16)fminf(fmaxf(lo, -65504.0f), 65504.0f), (_Float16)fminf(fmaxf(hi, -65504.0f), 65504.0f)};
+    o[e] = __builtin_bit_cast(uint32_t, h);
+  }
+  dst[i] = o;
+}
+
+// n values (n % 8 == 0), both buffers 16-byte aligned and contiguous
+extern "C" int bigdl_bf16_to_f16(const void* src, void* dst, int64_t n, hipStream_t st) {
+  if (n <= 0 || (n & 7) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return -1;
+  const int64_t nvec = n >> 3;
+  hipLaunchKernelGGL(bf16_to_f16_kernel, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, st, (const uint4v*)src, (uint4v*)dst, nvec);
+  return HIP_CHECK_LAUNCH();
+}
+
 extern "C" int bigdl_rms_norm(const void* x, const void* residual, const void* w, void* out, void* res_out, int64_t rows,
                               int H, int64_t ldx, float eps, float offset, int dtype, hipStream_t st) {
   if (rows <= 0 || H <= 0 || (H & 7) || (ldx & 7) || H > 8 * 256 * 8) return -1;

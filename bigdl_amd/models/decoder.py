@@ -211,6 +211,18 @@ class Lin:
             return hip.dequant_t16(self.w, self.qtype, self.n, self.k, dtype=dtype)
         return self.w
 
+    def fp8(self):
+        """(codes ``float8_e4m3fn`` [n, k], scales fp32 [n, 1]) with ``W ~= codes * scales`` (one scale per output row),
+        made once and kept: the weight operand of the opt-in fp8 prompt pass (1 byte per weight of HBM on top of the
+        low-bit tiles, which decode keeps using)."""
+        w8 = getattr(self, "_fp8", None)
+        if w8 is None:
+            from ..ops import hip
+            d = hip.dequant_t16(self.w, self.qtype, self.n, self.k, dtype=torch.float16) if self.fused else self.w
+            sw = d.abs().amax(dim=1, keepdim=True).float().clamp_min(1e-12) / 448.0
+            w8 = self._fp8 = ((d.float() / sw).to(torch.float8_e4m3fn), sw)
+        return w8
+
 
 @dataclass
 class MLAWeights:
@@ -340,6 +352,8 @@ class NativeDecoder:
         self.cache: Optional[KVCache] = None
         self._graphs = {}
         self._static = {}
+        # opt-in fp8 prompt pass (``BIGDL_PREFILL_FP8=1``): see _linear_dense
+        self.prefill_fp8 = os.environ.get("BIGDL_PREFILL_FP8") == "1"
         self._ssq_ring = {}             # rows -> [slots, rows] fp32 (see _ssq_reset)
         self._ssq_owner = None
         self._ssq_next = 0
@@ -439,7 +453,14 @@ class NativeDecoder:
             return hip.gemv_lowbit(x.contiguous(), lin.w, lin.qtype, lin.n, lin.k, bias=lin.bias)
         if lin.fused and x.shape[0] <= GEMM_MAX_ROWS:
             return hip.gemm_lowbit(x.contiguous(), lin.w, lin.qtype, lin.n, lin.k, bias=lin.bias)
-        y = F.linear(x, lin.dense())
+        if self.prefill_fp8 and x.dtype == torch.float16 and lin.k % 16 == 0 and lin.n % 16 == 0 and lin.k <= 16384:
+            # opt-in: activations quantized per row to e4m3, weights per output row, hipBLASLt's fp8 GEMM (twice the fp16
+            # MFMA rate on gfx950); lower precision than the fp16 product, never the default
+            w8, sw = lin.fp8()
+            x8, sx = hip.quant_rows_e4m3(x.contiguous())
+            y = hip.bf16_to_f16(torch._scaled_mm(x8, w8.t(), scale_a=sx, scale_b=sw.t(), out_dtype=torch.bfloat16))
+        else:
+            y = F.linear(x, lin.dense())
         if lin.bias is not None:
             y = y + lin.bias
         return y

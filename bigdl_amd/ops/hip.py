@@ -46,6 +46,8 @@ def lib():
         L.bigdl_attn_decode_counters.argtypes = [ci] * 3
         L.bigdl_rope_append.argtypes = [vp, vp, vp, vp, vp, vp, cf] + [ci] * 10 + [vp]
         L.bigdl_rms_norm.argtypes = [vp, vp, vp, vp, vp, i64, ci, i64, cf, cf, ci, vp]
+        L.bigdl_quant_rows_e4m3.argtypes = [vp, vp, vp, i64, ci, i64, i64, vp]
+        L.bigdl_bf16_to_f16.argtypes = [vp, vp, i64, vp]
         L.bigdl_layer_norm.argtypes = [vp, vp, vp, vp, i64, ci, i64, cf, ci, vp]
         L.bigdl_act_mul.argtypes = [vp, vp, vp, i64, ci, i64, i64, i64, ci, ci, vp]
         L.bigdl_softmax_inplace.argtypes = [vp, i64, ci, cf, ci, vp]
@@ -477,6 +479,30 @@ def rms_norm(x, weight, eps, *, residual=None, res_out=None, offset=0.0, out=Non
     rc = lib().bigdl_rms_norm(_ptr(x2), _ptr(residual), _ptr(weight.contiguous()), _ptr(out), _ptr(res_out),
                               x2.shape[0], h, x2.stride(0), eps, offset, _out_type(x.dtype), _stream())
     _check(rc, "rms_norm")
+    return out
+
+
+def quant_rows_e4m3(x):
+    """x fp16 [M, K] -> (codes ``torch.float8_e4m3fn`` [M, K], scales fp32 [M, 1]) with ``x ~= codes * scales``: the
+    row-wise dynamic activation quantization of the opt-in fp8 prompt pass (``torch._scaled_mm`` takes both as they are)."""
+    _need_cuda(x)
+    if x.dim() != 2 or x.dtype != torch.float16 or x.stride(1) != 1:
+        raise ValueError("x must be a 2-D fp16 tensor with contiguous rows")
+    m, k = x.shape
+    q = torch.empty((m, k), dtype=torch.uint8, device=x.device)
+    scale = torch.empty((m, 1), dtype=torch.float32, device=x.device)
+    rc = lib().bigdl_quant_rows_e4m3(_ptr(x), _ptr(q), _ptr(scale), m, k, x.stride(0), q.stride(0), _stream())
+    _check(rc, "quant_rows_e4m3")
+    return q.view(torch.float8_e4m3fn), scale
+
+
+def bf16_to_f16(x):
+    """contiguous bf16 tensor -> fp16 (values beyond the fp16 range saturate)"""
+    _need_cuda(x)
+    if x.dtype != torch.bfloat16 or not x.is_contiguous() or x.numel() % 8:
+        return x.to(torch.float16)
+    out = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+    _check(lib().bigdl_bf16_to_f16(_ptr(x), _ptr(out), x.numel(), _stream()), "bf16_to_f16")
     return out
 
 

@@ -329,3 +329,28 @@ def test_engine_snapkv_compression_matches_module_path_selection():
     eng.compress_kv = None
     out_u = eng.generate(ids, max_new_tokens=8)
     assert out_c.shape == out_u.shape
+
+
+def test_fp8_prompt_pass_is_opt_in_and_close_to_fp16():
+    """``prefill_fp8``: prompt GEMMs above the fused-GEMM row limit on hipBLASLt's fp8 path (row-wise e4m3 for activations
+    and weights).  Off by default; when on, the logits stay within quantization noise of the fp16 prompt pass and decode
+    (which never uses it) continues from the cache it filled."""
+    import torch
+    from bigdl_amd import qtypes as Q
+    from bigdl_amd.models.decoder import DecoderConfig, build_random_decoder
+    cfg = DecoderConfig(vocab_size=512, hidden_size=512, intermediate_size=1408, num_layers=3, num_heads=8, num_kv_heads=4,
+                        head_dim=64, max_position=1024)
+    eng = build_random_decoder(cfg, Q.SYM_INT4, device="cuda", seed=5)
+    assert eng.prefill_fp8 is False
+    ids = torch.randint(3, 512, (1, 400)).cuda()
+    eng.ensure_cache(1, 512)
+    eng.cache.reset()
+    ref = eng.prefill(ids, last_only=False).float().clone()
+    eng.prefill_fp8 = True
+    eng.cache.reset()
+    out = eng.prefill(ids, last_only=False).float().clone()
+    rel = ((out - ref).abs().mean() / ref.abs().mean()).item()
+    assert 0 < rel < 0.15, rel
+    assert (out.argmax(-1) == ref.argmax(-1)).float().mean().item() > 0.8
+    lg, nxt = eng.decode(out[:, -1].argmax(-1).view(1, 1))
+    assert torch.isfinite(lg).all()

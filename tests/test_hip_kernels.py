@@ -841,3 +841,29 @@ def test_attn_prefill_reads_the_e5m2_cache_directly(d, hq, hkv, sq, lk):
     got = hip.attn_prefill(q, k8, v8, scale=d ** -0.5, causal=True, v_transposed=True, kv_e5m2=True)
     assert torch.isfinite(got.float()).all()
     assert (got.float() - want.float()).abs().max().item() < 2e-3
+
+
+@pytest.mark.parametrize("shape", [(5, 64), (300, 4096), (33, 11008)])
+def test_quant_rows_e4m3_matches_torch_conversion(hip, shape):
+    """row-wise activation quantization of the opt-in fp8 prompt pass: scale = max|x| / 448 per row, codes equal to
+    PyTorch's own fp32 -> float8_e4m3fn conversion of x / scale"""
+    torch.manual_seed(0)
+    m, k = shape
+    x = (torch.randn(m, k) * torch.rand(m, 1) * 3).half().cuda()
+    x[0, :8] = 0
+    q, sc = hip.quant_rows_e4m3(x)
+    want_sc = x.float().abs().amax(1, keepdim=True) / 448.0
+    torch.testing.assert_close(sc, want_sc, rtol=1e-6, atol=0)
+    want = (x.float() / sc).to(torch.float8_e4m3fn)
+    same = (q.view(torch.uint8) == want.view(torch.uint8)).float().mean().item()
+    assert same > 0.999, same                   # (a product that lands exactly between two codes may round the other way)
+    back = q.float() * sc
+    assert ((back - x.float()).abs().mean() / x.float().abs().mean()).item() < 0.04
+
+
+def test_bf16_to_f16(hip):
+    torch.manual_seed(0)
+    x = (torch.randn(37, 1000) * 100).to(torch.bfloat16).cuda()
+    x[0, 0], x[0, 1] = 1.0e6, -1.0e6
+    want = x.float().clamp(-65504, 65504).half()
+    assert torch.equal(hip.bf16_to_f16(x), want)
