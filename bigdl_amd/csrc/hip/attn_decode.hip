@@ -52,6 +52,7 @@ struct AttnArgs {
   int rot, interleaved, rope_max_pos;
   int defer_combine;     // 1: stop after writing the per-split partials (the consumer GEMV combines them)
   int nchunk, gchunk;    // query-head chunks per kv head and heads per chunk (1, Hq/Hkv unless Hq/Hkv > 32)
+  int ablate;            // measurement builds only (bigdl_attn_set_ablation): 1 = K / V loads without the products
 };
 
 constexpr float NEG_BIG = -1.0e30f;
@@ -85,14 +86,38 @@ __device__ __forceinline__ uint32_t q_i4(float x, float inv) {
   return (uint32_t)(int)fminf(fmaxf(rintf(x * inv) + 8.0f, 0.0f), 15.0f);
 }
 
+// e5m2 caches feed the matrix cores as they are: v_mfma_f32_16x16x32_bf8_fp8 takes the cache bytes (bf8 = OCP e5m2) as
+// its A operand, 8 bytes per lane and k-step, and an e4m3 B operand.  The fp32 query row and the probabilities are
+// split into two e4m3 terms each (value ~ hi + lo, about 7 significant bits; two products into the same accumulator),
+// after a per-row scale that puts the row maximum at 256: no byte -> fp16 expansion, and the K / V^T fragments stay in
+// registers as the bytes that were loaded (a quarter of the registers of the fp16 fragments).
+__device__ __forceinline__ float4v mfma_bf8_fp8(uint2v a, uint2v b, float4v c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf8_fp8(__builtin_bit_cast(long, a), __builtin_bit_cast(long, b), c, 0, 0, 0);
+}
+// 8 floats -> 8 e4m3 bytes (hi) and the e4m3 bytes of what the first rounding left over (lo)
+__device__ __forceinline__ void split_e4m3(const float (&x)[8], uint2v& hi, uint2v& lo) {
+#pragma unroll
+  for (int w = 0; w < 2; ++w) {
+    int h = __builtin_amdgcn_cvt_pk_fp8_f32(x[4 * w], x[4 * w + 1], 0, false);
+    h = __builtin_amdgcn_cvt_pk_fp8_f32(x[4 * w + 2], x[4 * w + 3], h, true);
+    const float r0 = x[4 * w] - __builtin_amdgcn_cvt_f32_fp8(h, 0), r1 = x[4 * w + 1] - __builtin_amdgcn_cvt_f32_fp8(h, 1);
+    const float r2 = x[4 * w + 2] - __builtin_amdgcn_cvt_f32_fp8(h, 2), r3 = x[4 * w + 3] - __builtin_amdgcn_cvt_f32_fp8(h, 3);
+    int l = __builtin_amdgcn_cvt_pk_fp8_f32(r0, r1, 0, false);
+    l = __builtin_amdgcn_cvt_pk_fp8_f32(r2, r3, l, true);
+    hi[w] = (uint32_t)h;
+    lo[w] = (uint32_t)l;
+  }
+}
+constexpr float P8_SCALE = 256.0f;     // probabilities are carried as 256 p (and the row sums with them)
+
 // D = head dim (multiple of 32), RT = number of 16-row tiles, KW = keys per wavefront per iteration.
 // KW = 64 (e5m2 caches, D % 128 == 0): every lane loads 16 bytes of a key row / of a V^T channel row instead of 8, i.e.
 // half as many load instructions and 64-byte instead of 32-byte contiguous pieces per 4 lanes.  With 8-byte pieces the
 // e5m2 path is bound by the number of memory instructions, not by bytes (batch 64, 1024 keys: 184 us per layer where
 // the fp16 cache needs 258 us for twice the bytes).  The MFMA k index <-> head channel assignment is free as long as
 // Q and K agree, so lane group g takes channels [16 (g + 4 c2), +16) of a row for the k-steps 2 c2 and 2 c2 + 1.
-template <int D, bool FP8, int RT, int KW, bool I4, int NWT = ATT_NW>
-__global__ __launch_bounds__(NWT * 64) void attn_decode_kernel(AttnArgs a) {
+template <int D, bool FP8, int RT, int KW, bool I4, int NWT = ATT_NW, int MINW = 1>
+__global__ __launch_bounds__(NWT * 64, MINW) void attn_decode_kernel(AttnArgs a) {
   constexpr int DC = D / 32;   // QK k-steps
   constexpr int DT = D / 16;   // O^T d-tiles
   constexpr int NW = NWT;
@@ -100,6 +125,9 @@ __global__ __launch_bounds__(NWT * 64) void attn_decode_kernel(AttnArgs a) {
   constexpr int NU = KW / 16;          // 16-key score tiles per wavefront
   constexpr int KL = KW / 4;           // consecutive keys per lane
   constexpr bool WIDE = KW == 64;
+  // e5m2 bytes straight into the fp8 matrix instruction (below): the many-keys-per-workgroup form.  The latency-bound
+  // batch-1 form keeps fp16 fragments: splitting q into two e4m3 terms in its prologue cost 0.2 us per launch there.
+  constexpr bool F8M = FP8 && WIDE;
   static_assert(!WIDE || (FP8 && D % 128 == 0), "16-byte fragments: e5m2 cache, rotate-half partner in k-step c + DC/2");
   static_assert(!I4 || (!FP8 && KW == 32), "int4 caches: 32 keys per wavefront");
   // first head channel of this lane's 8 values in k-step c.  int4: lane group g owns the D/4 contiguous channels
@@ -137,6 +165,28 @@ __global__ __launch_bounds__(NWT * 64) void attn_decode_kernel(AttnArgs a) {
   _Float16* vs = I4 ? a.vs + kbase / 32 : nullptr;
   const int half_rot = a.rot >> 1;
 
+  // e5m2 caches: one block's K / V^T fragments as the bytes that were loaded
+  struct RawK { uint2v w[F8M ? NU : 1][F8M ? DC : 1]; };
+  struct RawV { uint2v w[F8M ? DT : 1][F8M ? KL / 8 : 1]; };
+  auto load_raw = [&](const int kb, RawK& kr, RawV& vr) {
+    const int key0 = kb + KL * (rr >> 2) + (rr & 3);
+    if constexpr (WIDE) {
+#pragma unroll
+      for (int u = 0; u < NU; ++u)
+#pragma unroll
+        for (int c2 = 0; c2 < DC / 2; ++c2) {
+          const uint4v w = *(const uint4v*)((const uint8_t*)kc + (int64_t)(key0 + 4 * u) * D + 64 * c2 + 16 * g);
+          kr.w[u][2 * c2] = uint2v{w[0], w[1]};
+          kr.w[u][2 * c2 + 1] = uint2v{w[2], w[3]};
+        }
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        const uint4v w = *(const uint4v*)((const uint8_t*)vc + (int64_t)(16 * d + rr) * a.Lmax + kb + 16 * g);
+        vr.w[d][0] = uint2v{w[0], w[1]};
+        vr.w[d][1] = uint2v{w[2], w[3]};
+      }
+    }
+  };
   // ---- fused RoPE(k) + KV append for the new tokens that fall into this workgroup's key range ----
   if (a.rope != nullptr || a.rot == 0) {
     if (a.q_off == 0) {
@@ -219,6 +269,8 @@ __global__ __launch_bounds__(NWT * 64) void attn_decode_kernel(AttnArgs a) {
           }
           continue;
         }
+        if constexpr (F8M)
+          if (a.ablate & 2) continue;   // (measurement: without the V^T byte stores, 128 partly written lines per key)
         for (int d = lane; d < D; d += 64) {
           if constexpr (FP8) ((uint8_t*)vc)[(int64_t)d * a.Lmax + p] = f16_to_e5m2(vrow[d]);
           else ((_Float16*)vc)[(int64_t)d * a.Lmax + p] = vrow[d];
@@ -231,7 +283,9 @@ __global__ __launch_bounds__(NWT * 64) void attn_decode_kernel(AttnArgs a) {
   const float qscale = a.softcap > 0.0f ? a.scale : a.scale * 1.4426950408889634f;
 
   // Q^T fragments (B operand): lane (row, g) holds d = 32c + 8g + j
-  half8 qf[RT][DC];
+  half8 qf[F8M ? 1 : RT][F8M ? 1 : DC];
+  uint2v qh[F8M ? RT : 1][F8M ? DC : 1], ql[F8M ? RT : 1][F8M ? DC : 1];   // e5m2 caches: e4m3 hi / lo terms of 256 q / max|q|
+  float q_unscale[RT];                                                       // max|q| / 256 (folds the softmax scale)
   int lim[RT];  // last visible key position per row (causal within the new tokens)
   int lo_lim[RT];
   float slope[RT];   // ALiBi slope of the row's head, in log2 units (0 without ALiBi)
@@ -306,12 +360,32 @@ __global__ __launch_bounds__(NWT * 64) void attn_decode_kernel(AttnArgs a) {
         }
       }
     }
+    if constexpr (F8M) {
+      float am = 0.0f;
 #pragma unroll
-    for (int c = 0; c < DC; ++c) {
-      half8 v;
+      for (int c = 0; c < DC; ++c)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = (_Float16)(qv[c][j] * qscale);
-      qf[t][c] = v;
+        for (int j = 0; j < 8; ++j) am = fmaxf(am, fabsf(qv[c][j]));
+      am = fmaxf(am, __shfl_xor(am, 16));
+      am = fmaxf(am, __shfl_xor(am, 32));
+      const float f = am > 0.0f ? P8_SCALE / am : 0.0f;
+      q_unscale[t] = am * (qscale / P8_SCALE);
+#pragma unroll
+      for (int c = 0; c < DC; ++c) {
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = qv[c][j] * f;
+        split_e4m3(x, qh[t][c], ql[t][c]);
+      }
+    } else {
+      q_unscale[t] = 1.0f;
+#pragma unroll
+      for (int c = 0; c < DC; ++c) {
+        half8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (_Float16)(qv[c][j] * qscale);
+        qf[t][c] = v;
+      }
     }
   }
 
@@ -326,14 +400,13 @@ __global__ __launch_bounds__(NWT * 64) void attn_decode_kernel(AttnArgs a) {
   }
   const float4v zero4 = {0, 0, 0, 0};
 
-  for (int blk = blk0; blk < blk1; ++blk) {
-    const int kb = blk * ATT_KEYS + wave * KW;
-    if (kb >= kv_len) break;
+  // the KW keys from kb on: K / V^T fragments loaded (e5m2: by load_raw) and folded into the running softmax state
+  auto process = [&](const int kb, const RawK& kr, const RawV& vr) {
     // ---- S^T = K . Q^T for NU 16-key tiles ----
     // A-row i of tile u  <->  key kb + KL*(i>>2) + 4*u + (i&3), so that lane group g ends up with the KL consecutive
     // keys kb + KL*g .. of every query row
     const int key0 = kb + KL * (rr >> 2) + (rr & 3);
-    half8 kf[NU][DC];
+    half8 kf[F8M ? 1 : NU][F8M ? 1 : DC];
     if constexpr (I4) {
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
@@ -358,23 +431,14 @@ __global__ __launch_bounds__(NWT * 64) void attn_decode_kernel(AttnArgs a) {
 #pragma unroll
         for (int c = 0; c < DC; ++c) kf[u][c] = dq_i4(w[c], sc[SPL > 1 ? c / 4 : 0]);
       }
-    } else if constexpr (WIDE) {
-#pragma unroll
-      for (int u = 0; u < NU; ++u)
-#pragma unroll
-        for (int c2 = 0; c2 < DC / 2; ++c2) {
-          const uint4v w = *(const uint4v*)((const uint8_t*)kc + (int64_t)(key0 + 4 * u) * D + 64 * c2 + 16 * g);
-          kf[u][2 * c2] = dec_e5m2(w[0], w[1]);
-          kf[u][2 * c2 + 1] = dec_e5m2(w[2], w[3]);
-        }
-    } else {
+    } else if constexpr (!F8M) {
 #pragma unroll
       for (int u = 0; u < NU; ++u)
 #pragma unroll
         for (int c = 0; c < DC; ++c) kf[u][c] = load_kv8<FP8>(kc, (int64_t)(key0 + 4 * u) * D + 32 * c + 8 * g);
     }
     // V^T fragments: lane (d_local, g) holds keys kb + KL*g .. of channel 16*dt + d_local (KL/8 k-steps)
-    half8 vf[DT][KL / 8];
+    half8 vf[F8M ? 1 : DT][F8M ? 1 : KL / 8];
     half8 vsc[I4 ? DT / 2 : 1];     // int4: V scales of this lane's 8 keys, per 32-channel group
     if constexpr (I4) {
       const _Float16 one = (_Float16)1.0f;
@@ -397,18 +461,24 @@ __global__ __launch_bounds__(NWT * 64) void attn_decode_kernel(AttnArgs a) {
         vf[2 * m + 1][0] = hi.v;
       }
       (void)one;
-    } else if constexpr (WIDE) {
-#pragma unroll
-      for (int d = 0; d < DT; ++d) {
-        const uint4v w = *(const uint4v*)((const uint8_t*)vc + (int64_t)(16 * d + rr) * a.Lmax + kb + 16 * g);
-        vf[d][0] = dec_e5m2(w[0], w[1]);
-        vf[d][1] = dec_e5m2(w[2], w[3]);
-      }
-    } else {
+    } else if constexpr (!F8M) {
 #pragma unroll
       for (int d = 0; d < DT; ++d) vf[d][0] = load_kv8<FP8>(vc, (int64_t)(16 * d + rr) * a.Lmax + kb + 8 * g);
     }
 
+    if constexpr (F8M) {
+      if (a.ablate & 1) {
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+          for (int c = 0; c < DC; ++c) asm volatile("" ::"v"(kr.w[u][c].x), "v"(kr.w[u][c].y));
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+          for (int h = 0; h < KL / 8; ++h) asm volatile("" ::"v"(vr.w[d][h].x), "v"(vr.w[d][h].y));
+        return;
+      }
+    }
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
       // lane (row rr, g): tile u, register q  <->  key kb + KL*g + 4*u + q
@@ -416,10 +486,18 @@ __global__ __launch_bounds__(NWT * 64) void attn_decode_kernel(AttnArgs a) {
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
         float4v su = zero4;
+        if constexpr (F8M) {
 #pragma unroll
-        for (int c = 0; c < DC; ++c) su = mfma16(kf[u][c], qf[t][c], su);
+          for (int c = 0; c < DC; ++c) {
+            su = mfma_bf8_fp8(kr.w[u][c], qh[t][c], su);
+            su = mfma_bf8_fp8(kr.w[u][c], ql[t][c], su);
+          }
+        } else {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) sv[4 * u + q] = su[q];
+          for (int c = 0; c < DC; ++c) su = mfma16(kf[u][c], qf[t][c], su);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sv[4 * u + q] = F8M ? su[q] * q_unscale[t] : su[q];
       }
       if (a.softcap > 0.0f) {
 #pragma unroll
@@ -453,19 +531,41 @@ __global__ __launch_bounds__(NWT * 64) void attn_decode_kernel(AttnArgs a) {
       m_run[t] = m_new;
       H8 pf[KL / 8];
       float ps = 0.0f;
+      if constexpr (F8M) {
+        // masked entries: sv = NEG_BIG; when the whole row is still masked m_new = NEG_BIG too and exp2(0) would be 1,
+        // so masked entries are forced to 0 explicitly
 #pragma unroll
-      for (int q = 0; q < KL; q += 2) {
-        // masked entries: sv = NEG_BIG; when the whole row is still masked m_new = NEG_BIG too and
-        // exp2(0) would be 1, so masked entries are forced to 0 explicitly
-        const float p0 = sv[q] <= NEG_BIG ? 0.0f : exp2f(sv[q] - m_new);
-        const float p1 = sv[q + 1] <= NEG_BIG ? 0.0f : exp2f(sv[q + 1] - m_new);
-        ps += p0 + p1;
-        pf[q >> 3].h2[(q & 7) >> 1] = half2v{(_Float16)p0, (_Float16)p1};
+        for (int q = 0; q < KL; ++q) {
+          sv[q] = sv[q] <= NEG_BIG ? 0.0f : P8_SCALE * exp2f(sv[q] - m_new);
+          ps += sv[q];
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < KL; q += 2) {
+          const float p0 = sv[q] <= NEG_BIG ? 0.0f : exp2f(sv[q] - m_new);
+          const float p1 = sv[q + 1] <= NEG_BIG ? 0.0f : exp2f(sv[q + 1] - m_new);
+          ps += p0 + p1;
+          pf[q >> 3].h2[(q & 7) >> 1] = half2v{(_Float16)p0, (_Float16)p1};
+        }
       }
       l_run[t] = l_run[t] * alpha + ps;
       if (__any(alpha != 1.0f)) {
 #pragma unroll
         for (int d = 0; d < DT; ++d) o[t][d] *= alpha;
+      }
+      if constexpr (F8M) {
+#pragma unroll
+        for (int h = 0; h < KL / 8; ++h) {
+          uint2v ph, pl;
+          const float(&p8)[8] = *(const float(*)[8])&sv[8 * h];
+          split_e4m3(p8, ph, pl);
+#pragma unroll
+          for (int d = 0; d < DT; ++d) {
+            o[t][d] = mfma_bf8_fp8(vr.w[d][h], ph, o[t][d]);
+            o[t][d] = mfma_bf8_fp8(vr.w[d][h], pl, o[t][d]);
+          }
+        }
+        continue;
       }
       if constexpr (I4) {
         // probabilities in the key order of the V^T fragments, times the V scale of each 32-channel group
@@ -491,6 +591,27 @@ __global__ __launch_bounds__(NWT * 64) void attn_decode_kernel(AttnArgs a) {
       for (int h = 0; h < KL / 8; ++h)
 #pragma unroll
         for (int d = 0; d < DT; ++d) o[t][d] = mfma16(vf[d][h], pf[h].v, o[t][d]);
+    }
+  };
+
+  if constexpr (F8M) {
+    // Requesting block i + 1 before block i is worked on (a second fragment set, 224 registers) and requesting the
+    // first block ahead of the append prologue were both measured: no gain at batch 64 (the loop already streams at the
+    // rate this access pattern reaches, 5.3 TB/s) and a slower batch-1 launch (vector memory returns in order, so the
+    // prologue's small dependent loads queue behind 16 KiB of K / V per wavefront).
+    for (int blk = blk0; blk < blk1; ++blk) {
+      const int kb = blk * ATT_KEYS + wave * KW;
+      if (kb >= kv_len) break;
+      RawK kr;
+      RawV vr;
+      load_raw(kb, kr, vr);
+      process(kb, kr, vr);
+    }
+  } else {
+    for (int blk = blk0; blk < blk1; ++blk) {
+      const int kb = blk * ATT_KEYS + wave * KW;
+      if (kb >= kv_len) break;
+      process(kb, RawK{}, RawV{});
     }
   }
 
@@ -582,7 +703,7 @@ __global__ __launch_bounds__(NWT * 64) void attn_decode_kernel(AttnArgs a) {
   }
 }
 
-template <int D, bool FP8, int RT, int KW, bool I4 = false, int NWT = ATT_NW>
+template <int D, bool FP8, int RT, int KW, bool I4 = false, int NWT = ATT_NW, int MINW = 1>
 static int launch_one(const AttnArgs& a, size_t, hipStream_t st) {
   const dim3 grid(a.splits, a.Hkv * a.nchunk, a.B), block(NWT * 64);
   const int rows = a.gchunk * a.q_cnt;
@@ -590,12 +711,12 @@ static int launch_one(const AttnArgs& a, size_t, hipStream_t st) {
   // more than 64 KiB of dynamic LDS has to be requested explicitly (once per kernel)
   static bool attr = false;
   if (!attr && smem > 65536) {
-    if (hipFuncSetAttribute((const void*)attn_decode_kernel<D, FP8, RT, KW, I4, NWT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void*)attn_decode_kernel<D, FP8, RT, KW, I4, NWT, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess)
       return -5;
     attr = true;
   }
-  hipLaunchKernelGGL((attn_decode_kernel<D, FP8, RT, KW, I4, NWT>), grid, block, smem, st, a);
+  hipLaunchKernelGGL((attn_decode_kernel<D, FP8, RT, KW, I4, NWT, MINW>), grid, block, smem, st, a);
   return HIP_CHECK_LAUNCH();
 }
 
@@ -623,7 +744,12 @@ static int launch_rt(const AttnArgs& a, hipStream_t st) {
       // registers: 186 either way), a second register set that prefetches the next block (256 registers, 8.83).
       static const char* nw4 = getenv("BIGDL_ATTN_NW4");           // "0" / "1": override for measurements
       const bool small = nw4 ? atoi(nw4) == 1 : (a.splits == 1 && (int64_t)a.B * a.Hkv * a.nchunk >= 512);
-      if (wide && small) return launch_one<D, FP8, 1, 64, false, 4>(a, smem, st);
+      if constexpr (D == 128) {
+        static const char* occ = getenv("BIGDL_ATTN_OCC");         // wavefronts per SIMD the register budget allows
+        if (wide && small && occ && atoi(occ) == 3) return launch_one<D, FP8, 1, 64, false, 4, 3>(a, smem, st);
+        if (wide && small && occ && atoi(occ) == 4) return launch_one<D, FP8, 1, 64, false, 4, 4>(a, smem, st);
+      }
+      if (wide && small) return launch_one<D, FP8, 1, 64, false, 4, (D <= 128 ? 2 : 1)>(a, smem, st);
       if (wide) return launch_one<D, FP8, 1, 64>(a, smem, st);
     }
     return launch_one<D, FP8, 1, 32>(a, smem, st);
@@ -708,6 +834,9 @@ __global__ __launch_bounds__(64) void rope_append_kernel(RopeAppendArgs a) {
 
 using namespace bigdl;
 
+static int g_attn_ablate = 0;
+extern "C" void bigdl_attn_set_ablation(int v) { g_attn_ablate = v; }
+
 // q tokens [q_off, q_off+q_cnt) of the q_total tokens appended this step; (Hq/Hkv)*q_cnt <= 32.
 // rope != null: q is rotated in registers, k is rotated and k/v appended to the caches by this launch
 // (requires q_off == 0 for the append; rot/2 % 32 == 0 unless interleaved).
@@ -735,7 +864,7 @@ extern "C" int bigdl_attn_decode(void* qkv, void* kc, void* vc, void* out, float
   a.rot = rope ? rot : (append ? 0 : -1); a.interleaved = interleaved;
   a.B = B; a.Hq = Hq; a.Hkv = Hkv; a.ld = ld; a.Lmax = Lmax; a.splits = splits; a.window = window;
   a.q_total = q_total; a.q_off = q_off; a.q_cnt = q_cnt; a.defer_combine = defer_combine;
-  a.nchunk = nchunk; a.gchunk = gchunk;
+  a.nchunk = nchunk; a.gchunk = gchunk; a.ablate = g_attn_ablate;
   a.ks = (_Float16*)k_scale; a.vs = (_Float16*)v_scale;
   if (k_scale != nullptr || v_scale != nullptr) {
     // int4 caches: the kernel appends itself (quantization needs the whole rotated key), full rotary only

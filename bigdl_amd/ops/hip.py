@@ -8,6 +8,7 @@ the call.  There is no silent fallback: on a GPU box a missing library is an err
 from __future__ import annotations
 
 import ctypes
+import os
 from pathlib import Path
 
 import torch
@@ -15,7 +16,8 @@ import torch
 from .. import qtypes as Q
 
 _LIB = None
-_LIB_PATH = Path(__file__).resolve().parent.parent / "lib" / "libbigdl_hip.so"
+# BIGDL_HIP_LIB: another build of the library (A/B measurements of a kernel change inside one process tree)
+_LIB_PATH = Path(os.environ.get("BIGDL_HIP_LIB") or Path(__file__).resolve().parent.parent / "lib" / "libbigdl_hip.so")
 
 OUT_F16, OUT_BF16, OUT_F32 = 0, 1, 2
 ACT = {None: 0, "none": 0, "silu": 1, "swish": 1, "gelu": 2, "gelu_tanh": 3, "gelu_pytorch_tanh": 3,
