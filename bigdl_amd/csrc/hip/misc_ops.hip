@@ -293,25 +293,43 @@ __global__ __launch_bounds__(256) void rep_penalty_kernel(void* scores, const in
   }
 }
 
-// argmax over the last dim: one workgroup per row, 16-byte loads; ties -> lowest index
+// argmax over the last dim; ties -> lowest index.  A row is split over gridDim.y workgroups (a single workgroup reads a
+// 32000-entry fp32 row at the rate of one CU: 6 us); each writes its (value, index) candidate, the last one to arrive
+// (agent-scope ticket) picks the winner.  The same launch can add `inc_alpha * inc_src[i]` to `inc_dst[i]` for
+// i < inc_n: the decode graph advances its per-sequence cache lengths here instead of in a launch of its own.
+struct ArgmaxArgs {
+  const void* x; int64_t* out; float* part_v; int* part_i; int* tickets;
+  int* inc_dst; const int* inc_src; int inc_n, inc_alpha;
+  int V; int64_t ld;
+};
+
 template <int DT>
-__global__ __launch_bounds__(1024) void argmax_kernel(const void* x, int64_t* out, int V, int64_t ld) {
+__global__ __launch_bounds__(1024) void argmax_kernel(ArgmaxArgs a) {
   __shared__ float sv[16];
   __shared__ int si[16];
+  __shared__ int s_last;
   const int64_t row = blockIdx.x;
+  const int nch = gridDim.y, ch = blockIdx.y;
+  if (row == 0 && ch == 0 && a.inc_dst != nullptr) {
+    for (int i = threadIdx.x; i < a.inc_n; i += 1024) a.inc_dst[i] += a.inc_alpha * a.inc_src[i];
+  }
   float best = -INFINITY;
   int bi = 0x7fffffff;
-  const int nvec = V / 8;
-  for (int i = threadIdx.x; i < nvec; i += 1024) {
+  const int nvec = a.V / 8;
+  const int per = (nvec + nch - 1) / nch;
+  const int v0 = ch * per, v1 = min(nvec, v0 + per);
+  for (int i = v0 + threadIdx.x; i < v1; i += 1024) {
     float v[8];
-    load8<DT>(x, row * ld + (int64_t)i * 8, v);
+    load8<DT>(a.x, row * a.ld + (int64_t)i * 8, v);
 #pragma unroll
     for (int j = 0; j < 8; ++j)
       if (v[j] > best) { best = v[j]; bi = i * 8 + j; }
   }
-  for (int c = nvec * 8 + threadIdx.x; c < V; c += 1024) {
-    const float v = Elem<DT>::ld(x, row * ld + c);
-    if (v > best) { best = v; bi = c; }
+  if (ch == nch - 1) {
+    for (int c = nvec * 8 + threadIdx.x; c < a.V; c += 1024) {
+      const float v = Elem<DT>::ld(a.x, row * a.ld + c);
+      if (v > best) { best = v; bi = c; }
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -325,7 +343,26 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const void* x, int64_t* ou
   if (threadIdx.x == 0) {
     for (int w = 1; w < 16; ++w)
       if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
-    out[row] = bi == 0x7fffffff ? 0 : bi;
+    if (nch == 1) {
+      a.out[row] = bi == 0x7fffffff ? 0 : bi;
+    } else {
+      // candidates and ticket as device-scope atomics: written through, read by the last arriver past its own L1
+      __hip_atomic_store(&a.part_v[row * nch + ch], best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&a.part_i[row * nch + ch], bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int ticket = __hip_atomic_fetch_add(&a.tickets[row], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (ticket == nch - 1) {
+        float bv = -INFINITY;
+        int bj = 0x7fffffff;
+        for (int c = 0; c < nch; ++c) {
+          const float v = __hip_atomic_load(&a.part_v[row * nch + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const int j = __hip_atomic_load(&a.part_i[row * nch + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (v > bv || (v == bv && j < bj)) { bv = v; bj = j; }
+        }
+        a.out[row] = bj == 0x7fffffff ? 0 : bj;
+        __hip_atomic_store(&a.tickets[row], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+      }
+    }
   }
 }
 
@@ -503,8 +540,14 @@ extern "C" int bigdl_repetition_penalty(void* scores, const int64_t* ids, int B,
   return HIP_CHECK_LAUNCH();
 }
 
-extern "C" int bigdl_argmax(const void* x, int64_t* out, int64_t rows, int V, int64_t ld, int dtype, hipStream_t st) {
-  if (rows <= 0 || V <= 0 || (ld & 7) || !aligned16(x)) return -1;
-  DISPATCH_DT(dtype, hipLaunchKernelGGL((argmax_kernel<DT>), dim3(rows), dim3(1024), 0, st, x, out, V, ld))
+// ws: rows * nch floats + rows * nch ints + rows ints (tickets, zero before the first launch) when nch > 1
+extern "C" int bigdl_argmax(const void* x, int64_t* out, int64_t rows, int V, int64_t ld, int dtype, int nch, void* ws,
+                            int* inc_dst, const int* inc_src, int inc_n, int inc_alpha, hipStream_t st) {
+  if (rows <= 0 || V <= 0 || (ld & 7) || !aligned16(x) || nch < 1 || (nch > 1 && ws == nullptr)) return -1;
+  ArgmaxArgs a;
+  a.x = x; a.out = out; a.V = V; a.ld = ld;
+  a.part_v = (float*)ws; a.part_i = (int*)ws + rows * nch; a.tickets = (int*)ws + 2 * rows * nch;
+  a.inc_dst = inc_dst; a.inc_src = inc_src; a.inc_n = inc_dst ? inc_n : 0; a.inc_alpha = inc_alpha;
+  DISPATCH_DT(dtype, hipLaunchKernelGGL((argmax_kernel<DT>), dim3(rows, nch), dim3(1024), 0, st, a))
   return HIP_CHECK_LAUNCH();
 }

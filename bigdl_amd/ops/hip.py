@@ -57,7 +57,7 @@ def lib():
         L.bigdl_to_e5m2.argtypes = [vp, vp, i64, ci, i64, i64, ci, vp]
         L.bigdl_from_e5m2.argtypes = [vp, vp, i64, ci, i64, i64, ci, vp]
         L.bigdl_repetition_penalty.argtypes = [vp, vp, ci, ci, ci, cf, ci, vp]
-        L.bigdl_argmax.argtypes = [vp, vp, i64, ci, i64, ci, vp]
+        L.bigdl_argmax.argtypes = [vp, vp, i64, ci, i64, ci, ci, vp, vp, vp, ci, ci, vp]
         L.bigdl_dequant_t16.argtypes = [vp, vp, ci, ci, i64, ci, ci, ci, ci, vp]
         L.bigdl_dequant_rows.argtypes = [vp, vp, vp, i64, i64, ci, ci, i64, ci, vp]
         L.bigdl_gemv_lowbit_moe.argtypes = [vp, vp, vp, vp, vp, vp, vp, cf, cf, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp]
@@ -691,15 +691,39 @@ def repetition_penalty_inplace(scores, input_ids, penalty):
     return scores
 
 
-def argmax(x, out=None):
+_ARGMAX_WS = {}
+
+
+def argmax(x, out=None, inc=None):
+    """Row-wise argmax (ties: lowest index).  ``inc=(dst, src, alpha)``: the same launch also does
+    ``dst += alpha * src`` on two int32 vectors (the decode graph advances its cache lengths this way)."""
     _need_cuda(x, out)
     v = x.shape[-1]
     x2 = x.reshape(-1, v)
     if x2.stride(1) != 1:
         x2 = x2.contiguous()
+    rows = x2.shape[0]
     if out is None:
-        out = torch.empty(x2.shape[0], dtype=torch.int64, device=x.device)
-    rc = lib().bigdl_argmax(_ptr(x2), _ptr(out), x2.shape[0], v, x2.stride(0), _out_type(x.dtype), _stream())
+        out = torch.empty(rows, dtype=torch.int64, device=x.device)
+    # long rows of a few-row call are split over several workgroups (candidates + tickets in a per-device workspace)
+    nch = 8 if rows <= 64 and v >= 8192 else 1
+    ws = None
+    if nch > 1:
+        key = (x.device.index, torch.cuda.current_stream(x.device).cuda_stream)
+        ws = _ARGMAX_WS.get(key)
+        if ws is None or ws.numel() < rows * (2 * nch + 1):
+            ws = _ARGMAX_WS[key] = torch.zeros(64 * (2 * nch + 1), dtype=torch.int32, device=x.device)
+    inc_dst = inc_src = None
+    inc_n = alpha = 0
+    if inc is not None:
+        inc_dst, inc_src, alpha = inc
+        _need_cuda(inc_dst, inc_src)
+        if inc_dst.dtype != torch.int32 or inc_src.dtype != torch.int32 or inc_dst.numel() != inc_src.numel() \
+                or not (inc_dst.is_contiguous() and inc_src.is_contiguous()):
+            raise ValueError("inc: two contiguous int32 vectors of one length")
+        inc_n = inc_dst.numel()
+    rc = lib().bigdl_argmax(_ptr(x2), _ptr(out), rows, v, x2.stride(0), _out_type(x.dtype), nch, _ptr(ws),
+                            _ptr(inc_dst), _ptr(inc_src), inc_n, int(alpha), _stream())
     _check(rc, "argmax")
     return out.reshape(x.shape[:-1])
 

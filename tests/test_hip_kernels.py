@@ -867,3 +867,26 @@ def test_bf16_to_f16(hip):
     x[0, 0], x[0, 1] = 1.0e6, -1.0e6
     want = x.float().clamp(-65504, 65504).half()
     assert torch.equal(hip.bf16_to_f16(x), want)
+
+
+@pytest.mark.parametrize("rows,v,dtype", [(1, 32000, torch.float32), (5, 128256, torch.float32), (3, 32000, torch.float16),
+                                          (70, 9000, torch.float32), (2, 1003, torch.float32)])
+def test_argmax_split_rows_and_fused_increment(hip, rows, v, dtype):
+    """Long rows of few-row calls are reduced by 8 workgroups and a last-arriver; ties resolve to the lowest index; the
+    launch can also advance two int32 vectors (cache lengths of the decode graph)."""
+    torch.manual_seed(3)
+    x = torch.randn(rows, (v + 7) // 8 * 8, device="cuda").to(dtype)[:, :v]
+    x[0, v // 3] = 50.0
+    x[0, v - 2] = 50.0                      # a tie: the first one wins
+    x[rows - 1, v - 1] = 60.0               # winner in the scalar tail / last chunk
+    out = torch.empty(rows, dtype=torch.int64, device="cuda")
+    dst = torch.arange(6, dtype=torch.int32, device="cuda")
+    src = torch.tensor([1, 0, 1, 1, 0, 1], dtype=torch.int32, device="cuda")
+    for _ in range(3):                      # tickets must be left ready for the next launch
+        hip.argmax(x, out=out, inc=(dst, src, 2))
+    ref = x.float().cpu().argmax(-1)
+    assert out[0].item() == v // 3 or rows - 1 == 0
+    assert torch.equal(out.cpu()[1:rows - 1], ref[1:rows - 1])
+    assert out[rows - 1].item() == v - 1
+    assert dst.cpu().tolist() == [0 + 6, 1, 2 + 6, 3 + 6, 4, 5 + 6]
+    assert torch.equal(hip.argmax(x).cpu(), out.cpu())
