@@ -540,13 +540,14 @@ extern "C" int bigdl_repetition_penalty(void* scores, const int64_t* ids, int B,
   return HIP_CHECK_LAUNCH();
 }
 
-// ws: rows * nch floats + rows * nch ints + rows ints (tickets, zero before the first launch) when nch > 1
+// ws (nch > 1, rows <= 64): 64 tickets (zero before the first launch; every launch leaves them zero), then 64 * nch
+// candidate values and 64 * nch candidate indices: the tickets never move when the row count changes between calls
 extern "C" int bigdl_argmax(const void* x, int64_t* out, int64_t rows, int V, int64_t ld, int dtype, int nch, void* ws,
                             int* inc_dst, const int* inc_src, int inc_n, int inc_alpha, hipStream_t st) {
-  if (rows <= 0 || V <= 0 || (ld & 7) || !aligned16(x) || nch < 1 || (nch > 1 && ws == nullptr)) return -1;
+  if (rows <= 0 || V <= 0 || (ld & 7) || !aligned16(x) || nch < 1 || (nch > 1 && (ws == nullptr || rows > 64))) return -1;
   ArgmaxArgs a;
   a.x = x; a.out = out; a.V = V; a.ld = ld;
-  a.part_v = (float*)ws; a.part_i = (int*)ws + rows * nch; a.tickets = (int*)ws + 2 * rows * nch;
+  a.tickets = (int*)ws; a.part_v = (float*)ws + 64; a.part_i = (int*)ws + 64 + 64 * nch;
   a.inc_dst = inc_dst; a.inc_src = inc_src; a.inc_n = inc_dst ? inc_n : 0; a.inc_alpha = inc_alpha;
   DISPATCH_DT(dtype, hipLaunchKernelGGL((argmax_kernel<DT>), dim3(rows, nch), dim3(1024), 0, st, a))
   return HIP_CHECK_LAUNCH();

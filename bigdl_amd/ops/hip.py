@@ -711,7 +711,7 @@ def argmax(x, out=None, inc=None):
     if nch > 1:
         key = (x.device.index, torch.cuda.current_stream(x.device).cuda_stream)
         ws = _ARGMAX_WS.get(key)
-        if ws is None or ws.numel() < rows * (2 * nch + 1):
+        if ws is None:
             ws = _ARGMAX_WS[key] = torch.zeros(64 * (2 * nch + 1), dtype=torch.int32, device=x.device)
     inc_dst = inc_src = None
     inc_n = alpha = 0
