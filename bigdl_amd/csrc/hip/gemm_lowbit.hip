@@ -126,6 +126,8 @@ static int launch_reduce(const GemmArgs& a, hipStream_t stream) {
   return HIP_CHECK_LAUNCH();
 }
 
+int gemm_launch_reduce(const GemmArgs& a, hipStream_t stream) { return launch_reduce(a, stream); }   // gemm_big.hip
+
 // counts[e] rows of expert e, rows sorted by expert -> table of m-blocks of at most bm rows; unused entries get
 // expert -1.  One wavefront: E is at most a few hundred.
 __global__ void moe_block_table_kernel(const int64_t* counts, int n_experts, int bm, int max_blocks, int* blk_expert,

@@ -63,6 +63,9 @@ def lib():
         L.bigdl_gemv_lowbit_moe.argtypes = [vp, vp, vp, vp, vp, vp, vp, cf, cf, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp]
         L.bigdl_gemm_lowbit.argtypes = [vp, vp, vp, vp, vp, vp, i64, ci, ci, ci, ci, ci, ci, ci, ci, vp]
         L.bigdl_gemm_lowbit_splitk.argtypes = [ci, ci, ci]
+        L.bigdl_gemm_lowbit_big.argtypes = [vp, vp, vp, vp, vp, vp, i64, ci, ci, ci, ci, ci, ci, ci, ci, vp]
+        L.bigdl_gemm_lowbit_big_splitk.argtypes = [ci, ci, ci]
+        L.bigdl_gemm_lowbit_big_supported.argtypes = [ci, ci]
         L.bigdl_gemm_lowbit_ex.argtypes = [vp] * 8 + [cf, cf, vp, vp, vp, i64] + [ci] * 8 + [vp]
         L.bigdl_gemm_lowbit_ex_splitk.argtypes = [ci, ci, ci, ci]
         L.bigdl_gemm_lowbit_bm.argtypes = [ci]
@@ -281,6 +284,47 @@ def gemm_lowbit(x, w, qtype, out_features, in_features, *, bias=None, residual=N
     rc = L.bigdl_gemm_lowbit(_ptr(x), _ptr(w), _ptr(out), _ptr(bias), _ptr(residual), _ptr(ws), ws_n, m, out_features, k,
                              x.stride(0), out.stride(0), qtype, ACT[act], _out_type(out_dtype), _stream())
     _check(rc, "gemm_lowbit")
+    return out
+
+
+def gemm_lowbit_big_supported(qtype, in_features) -> bool:
+    return bool(lib().bigdl_gemm_lowbit_big_supported(int(qtype), int(in_features)))
+
+
+def gemm_lowbit_big(x, w, qtype, out_features, in_features, *, bias=None, residual=None, act=None, out=None,
+                    out_dtype=None):
+    """``y = act(x @ dequant(w)^T + bias) [+ residual]`` on the prompt-sized MFMA GEMM (128 x 256 tiles, x through
+    ``global_load_lds``): x [M, K] fp16, meant for M >= 256; 4-bit formats, K % 128 == 0.  w: T16 device buffer."""
+    _need_cuda(x, w, bias, residual, out)
+    if x.dim() != 2 or x.dtype != torch.float16 or x.stride(1) != 1:
+        raise ValueError("x must be a 2-D fp16 tensor with contiguous rows")
+    m, k = x.shape
+    if k != in_features:
+        raise ValueError(f"x has {k} features, weight expects {in_features}")
+    if not gemm_lowbit_big_supported(qtype, k):
+        raise ValueError(f"qtype {qtype} / K = {k} has no prompt-sized fused GEMM kernel")
+    from .host import device_nbytes
+    if w.numel() * w.element_size() != device_nbytes(qtype, out_features, in_features):
+        raise ValueError("weight buffer size does not match the tiled layout")
+    out_dtype = out_dtype or (out.dtype if out is not None else torch.float16)
+    if out is None:
+        out = torch.empty((m, out_features), dtype=out_dtype, device=x.device)
+    if out.shape != (m, out_features) or out.stride(1) != 1 or out.dtype != out_dtype:
+        raise ValueError("bad out tensor")
+    if bias is not None and (bias.dtype != torch.float16 or bias.numel() != out_features or not bias.is_contiguous()):
+        raise ValueError("bias must be contiguous fp16 [out_features]")
+    if residual is not None and (residual.shape != out.shape or residual.dtype != out.dtype
+                                 or residual.stride() != out.stride()):
+        raise ValueError("residual must match out")
+    L = lib()
+    sk = L.bigdl_gemm_lowbit_big_splitk(m, out_features, k)
+    ws, ws_n = None, 0
+    if sk > 1:
+        ws = _gemm_workspace(x.device, sk * m * out_features)
+        ws_n = ws.numel()
+    rc = L.bigdl_gemm_lowbit_big(_ptr(x), _ptr(w), _ptr(out), _ptr(bias), _ptr(residual), _ptr(ws), ws_n, m, out_features, k,
+                                 x.stride(0), out.stride(0), qtype, ACT[act], _out_type(out_dtype), _stream())
+    _check(rc, "gemm_lowbit_big")
     return out
 
 
