@@ -30,8 +30,9 @@ static BigPlan big_plan(int M, int N, int K) {
   static const int forced_nt = getenv("BIGDL_GEMM_BIG_NT") ? atoi(getenv("BIGDL_GEMM_BIG_NT")) : 0;
   BigPlan best = {4, 1, KT};
   double best_cost = 1e30;
+  // (256-column tiles, nt = 4, need more registers than there are with the three-slot weight ring: only when forced)
   for (int nt = 3; nt <= 4; ++nt) {
-    if (forced_nt && nt != forced_nt) continue;
+    if (forced_nt ? nt != forced_nt : nt != 3) continue;
     const int blocks = mblocks * ((N + 64 * nt - 1) / (64 * nt));
     for (int sk = 1; sk <= 8 && (sk == 1 || KT / sk >= 8); ++sk) {
       const int per = (KT + sk - 1) / sk, rsk = (KT + per - 1) / per;

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256, 2) void gemm_t16_big_kernel(GemmArgs a) {
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[j][n] = float4v{0, 0, 0, 0};
 
-  Tile<QT> tt[2][NT];
+  Tile<QT> tt[3][NT];                     // ring: the tile in use, and the next two on their way
   auto fetch_b = [&](Tile<QT> (&t)[NT], int kt) {
 #pragma unroll
     for (int n = 0; n < NT; ++n) load_tile<QT>(t[n], pl, tbase[n] + kt, lane);
@@ -138,27 +138,36 @@ __global__ __launch_bounds__(256, 2) void gemm_t16_big_kernel(GemmArgs a) {
     }
   };
 
-  // prologue: first x tile and first weight tiles; every later tile is requested one iteration ahead of its use and
-  // has that iteration's MFMA work (2048 issue cycles) to land.  The barrier ending an iteration waits for everything
-  // in flight: the next x tile must be complete in LDS for all wavefronts anyway.
+  // Pipeline.  Iteration k requests x tile k + 1 (LDS stage (k + 1) & 1) and weight tiles k + 2 (ring slot (k + 2) % 3),
+  // then works on tile k.  Vector memory completes in issue order, so waiting until only the NB youngest operations
+  // (the weight loads just issued) are outstanding retires x tile k + 1 and weight tiles k + 1; the weight tiles get two
+  // iterations to arrive (they come from HBM, cold, exactly once per 128-row block).  The waits are
+  // __builtin_amdgcn_s_waitcnt, which the compiler's own wait insertion sees: a __syncthreads() here would drain
+  // everything (vmcnt(0)) because an LDS-DMA is in flight.
+  constexpr int NB = NT * (has_min<QT>() ? 3 : 2);       // per tile: codes, scales (+ mins); 4-bit formats only
+  static_assert(NB < 16, "vmcnt immediate below assumes a 4-bit count");
+  constexpr int WAIT_NB = NB | (0x7 << 4) | (0xF << 8);      // vmcnt(NB), expcnt / lgkmcnt untouched
   const int klast = max(kt1 - 1, kt0);
   stage_a(kt0, 0);
   fetch_b(tt[0], kt0);
-  __syncthreads();
-  for (int kt = kt0; kt < kt1; kt += 2) {
+  fetch_b(tt[1], min(kt0 + 1, klast));
+  __builtin_amdgcn_s_waitcnt(WAIT_NB);
+  __builtin_amdgcn_s_barrier();
+  for (int kt = kt0; kt < kt1; kt += 6) {
 #pragma unroll
-    for (int d = 0; d < 2; ++d) {
-      const int k = kt + d;                 // block-uniform
+    for (int d = 0; d < 6; ++d) {
+      const int k = kt + d;                 // block-uniform; (k - kt0) % 6 == d
       if (k >= kt1) break;
-      if constexpr (!(BIG_ABL & 2)) stage_a(min(k + 1, klast), d ^ 1);
-      if constexpr (!(BIG_ABL & 1)) fetch_b(tt[d ^ 1], min(k + 1, klast));
-      // without this the scheduler sinks the requests to the end of the iteration (nothing uses their results before
-      // the barrier) and every k-tile waits out a full memory round trip
+      if constexpr (!(BIG_ABL & 2)) stage_a(min(k + 1, klast), (d + 1) & 1);
+      if constexpr (!(BIG_ABL & 1)) fetch_b(tt[(d + 2) % 3], min(k + 2, klast));
+      // (without this the scheduler sinks the requests to the end of the iteration: nothing uses them before the barrier)
       __builtin_amdgcn_sched_barrier(0);
-      compute(tt[(BIG_ABL & 1) ? 0 : d], d);
-      if constexpr (!(BIG_ABL & 8)) __syncthreads();
+      compute(tt[(BIG_ABL & 1) ? 0 : d % 3], d & 1);
+      __builtin_amdgcn_s_waitcnt(WAIT_NB);
+      if constexpr (!(BIG_ABL & 8)) __builtin_amdgcn_s_barrier();
     }
   }
+  __builtin_amdgcn_s_waitcnt(0 | (0x7 << 4) | (0xF << 8));     // the clamped look-ahead loads of the last iterations
 
   // epilogue (same contract as gemm_t16_kernel's dense mode).  The weight tile is the MFMA's A operand, so a lane holds
   // 4 consecutive output columns (n = 16 tile + 4 g + q) of one row (m = 16 j + r): 8-byte fp16 / 16-byte fp32 stores

@@ -354,7 +354,7 @@ class NativeDecoder:
         self._static = {}
         # ``BIGDL_PREFILL_FUSED=1``: prompt GEMMs above GEMM_MAX_ROWS rows on the fused prompt-sized kernel instead of
         # dequantize + hipBLASLt.  No fp16 scratch copy of a weight (0.18 GB less peak memory on Llama-2-7B) and no library
-        # GEMM, but the first token of a 1024-token prompt takes 21.3 instead of 18.9 ms: off by default.
+        # GEMM, but the first token of a 1024-token prompt takes 20.6 instead of 19.3 ms: off by default.
         self.prefill_fused = os.environ.get("BIGDL_PREFILL_FUSED", "0") == "1"
         # opt-in fp8 prompt pass (``BIGDL_PREFILL_FP8=1``): see _linear_dense
         self.prefill_fp8 = os.environ.get("BIGDL_PREFILL_FP8") == "1"
