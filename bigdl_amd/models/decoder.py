@@ -488,6 +488,19 @@ class NativeDecoder:
             return hip.layer_norm(x, w, b, self.cfg.rms_eps)
         return hip.rms_norm(x, w, self.cfg.rms_eps, offset=self.cfg.norm_offset, residual=residual, res_out=res_out)
 
+    def _add_norm(self, h, add, w, b=None):
+        """(norm(h + add), h + add): the residual add rides in the RMSNorm launch (the prompt pass otherwise spends one
+        elementwise launch per add: 64 of them, 0.37 ms, on a 1024-token Llama-2-7B prompt).  ``add`` None: (norm(h), h)."""
+        from ..ops import hip
+        if add is None:
+            return self._norm(h, w, b), h
+        if self.cfg.norm == "layer" or add.dtype != h.dtype or not (h.is_contiguous() and add.is_contiguous()):
+            h = h + add
+            return self._norm(h, w, b), h
+        hn = torch.empty_like(h)
+        x = hip.rms_norm(add, w, self.cfg.rms_eps, offset=self.cfg.norm_offset, residual=h, res_out=hn)
+        return x, hn
+
     def _embed_extras(self, h, pos):
         """learned absolute positions and the embedding LayerNorm; h [rows, hidden], pos [rows] (device, int64)"""
         from ..ops import hip
@@ -585,8 +598,10 @@ class NativeDecoder:
             top = mp.amax(dim=(0, 2))                                              # per sequence
             assert bool((top == top[0]).all()), "sequences of one batch must end at the same rotary position"
             mrope_delta = int(top[0]) + 1 - s
+        pend = None                          # MLP output of the previous layer, added to h by the next norm launch
         for li, lw in enumerate(self.layers):
-            x = self._norm(h, lw.input_norm, lw.input_norm_b)
+            x, h = self._add_norm(h, pend, lw.input_norm, lw.input_norm_b)
+            pend = None
             qkv = self._linear_dense(x, lw.qkv) if lw.mla is None else self._mla_qkv_dense(x, lw.mla)
             if nd:
                 # decode rows first: the idle slot's row appends a throw-away key at position 0 of the cache row
@@ -648,15 +663,16 @@ class NativeDecoder:
                 x2 = x if lw.post_norm is None else self._norm(h, lw.post_norm, lw.post_norm_b)
                 h = h + o + self._mlp_dense(x2, lw)
                 continue
-            h = h + o
-            x = self._norm(h, lw.pre_ffn_norm if lw.pre_ffn_norm is not None else lw.post_norm, lw.post_norm_b)
+            x, h = self._add_norm(h, o, lw.pre_ffn_norm if lw.pre_ffn_norm is not None else lw.post_norm, lw.post_norm_b)
             if lw.moe is not None:
                 m = lw.moe.forward_dense(x, self)
             else:
                 m = self._mlp_dense(x, lw)
             if lw.post_ffn_out_norm is not None:
                 m = self._norm(m, lw.post_ffn_out_norm)
-            h = h + m
+            pend = m
+        if pend is not None:
+            h = h + pend
         if slot is not None:
             cache.past_len[slot] += s
             cache.slot_len[slot] += s
