@@ -211,12 +211,25 @@ class FP4Params(torch.nn.Parameter):
 # ---------------------------------------------------------------------------
 # functional kernels (device dispatch lives here, nowhere else)
 # ---------------------------------------------------------------------------
+_TRAIN_DENSE_CACHE = os.environ.get("BIGDL_TRAIN_DENSE_CACHE") == "1"
+
+
 def dequant_weight(weight: FP4Params, dtype=torch.float16) -> torch.Tensor:
     """Dense [out, in] view of a quantized parameter on its own device (reference op ``xe_linear.dequant``)."""
     n, k = weight._shape
     if weight.data.device.type == "cuda":
         from ..ops import hip
         if weight.qlayout == "t16":
+            if _TRAIN_DENSE_CACHE:
+                # opt-in (BIGDL_TRAIN_DENSE_CACHE=1): keep the dense copy next to the low-bit one.  A QLoRA step
+                # dequantizes every frozen weight twice (forward and backward: 9 % of the step's kernel time on
+                # Llama-2-7B); 2 bytes per weight is affordable on a 288 GB device when speed matters more than footprint.
+                d = weight.data
+                key = (dtype, d.data_ptr(), d._version)
+                hit = getattr(weight, "_dense_cache", None)
+                if hit is None or hit[0] != key:
+                    hit = weight._dense_cache = (key, hip.dequant_t16(d, weight.qtype, n, k, dtype=dtype))
+                return hit[1]
             return hip.dequant_t16(weight.data, weight.qtype, n, k, dtype=dtype)
         raw = weight.data.view(torch.uint8) if weight.data.dtype != torch.uint8 else weight.data
         if weight.qtype in (Q.IQ2_XXS, Q.IQ2_XS, Q.IQ1_S, Q.IQ1_M):

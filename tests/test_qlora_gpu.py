@@ -72,3 +72,36 @@ def test_relora_merge_requantizes_on_gpu():
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
         after = pm(input_ids=ids).logits.float()
     assert ((after - before).abs().mean() / before.abs().mean()).item() < 0.03
+
+
+@pytest.mark.parametrize("p", [0.0, 0.25])
+def test_fused_lora_node_matches_module_by_module(monkeypatch, p):
+    """LoraLowBitLinear's one-node GPU path (FusedLoraLowBit) against the module-by-module form: output, activation
+    gradient and adapter gradients (dropout: same random stream, so the same mask)."""
+    from bigdl_amd.transformers.qlora import LoraConfig, get_peft_model, LoraLowBitLinear, FusedLoraLowBit
+    pm = get_peft_model(_qmodel("nf4"), LoraConfig(r=8, lora_alpha=16, target_modules=["q_proj"], lora_dropout=p,
+                                                   training_mode="qlora"))
+    lin = pm.base_model.model.layers[0].self_attn.q_proj
+    assert isinstance(lin, LoraLowBitLinear)
+    torch.nn.init.normal_(lin.lora_B["default"].weight, std=0.05)            # (zero-initialised: delta would vanish)
+    lin.train()
+    x0 = torch.randn(3, 40, 256, device="cuda", dtype=torch.bfloat16)
+    g = torch.randn(3, 40, lin.out_features, device="cuda", dtype=torch.bfloat16)
+    res = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("BIGDL_FUSED_LORA", fused)
+        x = x0.clone().requires_grad_(True)
+        for prm in (lin.lora_A["default"].weight, lin.lora_B["default"].weight):
+            prm.grad = None
+        torch.manual_seed(123)
+        assert lin._fusable(x) == (fused == "1")
+        y = lin(x)
+        y.backward(g)
+        res[fused] = (y.detach().float(), x.grad.float(), lin.lora_A["default"].weight.grad.float().clone(),
+                      lin.lora_B["default"].weight.grad.float().clone())
+    if p > 0.0:
+        # the two forms draw their dropout masks from different kernels: compare statistics only
+        assert abs(res["1"][0].std().item() / res["0"][0].std().item() - 1.0) < 0.05
+        return
+    for a, b in zip(res["1"], res["0"]):
+        torch.testing.assert_close(a, b, rtol=4e-2, atol=4e-2 * b.abs().max().item())
