@@ -5,6 +5,7 @@
 // (plain / importance-weighted / per-channel RTN), dequantize, block geometry queries,
 // host<->device re-layout, quantized matmul, MoE token bucketing.
 #include "qformats.h"
+#include <immintrin.h>
 #include <algorithm>
 #include <cfloat>
 #include <cstdlib>
@@ -121,12 +122,106 @@ int bigdl_relayout_to_host(int qtype, const void* src, void* dst, int64_t N, int
 }
 
 // y[M, N] = x[M, K] . dequant(w)[N, K]^T   (fp32 activations, host block layout)
-// Each thread dequantizes one weight row into a scratch line and reuses it for all M
-// activation rows, so the weight is read exactly once per call.
+// Each thread owns weight rows; a row is read exactly once per call and reused for all M activation rows.  AVX2 + FMA
+// (the library is built for x86-64-v3):
+//  * q4_0 / q4_1 / q8_0 (sym_int4, asym_int4, sym_int8: what CPU inference normally loads) never materialise the row:
+//    a block's 32 codes are widened to fp32 in registers, multiplied with the matching 32 activations of up to 4 rows
+//    at a time, and the block's partial sum is scaled by d (and the activations' block sum by m / -8 d) once per block;
+//  * every other format dequantizes the row into a scratch line (its own block decoder) and takes 8-wide dot products.
+}  // extern "C"
+
+static inline float hsum256(__m256 v) {
+  __m128 lo = _mm_add_ps(_mm256_castps256_ps128(v), _mm256_extractf128_ps(v, 1));
+  lo = _mm_add_ps(lo, _mm_movehl_ps(lo, lo));
+  lo = _mm_add_ss(lo, _mm_shuffle_ps(lo, lo, 1));
+  return _mm_cvtss_f32(lo);
+}
+
+static inline float dot_f32(const float* a, const float* b, int64_t K) {
+  __m256 s0 = _mm256_setzero_ps(), s1 = s0, s2 = s0, s3 = s0;
+  int64_t k = 0;
+  for (; k + 32 <= K; k += 32) {
+    s0 = _mm256_fmadd_ps(_mm256_loadu_ps(a + k), _mm256_loadu_ps(b + k), s0);
+    s1 = _mm256_fmadd_ps(_mm256_loadu_ps(a + k + 8), _mm256_loadu_ps(b + k + 8), s1);
+    s2 = _mm256_fmadd_ps(_mm256_loadu_ps(a + k + 16), _mm256_loadu_ps(b + k + 16), s2);
+    s3 = _mm256_fmadd_ps(_mm256_loadu_ps(a + k + 24), _mm256_loadu_ps(b + k + 24), s3);
+  }
+  for (; k + 8 <= K; k += 8) s0 = _mm256_fmadd_ps(_mm256_loadu_ps(a + k), _mm256_loadu_ps(b + k), s0);
+  float r = hsum256(_mm256_add_ps(_mm256_add_ps(s0, s1), _mm256_add_ps(s2, s3)));
+  for (; k < K; ++k) r += a[k] * b[k];
+  return r;
+}
+
+// the 32 codes of one block as four fp32 vectors: elements 0-7, 8-15, 16-23, 24-31
+static inline void widen_nibbles(const uint8_t* qs, __m256 (&c)[4]) {
+  const __m128i b = _mm_loadu_si128((const __m128i*)qs);
+  const __m128i lo = _mm_and_si128(b, _mm_set1_epi8(0x0F));                       // elements 0-15
+  const __m128i hi = _mm_and_si128(_mm_srli_epi16(b, 4), _mm_set1_epi8(0x0F));    // elements 16-31
+  c[0] = _mm256_cvtepi32_ps(_mm256_cvtepu8_epi32(lo));
+  c[1] = _mm256_cvtepi32_ps(_mm256_cvtepu8_epi32(_mm_srli_si128(lo, 8)));
+  c[2] = _mm256_cvtepi32_ps(_mm256_cvtepu8_epi32(hi));
+  c[3] = _mm256_cvtepi32_ps(_mm256_cvtepu8_epi32(_mm_srli_si128(hi, 8)));
+}
+static inline void widen_bytes(const int8_t* qs, __m256 (&c)[4]) {
+  for (int i = 0; i < 4; ++i) c[i] = _mm256_cvtepi32_ps(_mm256_cvtepi8_epi32(_mm_loadl_epi64((const __m128i*)(qs + 8 * i))));
+}
+
+// KIND 0: q4_0 ((q - 8) d), 1: q4_1 (q d + m), 2: q8_0 (q d).  R activation rows at once.
+template <int KIND, int R>
+static inline void block_row_dot(const uint8_t* wrow, const float* x, int64_t ldx, int64_t K, float* out, int64_t ldo) {
+  constexpr int BS = KIND == 0 ? sizeof(block_q4_0) : (KIND == 1 ? sizeof(block_q4_1) : sizeof(block_q8_0));
+  float acc[R];
+  for (int r = 0; r < R; ++r) acc[r] = 0.0f;
+  for (int64_t b = 0; b < K / QK; ++b) {
+    const uint8_t* blk = wrow + b * BS;
+    __m256 c[4];
+    float d, m = 0.0f;
+    if constexpr (KIND == 0) {
+      d = fp16_to_fp32(((const block_q4_0*)blk)->d);
+      widen_nibbles(((const block_q4_0*)blk)->qs, c);
+      m = -8.0f * d;
+    } else if constexpr (KIND == 1) {
+      d = fp16_to_fp32(((const block_q4_1*)blk)->d);
+      m = fp16_to_fp32(((const block_q4_1*)blk)->m);
+      widen_nibbles(((const block_q4_1*)blk)->qs, c);
+    } else {
+      d = fp16_to_fp32(((const block_q8_0*)blk)->d);
+      widen_bytes(((const block_q8_0*)blk)->qs, c);
+    }
+    for (int r = 0; r < R; ++r) {
+      const float* xr = x + r * ldx + b * QK;
+      const __m256 x0 = _mm256_loadu_ps(xr), x1 = _mm256_loadu_ps(xr + 8), x2 = _mm256_loadu_ps(xr + 16), x3 = _mm256_loadu_ps(xr + 24);
+      const __m256 p = _mm256_fmadd_ps(x0, c[0], _mm256_fmadd_ps(x1, c[1], _mm256_fmadd_ps(x2, c[2], _mm256_mul_ps(x3, c[3]))));
+      float v = d * hsum256(p);
+      if constexpr (KIND != 2) v += m * hsum256(_mm256_add_ps(_mm256_add_ps(x0, x1), _mm256_add_ps(x2, x3)));
+      acc[r] += v;
+    }
+  }
+  for (int r = 0; r < R; ++r) out[r * ldo] = acc[r];
+}
+
+template <int KIND>
+static void matmul_blocks(const float* x, const uint8_t* w, int64_t M, int64_t N, int64_t K, float* y) {
+  constexpr int BS = KIND == 0 ? sizeof(block_q4_0) : (KIND == 1 ? sizeof(block_q4_1) : sizeof(block_q8_0));
+  const int64_t row_bytes = K / QK * BS;
+#pragma omp parallel for schedule(static)
+  for (int64_t n = 0; n < N; ++n) {
+    const uint8_t* wrow = w + n * row_bytes;
+    int64_t m = 0;
+    for (; m + 4 <= M; m += 4) block_row_dot<KIND, 4>(wrow, x + m * K, K, K, y + m * N + n, N);
+    for (; m < M; ++m) block_row_dot<KIND, 1>(wrow, x + m * K, K, K, y + m * N + n, N);
+  }
+}
+
+extern "C" {
+
 int bigdl_matmul_q(const float* x, const void* w, int qtype, int64_t M, int64_t N, int64_t K, float* y) {
   const int qk = qk_size(qtype), ts = type_size(qtype);
   if (qk <= 1 || K % qk != 0) return -1;
   init_tables();
+  if (qtype == Q_SYM_INT4) { matmul_blocks<0>(x, (const uint8_t*)w, M, N, K, y); return 0; }
+  if (qtype == Q_ASYM_INT4) { matmul_blocks<1>(x, (const uint8_t*)w, M, N, K, y); return 0; }
+  if (qtype == Q_SYM_INT8) { matmul_blocks<2>(x, (const uint8_t*)w, M, N, K, y); return 0; }
   const int64_t row_bytes = K / qk * ts;
 #pragma omp parallel
   {
@@ -134,19 +229,7 @@ int bigdl_matmul_q(const float* x, const void* w, int qtype, int64_t M, int64_t 
 #pragma omp for schedule(static)
     for (int64_t n = 0; n < N; ++n) {
       dequantize_row(qtype, (const uint8_t*)w + n * row_bytes, line.data(), K);
-      for (int64_t m = 0; m < M; ++m) {
-        const float* xr = x + m * K;
-        float acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
-        int64_t k = 0;
-        for (; k + 4 <= K; k += 4) {
-          acc0 += xr[k] * line[k];
-          acc1 += xr[k + 1] * line[k + 1];
-          acc2 += xr[k + 2] * line[k + 2];
-          acc3 += xr[k + 3] * line[k + 3];
-        }
-        for (; k < K; ++k) acc0 += xr[k] * line[k];
-        y[m * N + n] = (acc0 + acc1) + (acc2 + acc3);
-      }
+      for (int64_t m = 0; m < M; ++m) y[m * N + n] = dot_f32(x + m * K, line.data(), K);
     }
   }
   return 0;
