@@ -52,7 +52,9 @@ def main():
                           "in_len": args.in_len, "out_len": args.out_len, "wall_s": round(dt, 3),
                           "gen_tokens_per_s": round(gen / dt, 1), "requests_per_s": round(n_req / dt, 2),
                           "mean_tpot_ms": round(1e3 * sum(tpot) / len(tpot), 3),
-                          "peak_mem_gb": round(torch.cuda.max_memory_reserved() / 2 ** 30, 2)}), flush=True)
+                          "peak_mem_gb": round(torch.cuda.max_memory_reserved() / 2 ** 30, 2), "steps": cb.steps,
+                          "mixed_steps": cb.mixed_steps, "packed_prompts": cb.packed_prompts,
+                          "packed_mixed_steps": getattr(cb, "packed_mixed_steps", 0)}), flush=True)
 
 
 if __name__ == "__main__":

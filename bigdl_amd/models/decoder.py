@@ -462,6 +462,18 @@ class NativeDecoder:
             # prompt-sized rows: the 128 x 192 / 256-tile fused kernel (weights expanded in registers; no fp16 copy of
             # the weight is written or read, no library GEMM)
             return hip.gemm_lowbit_big(x.contiguous(), lin.w, lin.qtype, lin.n, lin.k, bias=lin.bias)
+        m = x.shape[0]
+        if lin.fused and m >= 2048 and m % 256 and x.dim() == 2 and not self.prefill_fp8:
+            # hipBLASLt falls off a cliff at row counts just above a multiple of 256 (4160 rows: 433 us against 312 at 4096
+            # on the qkv shape, 576 against 279 on down_proj): packed prompts + decode rows are exactly that.  The whole
+            # 256-row blocks go to the library, the remaining rows (at most 255) to the fused low-bit kernels.
+            m0 = m // 256 * 256
+            y = torch.empty(m, lin.n, dtype=x.dtype, device=x.device)
+            torch.mm(x[:m0], lin.dense().t(), out=y[:m0])
+            if lin.bias is not None:
+                y[:m0] += lin.bias
+            y[m0:] = self._linear_dense(x[m0:], lin)
+            return y
         if self.prefill_fp8 and x.dtype == torch.float16 and lin.k % 16 == 0 and lin.n % 16 == 0 and lin.k <= 16384:
             # opt-in: activations quantized per row to e4m3, weights per output row, hipBLASLt's fp8 GEMM (twice the fp16
             # MFMA rate on gfx950); lower precision than the fp16 product, never the default
@@ -702,8 +714,10 @@ class NativeDecoder:
         logits = self._linear_dense(x, self.lm_head).float().view(b, -1, cfg.vocab_size)
         return self._finish_logits(logits)
 
+    packed_with_decode = True            # prefill_packed(with_decode=True) exists (serving/continuous.py asks)
+
     @torch.no_grad()
-    def prefill_packed(self, prompts, slots):
+    def prefill_packed(self, prompts, slots, with_decode: bool = False):
         """Several whole prompts (lists of token ids) into empty cache slots in ONE pass: norms, projections and the MLP
         run over the concatenated rows (one read of the weights for all prompts, what short chat prompts need: a
         32-token prompt alone costs 6 ms on a 7B model, mostly weight traffic), attention and the cache append run per
@@ -713,6 +727,13 @@ class NativeDecoder:
         from ..ops import hip
         cfg, cache = self.cfg, self.cache
         assert cache.slot_len is not None and len(prompts) == len(slots) > 0
+        nd, st = 0, None
+        if with_decode:
+            # one decode row per cache slot rides along, as in prefill(with_decode=True): returns
+            # (prompt logits [n, V], decode logits [slots, V], next tokens [slots]) and advances every active slot
+            assert max(cache.slot_len) + 1 <= cache.capacity, "KV cache capacity exceeded"
+            nd = cache.batch
+            st = self._get_graph(nd, 1, True)[1]
         lens = [len(p) for p in prompts]
         assert all(cache.slot_len[sl] == 0 and not cache.active_host[sl] for sl in slots), "packed prompts go to empty slots"
         assert max(lens) <= cache.capacity, "KV cache capacity exceeded"
@@ -724,6 +745,10 @@ class NativeDecoder:
         if cfg.embed_scale != 1.0:
             h = h * cfg.embed_scale
         pos = torch.cat([torch.arange(n, device=self.device) for n in lens])
+        if nd:
+            hd = F.embedding(st["tokens"].view(-1), self.embed).to(torch.float16)
+            h = torch.cat([h, hd * cfg.embed_scale if cfg.embed_scale != 1.0 else hd])
+            pos = torch.cat([pos, cache.past_len.to(torch.int64)])
         h = self._embed_extras(h, pos)
         hq, hkv, d = cfg.num_heads, cfg.num_kv_heads, cfg.head_dim
         rot = cfg.rot_dim or d
@@ -731,6 +756,11 @@ class NativeDecoder:
             x = self._norm(h, lw.input_norm, lw.input_norm_b)
             qkv_all = self._linear_dense(x, lw.qkv) if lw.mla is None else self._mla_qkv_dense(x, lw.mla)
             parts = []
+            attn_d = None
+            if nd:
+                # decode rows first: the rows of the slots being filled append a throw-away key at position 0 of cache rows
+                # that the prompts' keys are written to right after
+                attn_d = self._decode_attention(qkv_all[offs[-1]:], li, lw, st, nd)
             for j, slot in enumerate(slots):
                 s = lens[j]
                 qkv = qkv_all[offs[j]:offs[j + 1]].view(1, s, (hq + 2 * hkv) * d)
@@ -748,6 +778,8 @@ class NativeDecoder:
                 k = qkv[..., hq * d: (hq + hkv) * d].view(1, s, hkv, d).transpose(1, 2)
                 vt = scratch[..., :s] if scratch is not None else vc[:, :, :, :s]
                 parts.append(self._sdpa(q, k, vt, 0, lw.window).reshape(s, hq * d))
+            if attn_d is not None:
+                parts.append(attn_d)
             o = self._tp_reduce(self._linear_dense(torch.cat(parts), lw.o))
             if lw.post_attn_out_norm is not None:
                 o = self._norm(o, lw.post_attn_out_norm)
@@ -764,9 +796,17 @@ class NativeDecoder:
         for j, slot in enumerate(slots):
             cache.past_len[slot] += lens[j]
             cache.slot_len[slot] += lens[j]
-        last = torch.tensor([o - 1 for o in offs[1:]], device=self.device)
+        last = torch.tensor([o - 1 for o in offs[1:]] + list(range(offs[-1], offs[-1] + nd)), device=self.device)
         x = self._norm(h[last], self.final_norm, self.final_norm_b)
-        return self._finish_logits(self._linear_dense(x, self.lm_head).float())
+        logits = self._finish_logits(self._linear_dense(x, self.lm_head).float())
+        if not nd:
+            return logits
+        n = len(slots)
+        st["logits"].copy_(logits[n:])
+        hip.argmax(st["logits"], out=st["tokens"].view(-1))                      # chained like the graph's step
+        cache.past_len.add_(cache.active)
+        cache.slot_len = [a + b for a, b in zip(cache.slot_len, cache.active_host)]
+        return logits[:n], st["logits"], st["tokens"].view(-1)
 
     def _mla_qkv_dense(self, x, m: MLAWeights):
         """prompt rows: normed hidden [rows, hidden] -> qkv [rows, 3 * heads * head_dim] (un-rotated)"""

@@ -188,3 +188,29 @@ def test_failed_step_releases_requests_and_slots():
     except ValueError:
         return
     raise AssertionError("empty prompt was accepted")
+
+
+class _FakeEnginePackedMixed(_FakeEngine):
+    packed_with_decode = True
+    packed_mixed = 0
+
+    def prefill_packed(self, prompts, slots, with_decode=False):
+        first = super().prefill_packed(prompts, slots)
+        if not with_decode:
+            return first
+        self.packed_mixed += 1
+        return (first,) + self.decode(None, 1, chain=True)
+
+
+def test_packed_prompts_and_decode_rows_share_one_pass():
+    """Running sequences + two or more waiting prompts: one pass admits the prompts and advances the running ones;
+    tokens are those of separate passes."""
+    prompts = [[i + 1, 2 * i + 3, 5] + [7] * i for i in range(11)]
+    eng = _FakeEnginePackedMixed()
+    cb = ContinuousBatcher(eng, max_num_seqs=6, max_seq_len=64, max_prefill_per_step=4, max_prefill_tokens=32)
+    cb.packed_mixed = True                            # (BIGDL_SERVING_PACKED_MIXED=1)
+    reqs = [cb.submit(SeqRequest(str(i), list(p), max_new_tokens=2 + i % 5)) for i, p in enumerate(prompts)]
+    cb.run_until_done()
+    assert eng.packed_mixed > 0 and cb.packed_mixed_steps == eng.packed_mixed
+    assert [r.output_ids for r in reqs] == [_expected(p, 2 + i % 5) for i, p in enumerate(prompts)]
+    assert not cb.has_work() and sorted(cb.free_slots) == list(range(6))

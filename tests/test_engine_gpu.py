@@ -354,3 +354,44 @@ def test_fp8_prompt_pass_is_opt_in_and_close_to_fp16():
     assert (out.argmax(-1) == ref.argmax(-1)).float().mean().item() > 0.8
     lg, nxt = eng.decode(out[:, -1].argmax(-1).view(1, 1))
     assert torch.isfinite(lg).all()
+
+
+@pytest.mark.parametrize("fp8", [False, True])
+def test_packed_prompts_with_decode_rows_match_separate_passes(fp8):
+    """prefill_packed(with_decode=True) = one decode step of the running slots + the packed prompt pass of two new ones."""
+    from bigdl_amd.models import decoder as D
+    cfg = D.DecoderConfig(vocab_size=512, hidden_size=256, intermediate_size=512, num_layers=3, num_heads=4, num_kv_heads=2,
+                          head_dim=64, max_position=1024)
+    eng = D.build_random_decoder(cfg, device="cuda", seed=3)
+    g = torch.Generator().manual_seed(0)
+    p0, p1 = (torch.randint(3, 512, (1, n), generator=g).cuda() for n in (40, 19))
+    new = [torch.randint(3, 512, (n,), generator=g).tolist() for n in (120, 33)]
+    res = {}
+    for mixed in (False, True):
+        cache = eng.ensure_cache(5, 512, fp8=fp8)
+        cache.reset()
+        cache.enable_slots()
+        tokens = eng._get_graph(5, 1, True)[1]["tokens"]
+        for slot, p in ((0, p0), (2, p1)):
+            tokens[slot, 0] = eng.prefill(p, slot=slot)[0, -1].argmax()
+            cache.set_active(slot, True)
+        eng.decode(None, 1, chain=True)
+        if mixed:
+            first, lg, nxt = eng.prefill_packed(new, [4, 1], with_decode=True)
+        else:
+            lg, nxt = eng.decode(None, 1, chain=True)
+            lg, nxt = lg.clone(), nxt.clone()
+            first = eng.prefill_packed(new, [4, 1])
+        res[mixed] = (first.clone(), lg[[0, 2]].clone(), cache.past_len.clone(), list(cache.slot_len),
+                      cache.k[1][[0, 2], :, :45].float().clone(), cache.k[1][4, :, :120].float().clone())
+    a, b = res[False], res[True]
+    tol = 0.06 if fp8 else 1e-2
+    for i in (0, 1):
+        rel = ((a[i] - b[i]).abs().mean() / a[i].abs().mean()).item()
+        assert rel < tol, (i, rel)
+    assert torch.equal(a[2], b[2]) and a[3] == b[3] == [42, 33, 21, 0, 120]
+    for i in (4, 5):
+        if fp8:
+            assert (a[i] != b[i]).float().mean().item() < 0.03
+        else:
+            torch.testing.assert_close(a[i], b[i], rtol=2e-2, atol=2e-2)
