@@ -463,16 +463,20 @@ class NativeDecoder:
             # the weight is written or read, no library GEMM)
             return hip.gemm_lowbit_big(x.contiguous(), lin.w, lin.qtype, lin.n, lin.k, bias=lin.bias)
         m = x.shape[0]
-        if lin.fused and m >= 2048 and m % 256 and x.dim() == 2 and not self.prefill_fp8:
-            # hipBLASLt falls off a cliff at row counts just above a multiple of 256 (4160 rows: 433 us against 312 at 4096
-            # on the qkv shape, 576 against 279 on down_proj): packed prompts + decode rows are exactly that.  The whole
-            # 256-row blocks go to the library, the remaining rows (at most 255) to the fused low-bit kernels.
-            m0 = m // 256 * 256
+        if lin.fused and m > 4096 and x.dim() == 2 and not self.prefill_fp8:
+            # hipBLASLt falls off a cliff right above 4096 rows (4100 - 4352 rows: 402 - 439 us against 272 at 4096 on the
+            # qkv shape, 573 against 237 on down_proj) while 4096-row products run at its best rate: longer passes (packed
+            # prompts + decode rows, long prompt chunks) go through it 4096 rows at a time, the rest as its own product
+            # (at most 256 rows: the fused low-bit kernels).
             y = torch.empty(m, lin.n, dtype=x.dtype, device=x.device)
-            torch.mm(x[:m0], lin.dense().t(), out=y[:m0])
+            w = lin.dense()
+            m0 = m // 4096 * 4096
+            for r in range(0, m0, 4096):
+                torch.mm(x[r:r + 4096], w.t(), out=y[r:r + 4096])
             if lin.bias is not None:
                 y[:m0] += lin.bias
-            y[m0:] = self._linear_dense(x[m0:], lin)
+            if m0 < m:
+                y[m0:] = self._linear_dense(x[m0:], lin)
             return y
         if self.prefill_fp8 and x.dtype == torch.float16 and lin.k % 16 == 0 and lin.n % 16 == 0 and lin.k <= 16384:
             # opt-in: activations quantized per row to e4m3, weights per output row, hipBLASLt's fp8 GEMM (twice the fp16
