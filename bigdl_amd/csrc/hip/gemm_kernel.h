@@ -314,8 +314,10 @@ static int gemm_launch_mt(const GemmArgs& a, int mblocks, hipStream_t st) {
   return HIP_CHECK_LAUNCH();
 }
 
-// bm: rows per block (64 / 128); bn: columns per block (128).  64-column blocks and 32-row blocks were measured too
-// (more workgroups streaming weights at few rows): slower or equal on every Llama-2-7B projection shape.
+// bm: rows per block (16 / 32 / 64 / 128); bn: columns per block (128).  64-column blocks were measured too (more
+// workgroups streaming weights at few rows): slower or equal on every Llama-2-7B projection shape.  The row block
+// follows the row count: every workgroup re-reads the x rows of its K range, and with 64-row blocks that x tile (16 KiB
+// per k-tile) is twice the weight tile (8 KiB) whatever the real row count is.
 template <int QT>
 static int gemm_launch_qt(const GemmArgs& a, int bm, int bn, int mblocks, hipStream_t st) {
   if (bn != 128) return -4;
@@ -324,6 +326,8 @@ static int gemm_launch_qt(const GemmArgs& a, int bm, int bn, int mblocks, hipStr
     if (bm == 128) return gemm_launch_mt<QT, 8, 2, true>(a, mblocks, st);
     return -4;
   }
+  if (bm == 16) return gemm_launch_mt<QT, 1, 2>(a, mblocks, st);
+  if (bm == 32) return gemm_launch_mt<QT, 2, 2>(a, mblocks, st);
   if (bm == 64) return gemm_launch_mt<QT, 4, 2>(a, mblocks, st);
   if (bm == 128) return gemm_launch_mt<QT, 8, 2>(a, mblocks, st);
   return -4;

@@ -197,9 +197,13 @@ extern "C" int bigdl_gemm_lowbit_splitk(int M, int N, int K) {
 
 extern "C" int bigdl_gemm_lowbit_bm(int M) {
   static const int forced = getenv("BIGDL_GEMM_BM") ? atoi(getenv("BIGDL_GEMM_BM")) : 0;
-  if (forced == 64 || forced == 128) return forced;
+  if (forced == 16 || forced == 32 || forced == 64 || forced == 128) return forced;
   // 64-row blocks keep two or more wavefronts per SIMD (170 VGPRs): measured 10-40 % faster than 128-row blocks at
-  // every M between 64 and 1024 on the Llama-2-7B projection shapes
+  // every M between 64 and 1024 on the Llama-2-7B projection shapes; 16 / 32-row blocks for row counts that fit them
+  // (a quarter / half of the x tile traffic of a 64-row block)
+  static const int small = getenv("BIGDL_GEMM_SMALL_BM") ? atoi(getenv("BIGDL_GEMM_SMALL_BM")) : 1;
+  if (small && M <= 16) return 16;
+  if (small && M <= 32) return 32;
   return 64;
 }
 
@@ -242,7 +246,7 @@ extern "C" int bigdl_gemm_lowbit_ex(const void* x, const void* w, const void* w2
   a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldo = ldo; a.act = act; a.out_type = out_type;
   a.gamma = (const _Float16*)gamma; a.gamma_offset = gamma_offset; a.eps = eps; a.row_ssq = gamma != nullptr ? row_ssq : nullptr;
   a.ssq_out = ssq_out; a.w2 = w2; a.bias2 = bias2;
-  const int bm = bigdl_gemm_lowbit_bm(M);
+  const int bm = gamma != nullptr ? (bigdl_gemm_lowbit_bm(M) < 64 ? 64 : bigdl_gemm_lowbit_bm(M)) : bigdl_gemm_lowbit_bm(M);
   const int bn = pick_bn(M);
   const int mblocks = (M + bm - 1) / bm;
   plan(mblocks * (w2 != nullptr ? 2 : 1), bn, N, K, &a.splitk, &a.kt_per_split);

@@ -30,7 +30,7 @@ TORCH_LINEAR_THRESHOLD = int(os.getenv("BIGDL_LLM_LINEAR_THRESHOLD", "512"))
 # row-count policy of the fused kernels on the GPU (measured on the Llama-2-7B projection shapes, sym_int4): the skinny
 # GEMV wins up to 16 rows (one row tile), the fused MFMA GEMM from 17 to 256 rows (in isolation the two-tile GEMV ties it
 # up to 32 rows, inside the batched decode step the GEMM path is 20 % ahead at 32 rows), dequantize + hipBLASLt above
-GEMV_MAX_ROWS = 16
+GEMV_MAX_ROWS = int(os.getenv("BIGDL_GEMV_MAX_ROWS", "16"))
 GEMM_MAX_ROWS = 256
 
 
