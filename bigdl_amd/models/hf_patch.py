@@ -250,6 +250,14 @@ def attention_forward(self, hidden_states, position_embeddings=None, attention_m
             k, v = past_key_values.update(k, v, self.layer_idx, query_states=q, num_key_value_groups=nq // nk)
         else:
             k, v = past_key_values.update(k, v, self.layer_idx)
+    if k.dtype == torch.uint8:
+        # byte views of an Fp8RawLayer (K, V^T as e5m2): read in place by the flash kernel, else expanded once
+        raw = _fp8_raw_attention(self, q, k, v, attention_mask, 0.0, self.scaling, None,
+                                 dict(kwargs, softcap=getattr(self, "attn_logit_softcapping", None)))
+        if raw is not None:
+            return self.o_proj(raw.reshape(*input_shape, -1)), None
+        from ..transformers.kv import fp8_raw_to_dense
+        k, v = fp8_raw_to_dense(k, v, q.dtype if q.dtype in (torch.float16, torch.bfloat16) else torch.float16)
     native = _native_attention(self, q, k, v, attention_mask, kwargs)
     if native is not None:
         return self.o_proj(native), None
@@ -312,6 +320,32 @@ def _native_attention(module, q, k, v, attention_mask, kwargs):
 HIP_ATTENTION = "bigdl_hip"
 
 
+def _fp8_raw_attention(module, query, key, value, attention_mask, dropout, scaling, is_causal, kwargs):
+    from ..ops import hip
+    b, hq, sq, d = query.shape
+    lk = key.shape[2]
+    if not (_is_cuda(query) and query.dtype == torch.float16 and not torch.is_grad_enabled() and d in (64, 96, 128, 256)
+            and not module.training and not dropout and kwargs.get("position_bias") is None
+            and not kwargs.get("output_attentions") and hq % key.shape[1] == 0 and lk >= sq):
+        return None
+    mask = attention_mask
+    if mask is not None:
+        if mask.dim() != 4 or mask.shape[1] != 1 or mask.shape[-2] != sq or mask.shape[-1] != lk:
+            return None
+        if mask.dtype == torch.bool:
+            mask = torch.zeros(mask.shape, dtype=torch.float16, device=mask.device).masked_fill_(~mask, float("-inf"))
+        elif mask.dtype != torch.float16:
+            mask = mask.to(torch.float16)
+        if mask.stride(-1) != 1:
+            mask = mask.contiguous()
+    causal = mask is None and sq > 1 and (is_causal if is_causal is not None else getattr(module, "is_causal", True))
+    q = query if (query.stride(-1) == 1 and all(query.stride(i) % 8 == 0 for i in (0, 1, 2))) else query.contiguous()
+    softcap = kwargs.get("softcap", getattr(module, "attn_logit_softcapping", None)) or 0.0
+    out = hip.attn_prefill(q, key, value, scale=scaling if scaling is not None else d ** -0.5, causal=bool(causal),
+                           mask=mask, softcap=softcap, v_transposed=True, kv_e5m2=True)
+    return out.view(b, sq, hq, d)
+
+
 def hip_attention_interface(module, query, key, value, attention_mask, dropout=0.0, scaling=None, is_causal=None, **kwargs):
     """Entry in HuggingFace's attention-function registry (``config._attn_implementation = "bigdl_hip"``): every
     architecture that dispatches through that registry (gpt2, gpt_neox, falcon, phi, starcoder2, opt, whisper, bert,
@@ -320,6 +354,14 @@ def hip_attention_interface(module, query, key, value, attention_mask, dropout=0
     {gpt2,gptneox,phi,starcoder2,whisper,bert}.py).  Cases the kernel does not cover fall through to PyTorch SDPA."""
     from transformers.integrations.sdpa_attention import sdpa_attention_forward
     d = query.shape[-1]
+    if key.dtype == torch.uint8:
+        # byte views of an Fp8RawLayer: K [B, Hkv, L, D] and V^T [B, Hkv, D, L] as e5m2.  The flash kernel reads them as
+        # they lie (prompt chunks and single decode tokens alike); anything it does not cover gets a dense copy.
+        out = _fp8_raw_attention(module, query, key, value, attention_mask, dropout, scaling, is_causal, kwargs)
+        if out is not None:
+            return out, None
+        from ..transformers.kv import fp8_raw_to_dense
+        key, value = fp8_raw_to_dense(key, value, query.dtype if query.dtype in (torch.float16, torch.bfloat16) else torch.float16)
     ok = (_is_cuda(query) and query.dtype == torch.float16 and not torch.is_grad_enabled() and d in PREFILL_HEAD_DIMS
           and not module.training and not dropout and kwargs.get("position_bias") is None
           and query.dim() == 4 and key.shape[1] > 0 and query.shape[1] % key.shape[1] == 0)
@@ -737,6 +779,12 @@ def optimize_post(model):
     return model
 
 
+def _raw_fp8_head_dim(cfg) -> bool:
+    d = getattr(cfg, "head_dim", None) or (cfg.hidden_size // cfg.num_attention_heads
+                                           if getattr(cfg, "num_attention_heads", 0) else 0)
+    return d in (64, 96, 128, 256)
+
+
 def kv_cache_pre_hook(module, args, kwargs):
     """Forward pre-hook of the base model: choose the KV cache class by policy (fp8 storage, SnapKV compression,
     else the block-preallocated cache) when the caller passed none or HF's empty default.  Reference: the cache
@@ -755,7 +803,13 @@ def kv_cache_pre_hook(module, args, kwargs):
     ids = kwargs.get("input_ids", args[0] if args else None)
     emb = kwargs.get("inputs_embeds")
     seq = ids.shape[1] if ids is not None else (emb.shape[1] if emb is not None else 0)
-    kwargs["past_key_values"] = make_kv_cache(use_quantize_kv_cache(), should_use_compresskv(prompt_len=seq))
+    # fp16 models on the GPU whose attention goes through the registry entry below get the fp8 cache that is read as
+    # bytes (no fp16 copy of the cache per step); BIGDL_FP8_RAW_CACHE=0 keeps the expanding one
+    cfg = module.config
+    p0 = next((p for p in module.parameters() if p.is_floating_point()), None)     # (low-bit weights are byte buffers)
+    raw = (getattr(cfg, "_attn_implementation", None) == HIP_ATTENTION and p0 is not None and p0.device.type == "cuda"
+           and p0.dtype == torch.float16 and _raw_fp8_head_dim(cfg) and os.environ.get("BIGDL_FP8_RAW_CACHE", "1") != "0")
+    kwargs["past_key_values"] = make_kv_cache(use_quantize_kv_cache(), should_use_compresskv(prompt_len=seq), raw_fp8=raw)
     kwargs["use_cache"] = True
     return args, kwargs
 

@@ -687,11 +687,15 @@ def _rows(t, d):
         return t.contiguous().view(-1, d), False
 
 
+def _last_dim_dense(t):
+    return t.shape[-1] == 1 or t.stride(-1) == 1     # (the stride of a one-element dimension is never used)
+
+
 def to_e5m2(src, dst):
     """src [..., D] float -> dst uint8 of identical logical shape (last dim contiguous on both; slices of a
     larger buffer are fine)."""
     _need_cuda(src, dst)
-    if src.shape != dst.shape or dst.dtype != torch.uint8 or src.stride(-1) != 1 or dst.stride(-1) != 1:
+    if src.shape != dst.shape or dst.dtype != torch.uint8 or not (_last_dim_dense(src) and _last_dim_dense(dst)):
         raise ValueError("to_e5m2: shapes must match, dst uint8, last dim contiguous")
     d = src.shape[-1]
     s2, _ = _rows(src, d)
@@ -708,7 +712,7 @@ def to_e5m2(src, dst):
 
 def from_e5m2(src, dst):
     _need_cuda(src, dst)
-    if src.shape != dst.shape or src.dtype != torch.uint8 or src.stride(-1) != 1 or dst.stride(-1) != 1:
+    if src.shape != dst.shape or src.dtype != torch.uint8 or not (_last_dim_dense(src) and _last_dim_dense(dst)):
         raise ValueError("from_e5m2: shapes must match, src uint8, last dim contiguous")
     d = src.shape[-1]
     s2, _ = _rows(src, d)

@@ -110,6 +110,82 @@ class Fp8Layer(NormalLayer):
         return src.contiguous().view(torch.float8_e5m2).to(dtype)
 
 
+class Fp8RawLayer(Fp8Layer):
+    """e5m2 storage that is never expanded: K [B, H, cap, D] and V^T [B, H, D, cap] bytes (the layout the attention
+    kernels read: one launch attends to the cache bytes where they lie), and ``update`` hands back byte VIEWS
+    (``uint8``: K [B, H, len, D], V^T [B, H, D, len]).  Only for models whose attention goes through the ``bigdl_hip``
+    registry entry (models/hf_patch.py::hip_attention_interface), which recognises those views; the plain ``Fp8Layer``
+    restores an fp16 copy of the whole cache on every step, which is what the reference's ``sdp_fp8`` avoids
+    (python/llm/src/ipex_llm/transformers/models/common.py:243-253)."""
+
+    def _reserve(self, key_states, value_states, need):
+        b, h, _, d = key_states.shape
+        cap = 0 if self._kbuf is None else self._kbuf.shape[2]
+        if need <= cap:
+            return
+        new_cap = (need + KV_CACHE_ALLOC_BLOCK_LENGTH + 255) // 256 * 256
+        kb = torch.zeros(b, h, new_cap, d, dtype=torch.uint8, device=self.device)
+        vb = torch.zeros(b, value_states.shape[1], value_states.shape[3], new_cap, dtype=torch.uint8, device=self.device)
+        if self._len:
+            kb[:, :, : self._len] = self._kbuf[:, :, : self._len]
+            vb[:, :, :, : self._len] = self._vbuf[:, :, :, : self._len]
+        self._kbuf, self._vbuf = kb, vb
+
+    def _views(self):
+        return self._kbuf[:, :, : self._len], self._vbuf[:, :, :, : self._len]
+
+    def update(self, key_states, value_states, *args, **kwargs):
+        from ..ops import hip
+        if not self.is_initialized:
+            self.lazy_initialization(key_states, value_states)
+        n = key_states.shape[2]
+        self._reserve(key_states, value_states, self._len + n)
+        hip.to_e5m2(key_states if key_states.stride(-1) == 1 else key_states.contiguous(),
+                    self._kbuf[:, :, self._len:self._len + n])
+        hip.to_e5m2(value_states.transpose(2, 3).contiguous(), self._vbuf[:, :, :, self._len:self._len + n])
+        self._len += n
+        self.keys, self.values = self._views()
+        return self.keys, self.values
+
+    def crop(self, tokens_to_remove=None, max_length=None):
+        if max_length is None:
+            max_length = self._len - (tokens_to_remove or 0)
+        if max_length < 0:
+            max_length = self._len + max_length
+        self._len = max(0, min(self._len, max_length))
+        if self._kbuf is not None:
+            self.keys, self.values = self._views()
+
+    def reorder_cache(self, beam_idx):
+        if self._kbuf is not None:
+            self._kbuf = self._kbuf.index_select(0, beam_idx.to(self._kbuf.device))
+            self._vbuf = self._vbuf.index_select(0, beam_idx.to(self._vbuf.device))
+            self.keys, self.values = self._views()
+
+    def batch_repeat_interleave(self, repeats):
+        if self._kbuf is not None:
+            self._kbuf = self._kbuf.repeat_interleave(repeats, dim=0)
+            self._vbuf = self._vbuf.repeat_interleave(repeats, dim=0)
+            self.keys, self.values = self._views()
+
+    def batch_select_indices(self, indices):
+        if self._kbuf is not None:
+            self._kbuf = self._kbuf[indices, ...]
+            self._vbuf = self._vbuf[indices, ...]
+            self.keys, self.values = self._views()
+
+
+def fp8_raw_to_dense(key_bytes, vt_bytes, dtype=torch.float16):
+    """(K [B,H,L,D], V^T [B,H,D,L]) byte views of an ``Fp8RawLayer`` -> dense (K, V) [B,H,L,D]: the way out for an
+    attention call the byte-reading kernel does not cover."""
+    from ..ops import hip
+    k = torch.empty(key_bytes.shape, dtype=dtype, device=key_bytes.device)
+    vt = torch.empty(vt_bytes.shape, dtype=dtype, device=vt_bytes.device)
+    hip.from_e5m2(key_bytes, k)
+    hip.from_e5m2(vt_bytes, vt)
+    return k, vt.transpose(2, 3)
+
+
 def snapkv_indices(query_states, key_states, window_size=32, max_capacity_prompt=1024, kernel_size=7, pooling="maxpool",
                    num_key_value_groups=1, scale=None):
     """SnapKV vote: which ``max_capacity_prompt - window_size`` prefix positions each kv head keeps, ascending.
@@ -195,6 +271,13 @@ class DynamicFp8Cache(Cache):
         super().__init__(layer_class_to_replicate=Fp8Layer)
 
 
+class DynamicFp8RawCache(DynamicFp8Cache):
+    """fp8 cache whose layers hand the attention function byte views (see ``Fp8RawLayer``)"""
+
+    def __init__(self, *args, **kwargs):
+        Cache.__init__(self, layer_class_to_replicate=Fp8RawLayer)
+
+
 class DynamicCompressCache(Cache):
     wants_query = True
 
@@ -219,8 +302,11 @@ class DynamicCompressFp8Cache(DynamicCompressCache):
         return CompressFp8Layer
 
 
-def make_kv_cache(quantize_kv=False, compress_kv_=False, **kwargs) -> Cache:
-    """Cache selection used by the bound model forwards (reference models/llama.py:73-94)."""
+def make_kv_cache(quantize_kv=False, compress_kv_=False, raw_fp8=False, **kwargs) -> Cache:
+    """Cache selection used by the bound model forwards (reference models/llama.py:73-94).  ``raw_fp8``: the model's
+    attention reads e5m2 bytes itself (``DynamicFp8RawCache``)."""
+    if quantize_kv and raw_fp8 and not compress_kv_:
+        return DynamicFp8RawCache()
     if compress_kv_:
         return DynamicCompressFp8Cache(**kwargs) if quantize_kv else DynamicCompressCache(**kwargs)
     return DynamicFp8Cache() if quantize_kv else DynamicNormalCache()

@@ -146,6 +146,37 @@ def test_fp8_kv_cache_module_path(tiny, monkeypatch):
     assert _rel(b, a) < 0.12      # e5m2 keeps 2 mantissa bits
 
 
+def test_fp8_kv_cache_read_as_bytes_on_the_module_path(tiny, monkeypatch):
+    """fp16 models whose attention goes through the registry entry get the fp8 cache that is never expanded: the flash
+    kernel reads K / V^T bytes in place (prompt, a 3-token step, single-token steps); logits equal those of the
+    expanding fp8 cache (same e5m2 values either way), generation runs on it."""
+    from ipex_llm.transformers import AutoModelForCausalLM
+    from bigdl_amd.transformers import kv
+    d, _ = tiny
+    q = AutoModelForCausalLM.from_pretrained(d, load_in_low_bit="sym_int8").half().to("cuda")
+    monkeypatch.setenv("IPEX_LLM_QUANTIZE_KV_CACHE", "1")
+    ids = torch.randint(0, 320, (2, 40)).cuda()
+    more = torch.randint(0, 320, (2, 3)).cuda()
+    res = {}
+    for raw in ("1", "0"):
+        monkeypatch.setenv("BIGDL_FP8_RAW_CACHE", raw)
+        with torch.no_grad():
+            out = q(ids, use_cache=True)
+            pkv = out.past_key_values
+            assert isinstance(pkv, kv.DynamicFp8RawCache) == (raw == "1") and isinstance(pkv, kv.DynamicFp8Cache)
+            step3 = q(more, past_key_values=pkv, use_cache=True).logits.float()
+            nxt = step3[:, -1:].argmax(-1)
+            step1 = q(nxt, past_key_values=pkv, use_cache=True).logits.float()
+        assert pkv.get_seq_length() == 44
+        res[raw] = (out.logits.float(), step3, step1)
+    assert pkv.layers[0].keys.dtype == torch.float16               # (last pass: the expanding cache hands back fp16 copies)
+    for a, b in zip(res["1"], res["0"]):
+        assert _rel(a, b) < 2e-2
+    monkeypatch.setenv("BIGDL_FP8_RAW_CACHE", "1")
+    gen = q._hf_generate(ids, max_new_tokens=6, do_sample=False)
+    assert gen.shape == (2, 46)
+
+
 @pytest.mark.parametrize("family", ["mixtral", "qwen2_moe"])
 def test_moe_models_module_path_and_native_engine(family, tmp_path):
     """Fused HF experts -> LowBitExperts; routed GEMV decode (module path and hipGraph engine) vs the CPU model."""
