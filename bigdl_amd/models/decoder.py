@@ -356,6 +356,13 @@ class NativeDecoder:
         # dequantize + hipBLASLt.  No fp16 scratch copy of a weight (0.18 GB less peak memory on Llama-2-7B) and no library
         # GEMM, but the first token of a 1024-token prompt takes 20.6 instead of 19.3 ms: off by default.
         self.prefill_fused = os.environ.get("BIGDL_PREFILL_FUSED", "0") == "1"
+        # ``BIGDL_DEQUANT_AHEAD=1``: while the library GEMM of one weight runs, the next weight of the prompt pass is
+        # expanded to fp16 on a second stream into the other of two scratch buffers.  Measured on Llama-2-7B at 1024
+        # prompt tokens: first token 19.4 against 17.5 ms (18.8 with the side stream at equal priority on another box):
+        # the expansion's workgroups take CU time and cache from the GEMM they run beside, which costs more than the
+        # 3.7 ms of expansion that leave the critical path.  Off by default.
+        self.dequant_ahead = os.environ.get("BIGDL_DEQUANT_AHEAD", "0") == "1"
+        self._ahead = None
         # opt-in fp8 prompt pass (``BIGDL_PREFILL_FP8=1``): see _linear_dense
         self.prefill_fp8 = os.environ.get("BIGDL_PREFILL_FP8") == "1"
         self._ssq_ring = {}             # rows -> [slots, rows] fp32 (see _ssq_reset)
@@ -469,7 +476,7 @@ class NativeDecoder:
             # prompts + decode rows, long prompt chunks) go through it 4096 rows at a time, the rest as its own product
             # (at most 256 rows: the fused low-bit kernels).
             y = torch.empty(m, lin.n, dtype=x.dtype, device=x.device)
-            w = lin.dense()
+            w = self._dense_of(lin)
             m0 = m // 4096 * 4096
             for r in range(0, m0, 4096):
                 torch.mm(x[r:r + 4096], w.t(), out=y[r:r + 4096])
@@ -485,10 +492,59 @@ class NativeDecoder:
             x8, sx = hip.quant_rows_e4m3(x.contiguous())
             y = hip.bf16_to_f16(torch._scaled_mm(x8, w8.t(), scale_a=sx, scale_b=sw.t(), out_dtype=torch.bfloat16))
         else:
-            y = F.linear(x, lin.dense())
+            y = F.linear(x, self._dense_of(lin))
         if lin.bias is not None:
             y = y + lin.bias
         return y
+
+    def _dense_ahead(self, lin: Lin):
+        """fp16 form of ``lin``'s weight for a library GEMM on the current stream, valid until the next-but-one call.
+        Starts the expansion of the weight that follows ``lin`` in a prompt pass on the side stream."""
+        from ..ops import hip
+        a = self._ahead
+        if a is None:
+            plain = [lw for lw in self.layers if lw.mla is None and lw.moe is None]
+            order = [l for lw in plain for l in (lw.qkv, lw.o, lw.gate, lw.up, lw.down) if l is not None and l.fused]
+            a = self._ahead = dict(next={id(p): n for p, n in zip(order, order[1:])}, lin=[None, None], last=1,
+                                   buf=[None, None], side=torch.cuda.Stream(device=self.device),
+                                   ready=[torch.cuda.Event(), torch.cuda.Event()], free=[torch.cuda.Event(), torch.cuda.Event()])
+            a["numel"] = max((l.n * l.k for l in order), default=0)
+        main = torch.cuda.current_stream()
+
+        def view(j, l):
+            need = max(a["numel"], l.n * l.k)
+            if a["buf"][j] is None or a["buf"][j].numel() < need:
+                a["buf"][j] = torch.empty(need, dtype=torch.float16, device=self.device)
+                a["buf"][j].record_stream(a["side"])
+            return a["buf"][j][: l.n * l.k].view(l.n, l.k)
+
+        j = 0 if a["lin"][0] is lin else 1 if a["lin"][1] is lin else None
+        if j is not None:
+            main.wait_event(a["ready"][j])
+        else:
+            j = 1 - a["last"]
+            if a["lin"][j] is not None:
+                main.wait_event(a["ready"][j])        # (a look-ahead nobody consumed may still be writing the buffer)
+            w = view(j, lin)
+            hip.dequant_t16(lin.w, lin.qtype, lin.n, lin.k, out=w)
+            a["lin"][j] = lin
+        a["last"] = j
+        w = view(j, lin)
+        nxt = a["next"].get(id(lin))
+        if nxt is not None and a["lin"][1 - j] is not nxt:
+            o = 1 - j
+            a["free"][o].record(main)                 # the GEMM that read this buffer is already in the stream
+            a["side"].wait_event(a["free"][o])
+            with torch.cuda.stream(a["side"]):
+                hip.dequant_t16(nxt.w, nxt.qtype, nxt.n, nxt.k, out=view(o, nxt))
+                a["ready"][o].record(a["side"])
+            a["lin"][o] = nxt
+        return w
+
+    def _dense_of(self, lin: Lin):
+        if lin.fused and self.dequant_ahead and not Lin.cache_dense and not torch.cuda.is_current_stream_capturing():
+            return self._dense_ahead(lin)
+        return lin.dense()
 
     def _tp_reduce(self, t):
         if self.tp_group is not None:
