@@ -42,11 +42,12 @@ if __name__ == "__main__":
             got = hip.gemm_lowbit_big(x, w, qt, n, k).float()
             err = ((got - ref).abs().max() / ref.abs().max()).item()
             us_big = timed(lambda: hip.gemm_lowbit_big(x, w, qt, n, k))
+            us_small = timed(lambda: hip.gemm_lowbit(x, w, qt, n, k)) if m <= 256 else None
             us_dense = timed(lambda: torch.nn.functional.linear(x, hip.dequant_t16(w, qt, n, k)))
             us_blas = timed(lambda: torch.nn.functional.linear(x, wd))
             print(json.dumps({"qtype": args.qtype, "shape": name, "M": m, "N": n, "K": k, "max_rel_err": round(err, 5),
                               "splitk": hip.lib().bigdl_gemm_lowbit_big_splitk(m, n, k),
-                              "fused_big_us": round(us_big, 1), "dequant_plus_hipblaslt_us": round(us_dense, 1),
+                              "fused_big_us": round(us_big, 1), "fused_rows_le_256_us": us_small and round(us_small, 1), "dequant_plus_hipblaslt_us": round(us_dense, 1),
                               "hipblaslt_only_us": round(us_blas, 1),
                               "fused_big_tflops": round(2.0 * m * n * k / us_big / 1e6, 1),
                               "dequant_plus_hipblaslt_tflops": round(2.0 * m * n * k / us_dense / 1e6, 1)}), flush=True)

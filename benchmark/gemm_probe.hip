@@ -15,6 +15,11 @@
 
 using namespace bigdl;
 
+#ifndef PROBE_NT
+#define PROBE_NT 2          // 16-column weight tiles per wavefront: column block = 64 * PROBE_NT
+#endif
+#define PROBE_BN (64 * PROBE_NT)
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
 static size_t t16_bytes(int n, int k) {   // sym_int4: 4-bit codes + fp16 scale per 32
@@ -89,7 +94,7 @@ int main(int argc, char** argv) {
       GemmArgs a = {};
       a.x = x; a.w = w[l]; a.out = out; a.partial = ws; a.M = M; a.N = sh.n; a.K = sh.k; a.ldx = sh.k; a.ldo = sh.n; a.out_type = OUT_F16;
       const int mblocks = (M + 63) / 64;
-      const int blocks = ((sh.n + 127) / 128) * mblocks;
+      const int blocks = ((sh.n + PROBE_BN - 1) / PROBE_BN) * mblocks;
       int sk = 1;
       if (blocks < target * 3 / 4) sk = (target + blocks - 1) / blocks;
       if (getenv("PROBE_SK_FLOOR")) sk = std::max(1, target / blocks);      // never more workgroups than the target
@@ -105,7 +110,7 @@ int main(int argc, char** argv) {
       const int mblocks = (M + 63) / 64;
       int rc;
       (void)use_kg;
-      rc = gemm_launch_mt<Q_SYM_INT4, 4, 2>(a, mblocks, st);
+      rc = gemm_launch_mt<Q_SYM_INT4, 4, PROBE_NT>(a, mblocks, st);
       if (rc != 0) { printf("launch failed %d\n", rc); exit(1); }
       if (a.splitk > 1) hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)(((int64_t)M * sh.n + 255) / 256)), dim3(256), 0, st, a);
       return a;
@@ -132,7 +137,7 @@ int main(int argc, char** argv) {
       std::vector<unsigned long long> hs(nst);
       CK(hipMemcpy(hs.data(), sbuf, nst * 8, hipMemcpyDeviceToHost));
       unsigned long long t0 = ~0ull;
-      const int nwv = a2.splitk * ((sh.n + 127) / 128) * 16;
+      const int nwv = a2.splitk * ((sh.n + PROBE_BN - 1) / PROBE_BN) * 16;
       for (int w = 0; w < nwv; ++w) if (hs[(size_t)w * 32] && hs[(size_t)w * 32] < t0) t0 = hs[(size_t)w * 32];
       printf("{\"tag\": \"%s\", \"shape\": \"%s\", \"stamps_us [min, median, p90, max]\": {", tag, sh.name);
       for (int i = 0; i < 32; ++i) {
@@ -170,7 +175,7 @@ int main(int argc, char** argv) {
     total_us += us * (strcmp(sh.name, "gate") == 0 ? 2 : 1);
     printf("{\"tag\": \"%s\", \"shape\": \"%s\", \"M\": %d, \"kg\": %d, \"splitk\": %d, \"kt_per_split\": %d, \"workgroups\": %d, \"us\": %.2f, "
            "\"weight_TBps\": %.2f, \"maxdiff_vs_kg1\": %.4g, \"max_abs\": %.4g, \"kg1_splitk\": %d}\n", tag, sh.name, M, kg, a2.splitk,
-           a2.kt_per_split, ((sh.n + 127) / 128) * a2.splitk * ((M + 63) / 64), us, t16_bytes(sh.n, sh.k) / us * 1e-6, dmax, vmax, a1.splitk);
+           a2.kt_per_split, ((sh.n + PROBE_BN - 1) / PROBE_BN) * a2.splitk * ((M + 63) / 64), us, t16_bytes(sh.n, sh.k) / us * 1e-6, dmax, vmax, a1.splitk);
     CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
     for (int l = 0; l < L; ++l) CK(hipFree(w[l]));
   }
