@@ -122,6 +122,18 @@ def optimize_model(model, low_bit="sym_int4", optimize_llm=True, modules_to_not_
                    **kwargs):
     """Quantize every linear of an arbitrary ``nn.Module`` and apply the LLM forward optimizations."""
     from .transformers.convert import ggml_convert_low_bit
+    from .models.sd import is_diffusion_pipeline, optimize_diffusion_pipeline, unwrap_sentence_transformer
+    if is_diffusion_pipeline(model):
+        # diffusers pipelines are not modules: fused attention processor on the denoiser, bf16 guard on the SDXL VAE
+        # (reference transformers/convert.py:1251-1263; its examples call optimize_model(pipe, low_bit=None))
+        return optimize_diffusion_pipeline(model, low_bit=low_bit, modules_to_not_convert=modules_to_not_convert)
+    inner = unwrap_sentence_transformer(model) if isinstance(model, nn.Module) else None
+    if inner is not None:
+        # a SentenceTransformer: its encoder is converted in place, pooling / normalisation modules stay
+        # (reference convert.py:1265-1281)
+        optimize_model(inner, low_bit=low_bit, optimize_llm=optimize_llm, modules_to_not_convert=modules_to_not_convert,
+                       cpu_embedding=cpu_embedding, **kwargs)
+        return model
     invalidInputError(isinstance(model, nn.Module), "model should be an instance of `torch.nn.Module`, "
                                                     f"but got {type(model)} at last.")
     if low_bit is None:
