@@ -201,8 +201,11 @@ def _replace_with_low_bit_linear(model, qtype, modules_to_not_convert=None, conv
             continue
         if is_linear and not isinstance(module, LowBitLinear):
             in_features, out_features, mp_group = linear_args
+            # (not for encoder-decoder models: a teacher-forced pass scores every decoder position, and a decoding
+            # step has one position anyway)
             optimize_lm_head = is_lm_head(name, model_config, out_features) and \
-                os.environ.get("IPEX_LLM_LAST_LM_HEAD", None) != "0"
+                os.environ.get("IPEX_LLM_LAST_LM_HEAD", None) != "0" and \
+                not getattr(model_config, "is_encoder_decoder", False)
             new_linear = None
             packed = is_gptq_linear(module) or _is_awq_linear(module)
             if packed:
@@ -349,6 +352,31 @@ def ggml_convert_low_bit(model, qtype, optimize_model=True, convert_shape_only=F
             convert_bigdl_other_module(model, torch.float32)
     elif device == "meta":
         pass
+    _rebind_t5_feed_forward(model)
     if optimize_model:
         model = _optimize_post(model)
     return model
+
+
+def _t5_gated_ff_forward(self, hidden_states):
+    return self.wo(self.dropout(self.act(self.wi_0(hidden_states)) * self.wi_1(hidden_states)))
+
+
+def _t5_ff_forward(self, hidden_states):
+    return self.wo(self.dropout(self.act(self.wi(hidden_states))))
+
+
+def _rebind_t5_feed_forward(model):
+    """T5-style feed-forward blocks (t5, mt5, umt5, longt5, switch_transformers, pix2struct text) cast their hidden
+    states to ``wo.weight.dtype`` before the output projection, which for a low-bit ``wo`` is the byte type of the
+    packed blocks.  The reference works around it by leaving ``wo`` unconverted
+    (example/GPU/HuggingFace/LLM/flan-t5/generate.py:44-52); here such a block gets a forward without the cast."""
+    import types
+    from .low_bit_linear import LowBitLinear
+    for m in model.modules():
+        if not isinstance(getattr(m, "wo", None), LowBitLinear) or not hasattr(m, "act") or not hasattr(m, "dropout"):
+            continue
+        if hasattr(m, "wi_0") and hasattr(m, "wi_1"):
+            m.forward = types.MethodType(_t5_gated_ff_forward, m)
+        elif hasattr(m, "wi"):
+            m.forward = types.MethodType(_t5_ff_forward, m)

@@ -484,3 +484,24 @@ def test_siglip_tower_72_wide_heads_and_internvl_wrapper_on_gpu(monkeypatch):
         out = copy.deepcopy(m).half().to("cuda")(input_ids=ids.cuda(), pixel_values=px.half().cuda()).logits.float().cpu()
     assert calls["n"] > n0
     assert _rel(out, ref) < 0.03
+
+
+def test_t5_seq2seq_low_bit_on_gpu(tmp_path):
+    """flan-t5 style encoder-decoder, every linear low-bit (``wo`` and the head included), fp16 on the GPU."""
+    from transformers import T5Config, T5ForConditionalGeneration
+    from ipex_llm.transformers import AutoModelForSeq2SeqLM
+    torch.manual_seed(0)
+    cfg = T5Config(vocab_size=320, d_model=256, d_kv=64, d_ff=512, num_layers=2, num_decoder_layers=2, num_heads=4,
+                   feed_forward_proj="gated-gelu", decoder_start_token_id=0, pad_token_id=0, eos_token_id=1,
+                   tie_word_embeddings=False)
+    m = T5ForConditionalGeneration(cfg).eval()
+    m.save_pretrained(tmp_path)
+    ids = torch.randint(3, 320, (2, 12))
+    dec = torch.randint(3, 320, (2, 5))
+    with torch.no_grad():
+        ref = m(input_ids=ids, decoder_input_ids=dec).logits
+        q = AutoModelForSeq2SeqLM.from_pretrained(str(tmp_path), load_in_low_bit="sym_int8").half().to("cuda")
+        out = q(input_ids=ids.cuda(), decoder_input_ids=dec.cuda()).logits.float().cpu()
+        gen = q.generate(ids.cuda(), max_new_tokens=6, do_sample=False, use_cache=True)
+    assert _rel(out, ref) < 0.05
+    assert gen.shape[0] == 2 and gen.shape[1] <= 7

@@ -231,3 +231,39 @@ def test_idefics2_and_qwen2_audio_wrappers_keep_logits():
         ref = m(input_ids=ids).logits.float()
         out = optimize_model(copy.deepcopy(m), low_bit="sym_int8")(input_ids=ids).logits.float()
     assert _rel(out, ref) < 0.05
+
+
+def test_t5_encoder_decoder_through_the_seq2seq_auto_class(tmp_path):
+    """flan-t5 (reference example/GPU/HuggingFace/LLM/flan-t5/generate.py:47-52): AutoModelForSeq2SeqLM with
+    ``modules_to_not_convert=["wo", "lm_head"]``; logits and generation stay those of the fp32 model."""
+    from transformers import T5Config, T5ForConditionalGeneration
+    from bigdl_amd.transformers import AutoModelForSeq2SeqLM
+    from bigdl_amd.transformers.low_bit_linear import LowBitLinear
+    torch.manual_seed(0)
+    cfg = T5Config(vocab_size=320, d_model=128, d_kv=32, d_ff=256, num_layers=2, num_decoder_layers=2, num_heads=4,
+                   feed_forward_proj="gated-gelu", decoder_start_token_id=0, pad_token_id=0, eos_token_id=1,
+                   tie_word_embeddings=False)
+    m = T5ForConditionalGeneration(cfg).eval()
+    m.save_pretrained(tmp_path)
+    ids = torch.randint(3, 320, (2, 12))
+    dec = torch.randint(3, 320, (2, 5))
+    with torch.no_grad():
+        ref = m(input_ids=ids, decoder_input_ids=dec).logits
+        q = AutoModelForSeq2SeqLM.from_pretrained(str(tmp_path), load_in_low_bit="sym_int8", optimize_model=False,
+                                                  modules_to_not_convert=["wo", "lm_head"])
+        out = q(input_ids=ids, decoder_input_ids=dec).logits
+        gen = q.generate(ids, max_new_tokens=6, do_sample=False, use_cache=True)
+        gen_ref = m.generate(ids, max_new_tokens=6, do_sample=False, use_cache=True)
+    blk = q.encoder.block[0].layer
+    assert isinstance(blk[0].SelfAttention.q, LowBitLinear) and not isinstance(blk[1].DenseReluDense.wo, LowBitLinear)
+    assert not isinstance(q.lm_head, LowBitLinear)
+    assert _rel(out, ref) < 0.05
+    assert gen.shape == gen_ref.shape and (gen == gen_ref).float().mean() > 0.7
+    # everything converted (``wo`` and the head too), optimizations on: the feed-forward block no longer casts its hidden
+    # states to the byte type of a packed ``wo``, the head scores every position of a teacher-forced pass
+    q2 = optimize_model(copy.deepcopy(m), low_bit="sym_int8")
+    assert isinstance(q2.encoder.block[0].layer[1].DenseReluDense.wo, LowBitLinear) and isinstance(q2.lm_head, LowBitLinear)
+    with torch.no_grad():
+        assert _rel(q2(input_ids=ids, decoder_input_ids=dec).logits, ref) < 0.05
+        gen2 = q2.generate(ids, max_new_tokens=6, do_sample=False, use_cache=True)
+    assert gen2.shape == gen_ref.shape and (gen2 == gen_ref).float().mean() > 0.7
