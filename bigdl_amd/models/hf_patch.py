@@ -413,8 +413,10 @@ def register_hip_attention(model):
         return False
     for m in model.modules():
         cfg = getattr(m, "config", None)
+        # (``_supports_sdpa``: the model class itself declares that an SDPA-style backend computes what its eager
+        # attention computes; bigbird_pegasus, for one, goes through the registry but is only right in eager form)
         if cfg is not None and getattr(cfg, "_attn_implementation", None) in ("sdpa", "eager", None) \
-                and _dispatches_through_registry(type(m)):
+                and getattr(type(m), "_supports_sdpa", False) and _dispatches_through_registry(type(m)):
             try:
                 cfg._attn_implementation = HIP_ATTENTION
                 done = True
@@ -742,6 +744,44 @@ def language_model_inputs(model, input_ids, vl_inputs, attention_mask=None):
     raise RuntimeError("the multimodal wrapper did not call its language model")
 
 
+def _rms_forward_matches(m) -> bool:
+    """Does ``rms_norm_forward`` compute what this module's own forward computes?  Checked once per class on a CPU
+    copy of one instance with random weights: classes that only look like an RMSNorm (a weight that is never applied,
+    a (1 + weight) scale under another name than Gemma's, an extra bias or gate) keep their own forward."""
+    import copy
+    try:
+        probe = copy.deepcopy(m)
+        if any(t.is_meta for t in list(probe.parameters()) + list(probe.buffers())):
+            probe = probe.to_empty(device="cpu")
+        probe = probe.float().cpu()
+        with torch.no_grad():
+            for t in list(probe.parameters()) + list(probe.buffers()):
+                if t.is_floating_point():
+                    t.uniform_(0.5, 1.5)
+            x = torch.randn(2, 3, probe.weight.shape[0])
+            ref = type(m).forward(probe, x)
+            got = rms_norm_forward(probe, x)
+        return isinstance(ref, torch.Tensor) and ref.shape == got.shape and torch.allclose(ref, got, atol=1e-4, rtol=1e-4)
+    except Exception:
+        return False
+
+
+def _plain_gated_mlp(m) -> bool:
+    """``down(act(gate(x)) * up(x))`` and nothing else: the class's forward takes one tensor and touches no attribute
+    besides the three projections and the activation (sub-norms, gammas, expert gates keep HF's forward)."""
+    import inspect
+    import re
+    try:
+        fwd = type(m).forward
+        params = list(inspect.signature(fwd).parameters.values())
+        if len(params) != 2 or params[1].kind not in (params[1].POSITIONAL_ONLY, params[1].POSITIONAL_OR_KEYWORD):
+            return False
+        used = set(re.findall(r"self\.(\w+)", inspect.getsource(fwd)))
+    except (OSError, TypeError, ValueError):
+        return False
+    return {"gate_proj", "up_proj", "down_proj"} <= used <= {"gate_proj", "up_proj", "down_proj", "act_fn"}
+
+
 def optimize_post(model):
     """Bind the optimized forwards; install the native-engine generate front door."""
     from ..transformers.convert import convert_forward
@@ -754,7 +794,8 @@ def optimize_post(model):
         name = cls.__name__
         if name.endswith("RMSNorm") and hasattr(m, "weight") and m.weight is not None and m.weight.dim() == 1:
             seen.add(cls)
-            convert_forward(model, cls, rms_norm_forward)
+            if _rms_forward_matches(m):
+                convert_forward(model, cls, rms_norm_forward)
         elif cls is nn.LayerNorm:
             seen.add(cls)
             convert_forward(model, cls, layer_norm_forward)
@@ -764,7 +805,8 @@ def optimize_post(model):
         elif all(hasattr(m, p) for p in ("gate_proj", "up_proj", "down_proj", "act_fn")) and not list(
                 getattr(m, "experts", [])) and not hasattr(m, "num_experts"):
             seen.add(cls)
-            convert_forward(model, cls, mlp_forward)
+            if _plain_gated_mlp(m):
+                convert_forward(model, cls, mlp_forward)
     if getattr(cfg, "model_type", None) in ("rwkv", "rwkv5"):
         from .rwkv import bind_rwkv
         bind_rwkv(model)

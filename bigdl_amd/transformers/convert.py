@@ -185,6 +185,30 @@ def use_scale_search(model_config, qtype):
     return False
 
 
+_WEIGHT_DTYPE_READERS = {}
+
+
+def _parent_reads_weight_dtype(parent, name) -> bool:
+    """True when ``parent.forward`` casts something to ``self.<name>.weight.dtype`` (HF's Mamba / Mamba2 / Jamba heads do:
+    ``self.lm_head(hidden_states.to(self.lm_head.weight.dtype))``): with packed low-bit blocks that dtype is the byte
+    type and the cast would destroy the activations, so such a linear is left as it is.  T5-style feed-forward blocks
+    read ``wo.weight.dtype`` too but get a forward without the cast instead (``_rebind_t5_feed_forward``)."""
+    import inspect
+    cls = type(parent)
+    key = (cls, name)
+    hit = _WEIGHT_DTYPE_READERS.get(key)
+    if hit is None:
+        try:
+            hit = f"self.{name}.weight.dtype" in inspect.getsource(cls.forward)
+        except (OSError, TypeError):
+            hit = False
+        _WEIGHT_DTYPE_READERS[key] = hit
+    if hit and name == "wo" and hasattr(parent, "act") and hasattr(parent, "dropout") and (
+            hasattr(parent, "wi") or hasattr(parent, "wi_0")):
+        return False
+    return hit
+
+
 def _replace_with_low_bit_linear(model, qtype, modules_to_not_convert=None, convert_shape_only=False,
                                  cpu_embedding=False, prefix_name="", imatrix_data=None, embedding_qtype=None,
                                  model_config=None, torch_dtype=torch.float32, mixed_precision=False, act_order=False,
@@ -198,6 +222,9 @@ def _replace_with_low_bit_linear(model, qtype, modules_to_not_convert=None, conv
         is_linear, linear_args = is_linear_module(module)
         full_module_name = prefix_name + "." + name if prefix_name else name
         if any(key in full_module_name for key in modules_to_not_convert):
+            continue
+        if is_linear and _parent_reads_weight_dtype(model, name):
+            logger.info("%s stays dense: %s casts activations to its weight's dtype", full_module_name, type(model).__name__)
             continue
         if is_linear and not isinstance(module, LowBitLinear):
             in_features, out_features, mp_group = linear_args

@@ -31,7 +31,18 @@ def is_fused_experts(module) -> bool:
         return False
     # the [E, 2I, H] / [E, H, I] layout with a plain activation; experts with biases, interleaved gate / up columns or a
     # clamped activation of their own (GPT-OSS) keep their dense parameters
-    return hasattr(module, "act_fn") and getattr(module, "gate_up_proj_bias", None) is None
+    if not hasattr(module, "act_fn") or getattr(module, "gate_up_proj_bias", None) is not None:
+        return False
+    # gate_up [E, 2I, H] and down [E, H, I] (Llama-4 keeps the transposes, [E, H, 2I] / [E, I, H], and is called with
+    # rows already grouped by expert), and a forward that takes (hidden_states, top_k_index, top_k_weights)
+    if g.shape[0] != d.shape[0] or g.shape[2] != d.shape[1] or g.shape[1] != 2 * d.shape[2]:
+        return False
+    import inspect
+    try:
+        params = list(inspect.signature(type(module).forward).parameters)
+    except (TypeError, ValueError):
+        return False
+    return len(params) == 4
 
 
 class LowBitExperts(nn.Module):

@@ -267,3 +267,30 @@ def test_t5_encoder_decoder_through_the_seq2seq_auto_class(tmp_path):
         assert _rel(q2(input_ids=ids, decoder_input_ids=dec).logits, ref) < 0.05
         gen2 = q2.generate(ids, max_new_tokens=6, do_sample=False, use_cache=True)
     assert gen2.shape == gen_ref.shape and (gen2 == gen_ref).float().mean() > 0.7
+
+
+@pytest.mark.parametrize("model_type", ["mamba", "falcon_mamba", "bitnet", "bigbird_pegasus", "llama4_text", "inkling_text",
+                                        "opt", "gpt_neo", "persimmon", "xlstm"])
+def test_generic_patch_leaves_unlisted_families_intact(model_type):
+    """Families nobody wrote a rule for go through the same generic passes; each of these once broke one of them: a head
+    whose input is cast to ``lm_head.weight.dtype`` (mamba), an RMSNorm whose weight is never applied (falcon_mamba),
+    a gated MLP with a norm inside (bitnet) or extra arguments (inkling), a model that goes through the attention
+    registry but is only right in eager form (bigbird_pegasus), fused experts in transposed layout (llama4)."""
+    import inspect
+    from transformers import AutoModelForCausalLM
+    from transformers.models.auto.configuration_auto import CONFIG_MAPPING
+    if model_type not in CONFIG_MAPPING:
+        pytest.skip("not in this transformers version")
+    common = dict(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=4,
+                  num_key_value_heads=2, max_position_embeddings=128, n_embd=128, n_layer=2, n_head=4, n_positions=128,
+                  d_model=128, ffn_dim=256, n_inner=256, head_dim=32, num_experts=4, num_local_experts=4,
+                  num_experts_per_tok=2, moe_intermediate_size=64, pad_token_id=0, bos_token_id=1, eos_token_id=2)
+    cfg_cls = CONFIG_MAPPING[model_type]
+    cfg = cfg_cls(**{k: v for k, v in common.items() if k in inspect.signature(cfg_cls.__init__).parameters})
+    torch.manual_seed(0)
+    m = AutoModelForCausalLM.from_config(cfg).eval()
+    ids = torch.randint(3, 320, (2, 10))
+    with torch.no_grad():
+        ref = m(ids).logits
+        out = optimize_model(copy.deepcopy(m), low_bit="sym_int8")(ids).logits
+    assert out.shape == ref.shape and _rel(out, ref) < 0.08
