@@ -105,9 +105,14 @@ def load_low_bit(model, model_path):
     _materialize_meta_buffers(model)
     if hasattr(model, "tie_weights"):
         try:
-            model.tie_weights()
+            head = model.get_output_embeddings()
         except Exception:
-            pass
+            head = None
+        if head is None or type(head) is nn.Linear:          # (a low-bit head owns its packed blocks: never re-tied)
+            try:
+                model.tie_weights()
+            except Exception:
+                pass
     left = [n for n, p in model.named_parameters() if p.device.type == "meta"]
     if left == ["lm_head.weight"] and hasattr(model, "get_input_embeddings"):
         model.lm_head.weight = model.get_input_embeddings().weight

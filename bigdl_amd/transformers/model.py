@@ -396,10 +396,18 @@ class _BaseAutoModelClass:
             DiskEmbedding.replace_normal_embedding(model)
         model.config.update({"bigdl_transformers_low_bit": q_k, "bigdl_disk_embedding": disk_embedding})
         if getattr(model.config, "tie_word_embeddings", False) and not cpu_embedding and embedding_qtype is None:
+            # a head that stayed a plain nn.Linear shares its weight with the embedding again (the dtype pass above
+            # made two copies); a converted head owns packed low-bit blocks, which re-tying would overwrite with the
+            # dense embedding matrix
             try:
-                model.tie_weights()
+                head = model.get_output_embeddings()
             except Exception:
-                pass
+                head = None
+            if type(head) is torch.nn.Linear:
+                try:
+                    model.tie_weights()
+                except Exception:
+                    pass
         model.save_low_bit = types.MethodType(save_low_bit, model)
         return model
 
@@ -509,9 +517,14 @@ class _BaseAutoModelClass:
             invalidInputError(not absent, f"checkpoint is incomplete, missing tensors: {absent[:5]} ...")
         _materialize_meta_buffers(model)
         try:
-            model.tie_weights()
+            head = model.get_output_embeddings()
         except Exception:
-            pass
+            head = None
+        if head is None or type(head) is torch.nn.Linear:       # (a low-bit head owns its packed blocks: never re-tied)
+            try:
+                model.tie_weights()
+            except Exception:
+                pass
         still_meta = [n for n, p in model.named_parameters() if p.device.type == "meta"]
         if still_meta and getattr(config, "tie_word_embeddings", False) and still_meta == ["lm_head.weight"]:
             emb = model.get_input_embeddings()

@@ -356,3 +356,34 @@ def test_mlp_padding_and_norm_head_folding(tmp_path):
     fold_norm_head(holder)
     assert type(holder.lm_head) is nn.Linear
     torch.testing.assert_close(holder.lm_head(x), want)
+
+
+def test_tied_embedding_model_keeps_its_low_bit_head(tmp_path):
+    """tie_word_embeddings=True (Gemma, Qwen2-0.5B, Llama-3.2-1B ...): the converted head owns packed blocks and must not
+    be re-tied to the dense embedding, neither after from_pretrained nor after load_low_bit / optimize.load_low_bit."""
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from bigdl_amd.optimize import load_low_bit, low_memory_init, optimize_model
+    from bigdl_amd.transformers import AutoModelForCausalLM
+    from bigdl_amd.transformers.low_bit_linear import FP4Params
+    torch.manual_seed(0)
+    cfg = LlamaConfig(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=4,
+                      num_key_value_heads=2, tie_word_embeddings=True)
+    m = LlamaForCausalLM(cfg).eval()
+    m.save_pretrained(tmp_path / "hf")
+    ids = torch.randint(0, 320, (1, 8))
+    with torch.no_grad():
+        ref = m(ids).logits
+        q = AutoModelForCausalLM.from_pretrained(str(tmp_path / "hf"), load_in_low_bit="sym_int8")
+        assert isinstance(q.lm_head.weight, FP4Params)
+        out = q(ids).logits
+        assert (out - ref).abs().max() / ref.abs().max() < 0.05
+        q.save_low_bit(str(tmp_path / "lb"))
+        r = AutoModelForCausalLM.load_low_bit(str(tmp_path / "lb"))
+        assert isinstance(r.lm_head.weight, FP4Params) and torch.equal(r(ids).logits, out)
+        g = optimize_model(LlamaForCausalLM.from_pretrained(str(tmp_path / "hf")).eval(), low_bit="sym_int8")
+        g.save_low_bit(str(tmp_path / "lb2"))
+        with low_memory_init():
+            shell = LlamaForCausalLM(cfg)
+        g2 = load_low_bit(shell, str(tmp_path / "lb2"))
+        assert isinstance(g2.lm_head.weight, FP4Params)
+        assert (g2(ids).logits - ref).abs().max() / ref.abs().max() < 0.05
