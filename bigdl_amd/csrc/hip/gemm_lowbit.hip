@@ -34,18 +34,26 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs a) {
   float v[V], u[V];
 #pragma unroll
   for (int e = 0; e < V; ++e) v[e] = u[e] = 0.0f;
-  for (int s = 0; s < a.splitk; ++s) {
-    const fvec p = *(const fvec*)(a.partial + (int64_t)s * total + ic);
+  // the slabs of up to four splits are requested together: one at a time, every split costs its own memory round
+  // trip (8 splits: 8 dependent trips, most of this kernel's time)
+  auto gather = [&](float (&acc)[V], const float* base) {
+    int s = 0;
+    for (; s + 4 <= a.splitk; s += 4) {
+      const fvec p0 = *(const fvec*)(base + (int64_t)s * total + ic);
+      const fvec p1 = *(const fvec*)(base + (int64_t)(s + 1) * total + ic);
+      const fvec p2 = *(const fvec*)(base + (int64_t)(s + 2) * total + ic);
+      const fvec p3 = *(const fvec*)(base + (int64_t)(s + 3) * total + ic);
 #pragma unroll
-    for (int e = 0; e < V; ++e) v[e] += p[e];
-  }
-  if (a.w2 != nullptr) {
-    for (int s = 0; s < a.splitk; ++s) {
-      const fvec p = *(const fvec*)(a.partial + a.pair_stride + (int64_t)s * total + ic);
-#pragma unroll
-      for (int e = 0; e < V; ++e) u[e] += p[e];
+      for (int e = 0; e < V; ++e) acc[e] += (p0[e] + p1[e]) + (p2[e] + p3[e]);
     }
-  }
+    for (; s < a.splitk; ++s) {
+      const fvec p = *(const fvec*)(base + (int64_t)s * total + ic);
+#pragma unroll
+      for (int e = 0; e < V; ++e) acc[e] += p[e];
+    }
+  };
+  gather(v, a.partial);
+  if (a.w2 != nullptr) gather(u, a.partial + a.pair_stride);
   const float rs = a.row_ssq != nullptr ? rsqrtf(a.row_ssq[m] / (float)a.K + a.eps) : 1.0f;
   const float rsc = a.row_scale != nullptr ? a.row_scale[m] : 1.0f;
   const int64_t oi = (int64_t)m * a.ldo + n;
