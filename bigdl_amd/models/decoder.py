@@ -445,6 +445,47 @@ class NativeDecoder:
             self._rope_shift_buf[-off:].copy_(self.rope_table[: n + off])
         self.rope_dec = self._rope_shift_buf
 
+    @torch.no_grad()
+    def evict_middle(self, start_size: int = 4, recent_size: int = 2000) -> int:
+        """Attention-sink streaming (StreamingLLM, which the reference runs through the external ``streaming_llm``
+        package: python/llm/example/GPU/Applications/streaming-llm/run_streaming_llama.py): keep the first
+        ``start_size`` keys (the sinks) and the last ``recent_size``, drop what lies between, and let positions be the
+        positions INSIDE the cache.  The cache holds keys that are already rotated, so the kept recent keys are rotated
+        back by the number of dropped positions (rotations compose: R(p - drop) = R(-drop) R(p)); V^T columns only
+        move.  fp16 cache only (re-quantizing an e5m2 / int4 key at every eviction would pile up rounding error).
+        Returns the number of dropped positions.  Amortise it: evict down to ``recent_size`` whenever the next turn would
+        not fit, not at every token."""
+        cfg, cache = self.cfg, self.cache
+        assert cache is not None and cache.slot_len is None, "evict_middle works on the plain (non-slot) cache"
+        assert not cache.quantized, "attention-sink eviction needs the fp16 KV cache"
+        assert self.fused_rope and not self._rope_shift and all(lw.mla is None for lw in self.layers), \
+            "attention-sink eviction: plain rotary (or position-free) attention layers only"
+        n = cache.host_len
+        drop = n - start_size - recent_size
+        if drop <= 0:
+            return 0
+        d = cfg.head_dim
+        rot = 0 if self.no_rope else (cfg.rot_dim or d)
+        if rot:
+            ang = float(drop) * self.inv_freq.float().to(self.device)                 # [rot / 2]
+            c, sn = ang.cos().to(torch.float32), ang.sin().to(torch.float32)
+        for li in range(len(self.layers)):
+            kc, vc = cache.k[li], cache.v[li]
+            k = kc[:, :, start_size + drop:n].float()
+            if rot:
+                if cfg.rope_interleaved:
+                    k1, k2 = k[..., 0:rot:2], k[..., 1:rot:2]
+                    r1, r2 = k1 * c + k2 * sn, k2 * c - k1 * sn
+                    k = torch.cat([torch.stack([r1, r2], -1).flatten(-2), k[..., rot:]], -1)
+                else:
+                    k1, k2 = k[..., : rot // 2], k[..., rot // 2: rot]
+                    k = torch.cat([k1 * c + k2 * sn, k2 * c - k1 * sn, k[..., rot:]], -1)
+            kc[:, :, start_size:start_size + recent_size] = k.to(kc.dtype)
+            vc[:, :, :, start_size:start_size + recent_size] = vc[:, :, :, start_size + drop:n].clone()
+        cache.past_len.fill_(start_size + recent_size)
+        cache.host_len = start_size + recent_size
+        return drop
+
     def _compress_plan(self, past, s, slot, nd):
         """The SnapKV settings that apply to this prompt pass, or None."""
         ck = self.compress_kv

@@ -863,4 +863,8 @@ def install_generate_front_door(model):
         if not hasattr(model, "lookup_generate"):
             from ..transformers.lookup import lookup_generate
             model.lookup_generate = types.MethodType(lookup_generate, model)
+        if not hasattr(model, "native_engine"):
+            # the NativeDecoder behind ``generate`` (built on first use from views of the module's weights), for callers
+            # that drive prompt passes / decode steps / the KV cache themselves (examples/GPU/Applications/streaming-llm)
+            model.native_engine = types.MethodType(get_native_engine, model)
     return model

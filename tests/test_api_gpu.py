@@ -505,3 +505,29 @@ def test_t5_seq2seq_low_bit_on_gpu(tmp_path):
         gen = q.generate(ids.cuda(), max_new_tokens=6, do_sample=False, use_cache=True)
     assert _rel(out, ref) < 0.05
     assert gen.shape[0] == 2 and gen.shape[1] <= 7
+
+
+def test_streaming_turns_on_a_bounded_cache_through_the_model_engine(tiny):
+    """The streaming-llm application flow: ``model.native_engine()``, turns appended to one fp16 cache, attention-sink
+    eviction whenever the next turn would not fit; the cache never outgrows its capacity and tokens keep coming."""
+    from ipex_llm.transformers import AutoModelForCausalLM
+    d, _ = tiny
+    q = AutoModelForCausalLM.from_pretrained(d, load_in_low_bit="sym_int8").half().to("cuda")
+    eng = q.native_engine()
+    start, recent, gen, cap = 4, 48, 8, 128
+    eng.ensure_cache(1, cap, fp8=False)
+    eng.cache.reset()
+    dropped = 0
+    with torch.no_grad():
+        for turn in range(8):
+            ids = torch.randint(3, 320, (1, 24), device="cuda")
+            if eng.cache.host_len + 24 + gen > cap:
+                dropped += eng.evict_middle(start, recent)
+            logits = eng.prefill(ids)
+            nxt = logits[:, -1].argmax(-1).view(1, 1)
+            for _ in range(gen):
+                lg, n2 = eng.decode(nxt)
+                assert torch.isfinite(lg).all()
+                nxt = n2.view(1, 1)
+            assert eng.cache.host_len <= cap
+    assert dropped > 0

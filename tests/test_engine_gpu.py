@@ -395,3 +395,46 @@ def test_packed_prompts_with_decode_rows_match_separate_passes(fp8):
             assert (a[i] != b[i]).float().mean().item() < 0.03
         else:
             torch.testing.assert_close(a[i], b[i], rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("start", [0, 4])
+def test_attention_sink_eviction_re_rotates_the_kept_keys(start):
+    """evict_middle: sinks + recent window kept, keys re-indexed to their positions inside the cache.  Layer 0's keys
+    only depend on the embeddings, so the expected cache rows are the unrotated keys rotated (HF's half-rotation
+    formula, written out here) at the NEW positions; V^T columns move unchanged; decoding goes on from the new length."""
+    from bigdl_amd.models.decoder import build_random_decoder
+    eng = build_random_decoder(_tiny(), Q.SYM_INT8, device="cuda", seed=11)
+    cfg = eng.cfg
+    n, recent = 96, 40
+    ids = torch.randint(3, 320, (1, n), device="cuda")
+    eng.ensure_cache(1, 256, fp8=False)
+    eng.cache.reset()
+    eng.prefill(ids)
+    lw = eng.layers[0]
+    d, hq, hkv = cfg.head_dim, cfg.num_heads, cfg.num_kv_heads
+    x = eng._norm(eng.embed[ids[0]].to(torch.float16) * cfg.embed_scale, lw.input_norm)
+    qkv = eng._linear_dense(x, lw.qkv).float()
+    k_raw = qkv[:, hq * d:(hq + hkv) * d].view(n, hkv, d).transpose(0, 1)              # [hkv, n, d], no positions yet
+    inv = eng.inv_freq.float()
+
+    def rope(k, pos):
+        ang = pos.float()[:, None] * inv[None]
+        cos, sin = ang.cos(), ang.sin()
+        k0, k1 = k[..., : d // 2], k[..., d // 2:]
+        return torch.cat([k0 * cos - k1 * sin, k1 * cos + k0 * sin], -1)
+
+    before_k = eng.cache.k[0][0, :, :n].float().clone()
+    before_v = eng.cache.v[0][0, :, :, :n].clone()
+    assert torch.allclose(before_k, rope(k_raw, torch.arange(n, device="cuda")), atol=2e-2)      # the oracle's convention
+    drop = eng.evict_middle(start_size=start, recent_size=recent)
+    assert drop == n - start - recent and eng.cache.host_len == start + recent
+    assert int(eng.cache.past_len[0]) == start + recent
+    kept = torch.cat([torch.arange(start), torch.arange(n - recent, n)]).cuda()
+    want_k = rope(k_raw[:, kept], torch.arange(start + recent, device="cuda"))
+    got_k = eng.cache.k[0][0, :, : start + recent].float()
+    assert torch.allclose(got_k, want_k, atol=3e-2)
+    assert torch.equal(eng.cache.v[0][0, :, :, : start + recent], before_v[:, :, kept])
+    tok = torch.randint(3, 320, (1, 1), device="cuda")
+    logits, _ = eng.decode(tok)
+    assert torch.isfinite(logits).all() and eng.cache.host_len == start + recent + 1
+    assert eng.evict_middle(start_size=start, recent_size=recent + 8) == 0                 # fits: nothing to drop
