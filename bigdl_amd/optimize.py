@@ -35,8 +35,9 @@ def _save_low_bit(self, save_dir, *args, **kwargs):
         sd = {k: (v.data if isinstance(v, nn.Parameter) else v) for k, v in self.state_dict().items()}
         torch.save(sd, os.path.join(save_dir, PYTORCH_MODEL_NAME))
         self.to(device)
+    from .transformers.low_bit_linear import tensor_qtype_overrides
     with open(os.path.join(save_dir, CONFIG_NAME), "w") as f:
-        json.dump(self._bigdl_config, f)
+        json.dump(dict(self._bigdl_config, tensor_qtypes=tensor_qtype_overrides(self)), f)
 
 
 @contextmanager
@@ -103,6 +104,8 @@ def load_low_bit(model, model_path):
     for ck in files:
         _assign_state_dict(model, load_state_dict(ck))
     _materialize_meta_buffers(model)
+    from .transformers.low_bit_linear import apply_tensor_qtype_overrides
+    apply_tensor_qtype_overrides(model, _config.get("tensor_qtypes"))
     if hasattr(model, "tie_weights"):
         try:
             head = model.get_output_embeddings()

@@ -292,7 +292,11 @@ def _replace_with_low_bit_linear(model, qtype, modules_to_not_convert=None, conv
         elif is_fused_experts(module) and qtype not in (Q.FP16, Q.BF16) and module.gate_up_proj.shape[-1] % 64 == 0 \
                 and module.down_proj.shape[-1] % 64 == 0:
             cur_qtype, cur_imatrix = get_cur_qtype_and_imatrix(qtype, full_module_name, None, model_config)
-            cur_qtype = check_hidden_size(cur_qtype, module.gate_up_proj.shape[-1])
+            # one format for the three stacked projections: both reduction sizes (hidden for gate / up, intermediate
+            # for down) have to fit its block size
+            cur_qtype = check_hidden_size(check_hidden_size(cur_qtype, module.gate_up_proj.shape[-1]), module.down_proj.shape[-1])
+            if check_hidden_size(cur_qtype, module.gate_up_proj.shape[-1]) != cur_qtype:
+                cur_qtype = Q.ASYM_INT4
             model._modules[name] = LowBitExperts.from_experts(module, cur_qtype, convert_shape_only,
                                                               enable_scale_search=enable_scale_search)
             has_been_replaced = True

@@ -354,6 +354,19 @@ class LowBitLinear(nn.Linear):
         if act_order:
             self.register_buffer("g_idx_map", torch.arange(self.in_len, dtype=torch.int64))
 
+    # the format of the weight as it is stored: with the mixed formats (mixed_fp4 / mixed_fp8) every tensor settles on
+    # one of two formats when it is quantized, and kernels have to be told that one, not the name of the mixture
+    @property
+    def qtype(self):
+        w = self._parameters.get("weight")
+        if isinstance(w, FP4Params) and w.quantized:
+            return w.qtype
+        return self._qtype
+
+    @qtype.setter
+    def qtype(self, value):
+        self._qtype = value
+
     def forward(self, x: torch.Tensor):
         is_training = self.training and not torch.is_inference_mode_enabled()
         if is_training:
@@ -446,3 +459,22 @@ class vLLMFP16Linear(FP16Linear):
 class vLLMBF16Linear(BF16Linear):
     def forward(self, x: torch.Tensor):
         return super().forward(x), None
+
+
+def tensor_qtype_overrides(model) -> dict:
+    """{module name: format name} of the low-bit linears whose stored format is not the one the model was converted
+    with (the per-tensor outcome of a mixed format): written next to a low-bit checkpoint, because the packed bytes of
+    sym_int4 / fp4 (and sym_int8 / fp8_e4m3) tensors are the same size and nothing else tells them apart."""
+    out = {}
+    for name, m in model.named_modules():
+        if isinstance(m, LowBitLinear) and isinstance(m.weight, FP4Params) and m.weight.quantized and m.weight.qtype != m._qtype:
+            out[name] = Q.qtype_name(m.weight.qtype)
+    return out
+
+
+def apply_tensor_qtype_overrides(model, overrides: dict):
+    mods = dict(model.named_modules())
+    for name, fmt in (overrides or {}).items():
+        m = mods.get(name)
+        if isinstance(m, LowBitLinear) and isinstance(m.weight, FP4Params):
+            m.weight.qtype = Q.qtype_id(fmt)

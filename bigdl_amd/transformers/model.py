@@ -102,8 +102,9 @@ def save_low_bit(self, *args, **kwargs):
             gc.save_pretrained(save_dir)
         except Exception as e:  # invalid sampling combos in third-party configs must not block a save
             logger.warning(f"generation_config not saved: {e}")
+    from .low_bit_linear import tensor_qtype_overrides
     with open(os.path.join(save_dir, "load_keys.json"), "w") as f:
-        json.dump({"all_checkpoint_keys": list(sd.keys())}, f)
+        json.dump({"all_checkpoint_keys": list(sd.keys()), "tensor_qtypes": tensor_qtype_overrides(self)}, f)
     if origin_device.type != "cpu":
         self.to(origin_device)
 
@@ -512,7 +513,10 @@ class _BaseAutoModelClass:
         keys_file = os.path.join(str(pretrained_model_name_or_path), subfolder, "load_keys.json")
         if os.path.isfile(keys_file):
             with open(keys_file) as fk:
-                expected = json.load(fk).get("all_checkpoint_keys", [])
+                keys_doc = json.load(fk)
+            expected = keys_doc.get("all_checkpoint_keys", [])
+            from .low_bit_linear import apply_tensor_qtype_overrides
+            apply_tensor_qtype_overrides(model, keys_doc.get("tensor_qtypes"))       # mixed formats: per-tensor outcome
             absent = [k for k in expected if k not in loaded]
             invalidInputError(not absent, f"checkpoint is incomplete, missing tensors: {absent[:5]} ...")
         _materialize_meta_buffers(model)

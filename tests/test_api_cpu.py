@@ -387,3 +387,33 @@ def test_tied_embedding_model_keeps_its_low_bit_head(tmp_path):
         g2 = load_low_bit(shell, str(tmp_path / "lb2"))
         assert isinstance(g2.lm_head.weight, FP4Params)
         assert (g2(ids).logits - ref).abs().max() / ref.abs().max() < 0.05
+
+
+def test_mixed_format_checkpoint_remembers_the_format_of_every_tensor(tmp_path):
+    """mixed_fp4: each tensor settles on sym_int4 or fp4 (same packed size).  The module reports the settled format (the
+    GPU kernels are dispatched on it), and save_low_bit / load_low_bit carry the per-tensor outcome."""
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from bigdl_amd import qtypes as Q
+    from bigdl_amd.transformers import AutoModelForCausalLM
+    from bigdl_amd.transformers.low_bit_linear import LowBitLinear
+    torch.manual_seed(0)
+    cfg = LlamaConfig(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=4,
+                      num_key_value_heads=2)
+    m = LlamaForCausalLM(cfg).eval()
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if "up_proj" in n or "o_proj" in n:
+                p.copy_(torch.randn_like(p) ** 3 * 0.02)            # heavy tails: the fp format reconstructs these better
+    m.save_pretrained(tmp_path / "hf")
+    q = AutoModelForCausalLM.from_pretrained(str(tmp_path / "hf"), load_in_low_bit="mixed_fp4")
+    kinds = {n: mod.qtype for n, mod in q.named_modules() if isinstance(mod, LowBitLinear)}
+    assert set(kinds.values()) == {Q.SYM_INT4, Q.FP4}
+    assert all(mod.qtype == mod.weight.qtype for mod in q.modules() if isinstance(mod, LowBitLinear))
+    ids = torch.randint(0, 320, (1, 8))
+    with torch.no_grad():
+        out = q(ids).logits
+    q.save_low_bit(str(tmp_path / "lb"))
+    r = AutoModelForCausalLM.load_low_bit(str(tmp_path / "lb"))
+    assert {n: mod.qtype for n, mod in r.named_modules() if isinstance(mod, LowBitLinear)} == kinds
+    with torch.no_grad():
+        assert torch.equal(r(ids).logits, out)

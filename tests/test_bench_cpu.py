@@ -14,8 +14,15 @@ def _bench(*flags):
     env = dict(os.environ, BIGDL_FORCE_CPU="1", PYTHONPATH=ROOT)
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--model", "tiny", "--steps", "1", "--warmup", "0",
-                        "--in-len", "16", "--out-len", "4", *flags], env=env, capture_output=True, text=True, timeout=600)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--model", "tiny", "--steps", "1", "--warmup", "0",
+           "--in-len", "16", "--out-len", "4", *flags]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    if r.returncode != 0 and "--gpus" in flags:
+        # the launcher picks a free rendezvous port and releases it before the ranks bind it: another process of a busy
+        # test run can take it in between.  One more try on a new port; a real defect fails twice.
+        first = r.stderr[-1500:]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, first + "\n--- second attempt ---\n" + r.stderr[-1500:]
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout          # rank 0 prints exactly one JSON line
