@@ -297,6 +297,8 @@ def _replace_with_low_bit_linear(model, qtype, modules_to_not_convert=None, conv
             cur_qtype = check_hidden_size(check_hidden_size(cur_qtype, module.gate_up_proj.shape[-1]), module.down_proj.shape[-1])
             if check_hidden_size(cur_qtype, module.gate_up_proj.shape[-1]) != cur_qtype:
                 cur_qtype = Q.ASYM_INT4
+            # (the routed kernels read all experts of a layer in one format: a mixture resolves to its integer member)
+            cur_qtype = {Q.MOFQ4: Q.SYM_INT4, Q.MOFQ8: Q.SYM_INT8}.get(cur_qtype, cur_qtype)
             model._modules[name] = LowBitExperts.from_experts(module, cur_qtype, convert_shape_only,
                                                               enable_scale_search=enable_scale_search)
             has_been_replaced = True
