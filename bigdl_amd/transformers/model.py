@@ -40,6 +40,11 @@ def _state_dict_for_save(model):
     for k, v in model.state_dict().items():
         t = v.data if isinstance(v, torch.nn.Parameter) else v
         sd[k] = t.detach()
+    # an embedding that lives in a file (DiskEmbedding keeps an empty placeholder as its parameter) is written out whole
+    from .embedding import DiskEmbedding
+    for name, mod in model.named_modules():
+        if isinstance(mod, DiskEmbedding) and f"{name}.weight" in sd:
+            sd[f"{name}.weight"] = mod.to_embedding().weight.data
     # tied weights are stored once (HF convention): drop lm_head when it aliases the embedding
     tied = getattr(model.config, "tie_word_embeddings", False)
     if tied and "lm_head.weight" in sd:
@@ -395,7 +400,12 @@ class _BaseAutoModelClass:
         if disk_embedding:
             from .embedding import DiskEmbedding
             DiskEmbedding.replace_normal_embedding(model)
-        model.config.update({"bigdl_transformers_low_bit": q_k, "bigdl_disk_embedding": disk_embedding})
+        model.config.update({"bigdl_transformers_low_bit": q_k, "bigdl_disk_embedding": disk_embedding,
+                             # what load_low_bit has to repeat to rebuild the same module tree (its keyword arguments
+                             # of the same names override these)
+                             "bigdl_convert_options": {"optimize_model": bool(optimize_model),
+                                                       "modules_to_not_convert": list(modules_to_not_convert or []),
+                                                       "mixed_precision": bool(mixed_precision)}})
         if getattr(model.config, "tie_word_embeddings", False) and not cpu_embedding and embedding_qtype is None:
             # a head that stayed a plain nn.Linear shares its weight with the embedding again (the dtype pass above
             # made two copies); a converted head owns packed low-bit blocks, which re-tying would overwrite with the
@@ -442,7 +452,7 @@ class _BaseAutoModelClass:
     def load_low_bit(cls, pretrained_model_name_or_path, *model_args, **kwargs):
         """Load a directory written by ``save_low_bit``."""
         from .convert import ggml_convert_low_bit
-        optimize_model = kwargs.pop("optimize_model", True)
+        optimize_model = kwargs.pop("optimize_model", None)
         modules_to_not_convert = kwargs.pop("modules_to_not_convert", None)
         cpu_embedding = kwargs.pop("cpu_embedding", False)
         embedding_qtype = kwargs.pop("embedding_qtype", None)
@@ -453,7 +463,7 @@ class _BaseAutoModelClass:
         trust_remote_code = kwargs.pop("trust_remote_code", False)
         subfolder = kwargs.pop("subfolder", "")
         variant = kwargs.pop("variant", None)
-        mixed_precision = kwargs.pop("mixed_precision", False)
+        mixed_precision = kwargs.pop("mixed_precision", None)
         config = kwargs.pop("config", None)
         if config is None and isinstance(pretrained_model_name_or_path, str) and os.path.isfile(
                 os.path.join(pretrained_model_name_or_path, "config.json")):
@@ -467,6 +477,11 @@ class _BaseAutoModelClass:
                                                             trust_remote_code=trust_remote_code)
         config_dict = config.to_dict()
         bigdl_transformers_low_bit = config_dict.pop("bigdl_transformers_low_bit", False)
+        saved = config_dict.pop("bigdl_convert_options", None) or {}
+        optimize_model = saved.get("optimize_model", True) if optimize_model is None else optimize_model
+        mixed_precision = saved.get("mixed_precision", False) if mixed_precision is None else mixed_precision
+        if modules_to_not_convert is None:
+            modules_to_not_convert = saved.get("modules_to_not_convert") or None
         invalidInputError(bigdl_transformers_low_bit,
                           "Detect this model is not a low-bit model, Please use from_pretrained"
                           " with load_in_4bit or load_in_low_bit to get a low-bit model , and "

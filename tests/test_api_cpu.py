@@ -417,3 +417,28 @@ def test_mixed_format_checkpoint_remembers_the_format_of_every_tensor(tmp_path):
     assert {n: mod.qtype for n, mod in r.named_modules() if isinstance(mod, LowBitLinear)} == kinds
     with torch.no_grad():
         assert torch.equal(r(ids).logits, out)
+
+
+@pytest.mark.parametrize("tied", [False, True])
+@pytest.mark.parametrize("kw", [dict(optimize_model=False), dict(modules_to_not_convert=["lm_head"]), dict(mixed_precision=True),
+                                dict(disk_embedding=True), dict(cpu_embedding=True)],
+                         ids=["no_opt", "dense_head", "mixed_precision", "disk_embedding", "cpu_embedding"])
+def test_low_bit_checkpoint_describes_how_it_was_converted(tmp_path, tied, kw):
+    """A low-bit checkpoint reloads into the module tree it was saved from without the caller repeating
+    ``optimize_model`` / ``modules_to_not_convert`` / ``mixed_precision`` (they are kept in its config; keyword arguments of
+    the same names still override), and an embedding that lives in a file is written out whole."""
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from bigdl_amd.transformers import AutoModelForCausalLM
+    torch.manual_seed(0)
+    cfg = LlamaConfig(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=4,
+                      num_key_value_heads=2, tie_word_embeddings=tied)
+    LlamaForCausalLM(cfg).eval().save_pretrained(tmp_path / "hf")
+    ids = torch.randint(0, 320, (1, 8))
+    q = AutoModelForCausalLM.from_pretrained(str(tmp_path / "hf"), load_in_low_bit="sym_int4", **kw)
+    with torch.no_grad():
+        out = q(ids).logits
+    q.save_low_bit(str(tmp_path / "lb"))
+    r = AutoModelForCausalLM.load_low_bit(str(tmp_path / "lb"), **({"cpu_embedding": True} if kw.get("cpu_embedding") else {}))
+    with torch.no_grad():
+        assert torch.equal(r(ids).logits, out)
+    assert [n for n, _ in r.named_modules()] == [n for n, _ in q.named_modules()]

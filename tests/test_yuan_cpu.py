@@ -126,12 +126,13 @@ def test_gguf_yuan2_builder(tmp_path):
     ref = m(ids).logits
     got = model(ids).logits
     torch.testing.assert_close(got, ref, rtol=2e-2, atol=2e-2)          # fp16 storage of the linears
-    assert model.generate(ids, max_new_tokens=3).shape == (1, 10)
+    assert model.generate(ids, max_new_tokens=3, min_new_tokens=3).shape == (1, 10)
     assert tok is not None and "<FIM_MIDDLE>" in tok.get_vocab()
 
 
 def test_auto_classes_load_yuan_checkpoints_in_low_bit(tmp_path):
     from bigdl_amd.transformers import AutoModelForCausalLM
+    torch.manual_seed(0)                 # (unseeded, a random model now and then emits EOS early or lands a hair under the bound)
     m = _tiny()
     ids = torch.randint(0, 96, (1, 6))
     ref = m(ids).logits
@@ -141,4 +142,4 @@ def test_auto_classes_load_yuan_checkpoints_in_low_bit(tmp_path):
     assert hasattr(q.model.layers[0].self_attn, "v_proj")            # q / k / v stay separate: they read different streams
     cos = torch.nn.functional.cosine_similarity(q(ids).logits.flatten(), ref.flatten(), dim=0)
     assert cos > 0.999
-    assert q.generate(ids, max_new_tokens=3).shape == (1, 9)
+    assert q.generate(ids, max_new_tokens=3, min_new_tokens=3).shape == (1, 9)
