@@ -1,6 +1,6 @@
-"""The prompt-sized fused low-bit GEMM (gemm_lowbit_big) against dequantize + hipBLASLt and hipBLASLt alone on the
+"""The prompt-sized fused low-bit GEMM (gemm_prompt) against dequantize + hipBLASLt and hipBLASLt alone on the
 Llama-2-7B projection shapes; also checks the result against the dequantized product.
-    PYTHONPATH=. python benchmark/gemm_big_bench.py [--ms 512,1024,2048] [--qtype sym_int4]"""
+    PYTHONPATH=. python benchmark/gemm_big_bench.py [--ms 512,1024,2048] [--qtype sym_int4] [--sweep]"""
 import argparse
 import json
 
@@ -30,6 +30,8 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--qtype", default="sym_int4")
     ap.add_argument("--ms", default="1024")
+    ap.add_argument("--sweep", action="store_true", help="every tile configuration / K split instead of the planned one")
+    ap.add_argument("--no-ref", action="store_true", help="skip the library comparisons")
     args = ap.parse_args()
     qt = Q.ggml_tensor_qtype[args.qtype]
     gen = torch.Generator(device="cuda").manual_seed(0)
@@ -39,15 +41,22 @@ if __name__ == "__main__":
         for m in [int(v) for v in args.ms.split(",")]:
             x = torch.randn(m, k, device="cuda", dtype=torch.float16)
             ref = torch.nn.functional.linear(x.float(), wd.float())
-            got = hip.gemm_lowbit_big(x, w, qt, n, k).float()
-            err = ((got - ref).abs().max() / ref.abs().max()).item()
-            us_big = timed(lambda: hip.gemm_lowbit_big(x, w, qt, n, k))
-            us_small = timed(lambda: hip.gemm_lowbit(x, w, qt, n, k)) if m <= 256 else None
-            us_dense = timed(lambda: torch.nn.functional.linear(x, hip.dequant_t16(w, qt, n, k)))
-            us_blas = timed(lambda: torch.nn.functional.linear(x, wd))
-            print(json.dumps({"qtype": args.qtype, "shape": name, "M": m, "N": n, "K": k, "max_rel_err": round(err, 5),
-                              "splitk": hip.lib().bigdl_gemm_lowbit_big_splitk(m, n, k),
-                              "fused_big_us": round(us_big, 1), "fused_rows_le_256_us": us_small and round(us_small, 1), "dequant_plus_hipblaslt_us": round(us_dense, 1),
-                              "hipblaslt_only_us": round(us_blas, 1),
-                              "fused_big_tflops": round(2.0 * m * n * k / us_big / 1e6, 1),
-                              "dequant_plus_hipblaslt_tflops": round(2.0 * m * n * k / us_dense / 1e6, 1)}), flush=True)
+            forces = [(-1, 0)]
+            if args.sweep:
+                forces += [(c, sk) for c in (0, 1, 2) for sk in (1, 2, 4) if sk == 1 or k // 128 // sk >= 8]
+            us_dense = us_blas = None
+            if not args.no_ref:
+                us_dense = timed(lambda: torch.nn.functional.linear(x, hip.dequant_t16(w, qt, n, k)))
+                us_blas = timed(lambda: torch.nn.functional.linear(x, wd))
+            for cfg, sk in forces:
+                hip.gemm_prompt_force(cfg, sk)
+                got = hip.gemm_prompt(x, w, qt, n, k).float()
+                err = ((got - ref).abs().max() / ref.abs().max()).item()
+                us = timed(lambda: hip.gemm_prompt(x, w, qt, n, k))
+                plan = hip.gemm_prompt_plan(m, n, k)
+                hip.gemm_prompt_force()
+                print(json.dumps({"qtype": args.qtype, "shape": name, "M": m, "N": n, "K": k, "forced": cfg >= 0,
+                                  "cfg": plan[0], "splitk": plan[1], "max_rel_err": round(err, 5),
+                                  "fused_us": round(us, 1), "fused_tflops": round(2.0 * m * n * k / us / 1e6, 1),
+                                  "dequant_plus_hipblaslt_us": us_dense and round(us_dense, 1),
+                                  "hipblaslt_only_us": us_blas and round(us_blas, 1)}), flush=True)

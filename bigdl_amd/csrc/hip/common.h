@@ -253,13 +253,13 @@ struct T16Planes {
   const _Float16* mn;
 };
 
-__host__ __device__ inline int lo_bits_of(int qtype) {
+__host__ __device__ constexpr inline int lo_bits_of(int qtype) {
   return (qtype == Q_SYM_INT8 || qtype == Q_FP8_E4M3 || qtype == Q_FP8_E5M2) ? 8 : 4;
 }
-__host__ __device__ inline int hi_bits_of(int qtype) {
+__host__ __device__ constexpr inline int hi_bits_of(int qtype) {
   return (qtype == Q_SYM_INT5 || qtype == Q_ASYM_INT5) ? 1 : (qtype == Q_FP6 ? 2 : 0);
 }
-__host__ __device__ inline bool has_min_of(int qtype) {
+__host__ __device__ constexpr inline bool has_min_of(int qtype) {
   return qtype == Q_ASYM_INT4 || qtype == Q_ASYM_INT5 || qtype == Q_WOQ_INT4;
 }
 __host__ __device__ inline bool is_t16(int qtype) {

@@ -352,10 +352,10 @@ class NativeDecoder:
         self.cache: Optional[KVCache] = None
         self._graphs = {}
         self._static = {}
-        # ``BIGDL_PREFILL_FUSED=1``: prompt GEMMs above GEMM_MAX_ROWS rows on the fused prompt-sized kernel instead of
-        # dequantize + hipBLASLt.  No fp16 scratch copy of a weight (0.18 GB less peak memory on Llama-2-7B) and no library
-        # GEMM, but the first token of a 1024-token prompt takes 20.6 instead of 19.3 ms: off by default.
-        self.prefill_fused = os.environ.get("BIGDL_PREFILL_FUSED", "0") == "1"
+        # prompt GEMMs above GEMM_MAX_ROWS rows run on the fused prompt-sized kernel (csrc/hip/gemm_prompt_kernel.h): no
+        # fp16 scratch copy of a weight and no library GEMM.  ``BIGDL_PREFILL_LIBRARY=1`` selects dequantize + hipBLASLt
+        # instead (A/B measurements).
+        self.prefill_fused = os.environ.get("BIGDL_PREFILL_LIBRARY", "0") != "1"
         # ``BIGDL_DEQUANT_AHEAD=1``: while the library GEMM of one weight runs, the next weight of the prompt pass is
         # expanded to fp16 on a second stream into the other of two scratch buffers.  Measured on Llama-2-7B at 1024
         # prompt tokens: first token 19.4 against 17.5 ms (18.8 with the side stream at equal priority on another box):
@@ -506,10 +506,11 @@ class NativeDecoder:
         if lin.fused and x.shape[0] <= GEMM_MAX_ROWS:
             return hip.gemm_lowbit(x.contiguous(), lin.w, lin.qtype, lin.n, lin.k, bias=lin.bias)
         if lin.fused and self.prefill_fused and x.dtype == torch.float16 and x.dim() == 2 and not Lin.cache_dense \
-                and hip.gemm_lowbit_big_supported(lin.qtype, lin.k):
-            # prompt-sized rows: the 128 x 192 / 256-tile fused kernel (weights expanded in registers; no fp16 copy of
-            # the weight is written or read, no library GEMM)
-            return hip.gemm_lowbit_big(x.contiguous(), lin.w, lin.qtype, lin.n, lin.k, bias=lin.bias)
+                and not self.prefill_fp8:
+            # prompt-sized rows: the fused prompt kernel (weights expanded once per workgroup into LDS; no fp16 copy of the
+            # weight is written or read, no library GEMM)
+            from ..transformers.low_bit_linear import lowbit_rows
+            return lowbit_rows(x.contiguous(), lin.w, lin.qtype, lin.n, lin.k, bias=lin.bias)
         m = x.shape[0]
         if lin.fused and m > 4096 and x.dim() == 2 and not self.prefill_fp8:
             # hipBLASLt falls off a cliff right above 4096 rows (4100 - 4352 rows: 402 - 439 us against 272 at 4096 on the

@@ -63,9 +63,12 @@ def lib():
         L.bigdl_gemv_lowbit_moe.argtypes = [vp, vp, vp, vp, vp, vp, vp, cf, cf, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp]
         L.bigdl_gemm_lowbit.argtypes = [vp, vp, vp, vp, vp, vp, i64, ci, ci, ci, ci, ci, ci, ci, ci, vp]
         L.bigdl_gemm_lowbit_splitk.argtypes = [ci, ci, ci]
-        L.bigdl_gemm_lowbit_big.argtypes = [vp, vp, vp, vp, vp, vp, i64, ci, ci, ci, ci, ci, ci, ci, ci, vp]
-        L.bigdl_gemm_lowbit_big_splitk.argtypes = [ci, ci, ci]
-        L.bigdl_gemm_lowbit_big_supported.argtypes = [ci, ci]
+        L.bigdl_gemm_prompt.argtypes = [vp, vp, vp, vp, vp, vp, i64, ci, ci, ci, ci, ci, ci, ci, ci, vp]
+        L.bigdl_gemm_prompt_slabs.argtypes = [ci, ci, ci, ci, ci, ci]
+        L.bigdl_gemm_prompt_supported.argtypes = [ci, ci]
+        L.bigdl_gemm_prompt_plan.argtypes = [ci, ci, ci, ctypes.POINTER(ci), ctypes.POINTER(ci)]
+        L.bigdl_gemm_prompt_force.argtypes = [ci, ci]
+        L.bigdl_gemm_prompt_force.restype = None
         L.bigdl_gemm_lowbit_ex.argtypes = [vp] * 8 + [cf, cf, vp, vp, vp, i64] + [ci] * 8 + [vp]
         L.bigdl_gemm_lowbit_ex_splitk.argtypes = [ci, ci, ci, ci]
         L.bigdl_gemm_lowbit_bm.argtypes = [ci]
@@ -287,21 +290,36 @@ def gemm_lowbit(x, w, qtype, out_features, in_features, *, bias=None, residual=N
     return out
 
 
-def gemm_lowbit_big_supported(qtype, in_features) -> bool:
-    return bool(lib().bigdl_gemm_lowbit_big_supported(int(qtype), int(in_features)))
+def gemm_prompt_supported(qtype, in_features) -> bool:
+    """every tiled format, K a multiple of 128 and at least 256"""
+    return bool(lib().bigdl_gemm_prompt_supported(int(qtype), int(in_features)))
 
 
-def gemm_lowbit_big(x, w, qtype, out_features, in_features, *, bias=None, residual=None, act=None, out=None,
-                    out_dtype=None):
-    """``y = act(x @ dequant(w)^T + bias) [+ residual]`` on the prompt-sized MFMA GEMM (128 x 256 tiles, x through
-    ``global_load_lds``): x [M, K] fp16, meant for M >= 256; 4-bit formats, K % 128 == 0.  w: T16 device buffer."""
+def gemm_prompt_plan(m, out_features, in_features):
+    """(tile configuration, K splits) the prompt GEMM will use: 0 = 256 x 256, 1 = 256 x 192, 2 = 128 x 128 tiles"""
+    cfg, sk = ctypes.c_int(0), ctypes.c_int(0)
+    lib().bigdl_gemm_prompt_plan(int(m), int(out_features), int(in_features), ctypes.byref(cfg), ctypes.byref(sk))
+    return cfg.value, sk.value
+
+
+def gemm_prompt_force(cfg=-1, splitk=0):
+    """pin the tile configuration / K splits of the following ``gemm_prompt`` calls (tests, sweeps); no arguments: planned"""
+    lib().bigdl_gemm_prompt_force(int(cfg), int(splitk))
+
+
+def gemm_prompt(x, w, qtype, out_features, in_features, *, bias=None, residual=None, act=None, out=None,
+                out_dtype=None):
+    """``y = act(x @ dequant(w)^T + bias) [+ residual]`` on the prompt-sized fused MFMA GEMM (csrc/hip/
+    gemm_prompt_kernel.h: 256 x 256 / 256 x 192 / 128 x 128 tiles, x through ``global_load_lds``, weights expanded once
+    per workgroup into LDS): x [M, K] fp16, meant for M > 256; K % 128 == 0.  w: T16 device buffer.  The reference's
+    one native op for every row count: python/llm/src/ipex_llm/transformers/low_bit_linear.py:657-668."""
     _need_cuda(x, w, bias, residual, out)
     if x.dim() != 2 or x.dtype != torch.float16 or x.stride(1) != 1:
         raise ValueError("x must be a 2-D fp16 tensor with contiguous rows")
     m, k = x.shape
     if k != in_features:
         raise ValueError(f"x has {k} features, weight expects {in_features}")
-    if not gemm_lowbit_big_supported(qtype, k):
+    if not gemm_prompt_supported(qtype, k):
         raise ValueError(f"qtype {qtype} / K = {k} has no prompt-sized fused GEMM kernel")
     from .host import device_nbytes
     if w.numel() * w.element_size() != device_nbytes(qtype, out_features, in_features):
@@ -317,15 +335,21 @@ def gemm_lowbit_big(x, w, qtype, out_features, in_features, *, bias=None, residu
                                  or residual.stride() != out.stride()):
         raise ValueError("residual must match out")
     L = lib()
-    sk = L.bigdl_gemm_lowbit_big_splitk(m, out_features, k)
+    aligned = (out.data_ptr() % 16 == 0) and (residual is None or residual.data_ptr() % 16 == 0)
+    slabs = L.bigdl_gemm_prompt_slabs(m, out_features, k, out.stride(0), _out_type(out_dtype), int(aligned))
     ws, ws_n = None, 0
-    if sk > 1:
-        ws = _gemm_workspace(x.device, sk * m * out_features)
+    if slabs > 0:
+        ws = _gemm_workspace(x.device, slabs * m * out_features)
         ws_n = ws.numel()
-    rc = L.bigdl_gemm_lowbit_big(_ptr(x), _ptr(w), _ptr(out), _ptr(bias), _ptr(residual), _ptr(ws), ws_n, m, out_features, k,
-                                 x.stride(0), out.stride(0), qtype, ACT[act], _out_type(out_dtype), _stream())
-    _check(rc, "gemm_lowbit_big")
+    rc = L.bigdl_gemm_prompt(_ptr(x), _ptr(w), _ptr(out), _ptr(bias), _ptr(residual), _ptr(ws), ws_n, m, out_features, k,
+                             x.stride(0), out.stride(0), qtype, ACT[act], _out_type(out_dtype), _stream())
+    _check(rc, "gemm_prompt")
     return out
+
+
+# earlier names of the same entry points
+gemm_lowbit_big = gemm_prompt
+gemm_lowbit_big_supported = gemm_prompt_supported
 
 
 def gemm_lowbit_ex(x, w, qtype, out_features, in_features, *, w2=None, bias=None, bias2=None, residual=None, gamma=None,

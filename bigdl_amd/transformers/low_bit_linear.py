@@ -258,6 +258,19 @@ def dequant_weight_rows(weight: FP4Params, row0: int, nrows: int, dtype=torch.fl
     return host.dequantize(sl, weight.qtype, (nrows, k)).to(dtype)
 
 
+def lowbit_rows(xh, w, qtype, n, k, bias=None, out_dtype=None):
+    """More than GEMM_MAX_ROWS fp16 rows times a T16 weight on this repository's own kernels: the prompt-sized fused GEMM
+    where it applies (K a multiple of 128), otherwise the mid-size fused GEMM GEMM_MAX_ROWS rows at a time."""
+    from ..ops import hip
+    if hip.gemm_prompt_supported(qtype, k):
+        return hip.gemm_prompt(xh, w, qtype, n, k, bias=bias, out_dtype=out_dtype)
+    m = xh.shape[0]
+    y = torch.empty(m, n, dtype=out_dtype or torch.float16, device=xh.device)
+    for r0 in range(0, m, GEMM_MAX_ROWS):
+        hip.gemm_lowbit(xh[r0:r0 + GEMM_MAX_ROWS], w, qtype, n, k, bias=bias, out=y[r0:r0 + GEMM_MAX_ROWS])
+    return y
+
+
 def lowbit_matmul(x_2d: torch.Tensor, weight: FP4Params, out_features: int) -> torch.Tensor:
     """``x_2d @ dequant(weight)^T`` -> dtype of x_2d (reference op ``xe_linear.forward_new``)."""
     n, k = weight._shape
@@ -271,6 +284,14 @@ def lowbit_matmul(x_2d: torch.Tensor, weight: FP4Params, out_features: int) -> t
             if m <= GEMV_MAX_ROWS:
                 return hip.gemv_lowbit(xh, weight.data, weight.qtype, n, k, out_dtype=x_2d.dtype)
             return hip.gemm_lowbit(xh, weight.data, weight.qtype, n, k, out_dtype=x_2d.dtype)
+        if weight.qlayout == "t16" and not torch.is_grad_enabled() and getattr(weight, "_dense_cache", None) is None:
+            # prompt-sized rows: the fused kernels take every row count (reference: one native op,
+            # low_bit_linear.py:657-668); no fp16 copy of the weight is written and no library GEMM runs.  (Training keeps
+            # the dense product below: its backward needs the expanded weight anyway.)
+            xh = x_2d if x_2d.dtype == torch.float16 else x_2d.to(torch.float16)
+            if xh.stride(1) != 1 or xh.stride(0) % 8 or xh.data_ptr() % 16:
+                xh = xh.contiguous()
+            return lowbit_rows(xh, weight.data, weight.qtype, n, k, out_dtype=x_2d.dtype)
         cdt = x_2d.dtype if x_2d.dtype in (torch.float16, torch.bfloat16) else torch.float16
         w = dequant_weight(weight, cdt)
         xc = x_2d.to(cdt)

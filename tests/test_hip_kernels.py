@@ -891,29 +891,3 @@ def test_argmax_split_rows_and_fused_increment(hip, rows, v, dtype):
     assert out[rows - 1].item() == v - 1
     assert dst.cpu().tolist() == [0 + 6, 1, 2 + 6, 3 + 6, 4, 5 + 6]
     assert torch.equal(hip.argmax(x).cpu(), out.cpu())
-
-
-@pytest.mark.parametrize("qname", ["sym_int4", "asym_int4", "nf4", "fp4", "woq_int4"])
-@pytest.mark.parametrize("m,n,k", [(1024, 4096, 4096), (300, 1000, 1024), (513, 11008, 4096), (256, 4096, 11008)])
-def test_gemm_lowbit_big_matches_dequantized_product(hip, qname, m, n, k):
-    """The prompt-sized fused GEMM (128 x 192 / 256 tiles, x through global_load_lds, split K on small grids) against the
-    fp32 product with the dequantized weight; partial row / column tiles, bias, activation and residual epilogues."""
-    from bigdl_amd.models.decoder import _random_t16
-    torch.manual_seed(11)
-    qt = Q.ggml_tensor_qtype[qname]
-    if qname != "sym_int4" and (m, n, k) != (300, 1000, 1024):
-        pytest.skip("other formats: one shape")
-    w = _random_t16(n, k, qt, torch.device("cuda"), torch.Generator(device="cuda").manual_seed(5), scale=0.02).data
-    wd = hip.dequant_t16(w, qt, n, k).float()
-    x = torch.randn(m, k, device="cuda", dtype=torch.float16)
-    ref = x.float() @ wd.t()
-    got = hip.gemm_lowbit_big(x, w, qt, n, k).float()
-    tol = 2e-3 * ref.abs().max().item()
-    assert (got - ref).abs().max().item() < tol
-    bias = torch.randn(n, device="cuda", dtype=torch.float16)
-    res = torch.randn(m, n, device="cuda", dtype=torch.float16)
-    got2 = hip.gemm_lowbit_big(x, w, qt, n, k, bias=bias, residual=res, act="silu").float()
-    ref2 = torch.nn.functional.silu(ref + bias.float()) + res.float()
-    assert (got2 - ref2).abs().max().item() < 2e-3 * ref2.abs().max().item() + 2e-2
-    got3 = hip.gemm_lowbit_big(x, w, qt, n, k, out_dtype=torch.float32)
-    assert (got3 - ref).abs().max().item() < tol
