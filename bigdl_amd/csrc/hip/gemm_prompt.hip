@@ -32,14 +32,15 @@ static int prompt_dispatch(const GemmArgs& a, int qtype, int cfg, hipStream_t st
 // Tile configurations (gemm_prompt_launch<QT> instantiates them in this order) and their relative MFMA efficiency
 // (measured: benchmark/gemm_big_bench.py --sweep).  One workgroup per CU for the 8-wavefront tiles.
 struct PromptCfg { int bm, bn; double eff; };
-static const PromptCfg kPromptCfgs[PROMPT_NCFG] = {{256, 256, 1.0}, {256, 192, 0.97}, {128, 128, 0.70}};
+static const PromptCfg kPromptCfgs[PROMPT_NCFG] = {{256, 256, 1.0}, {256, 192, 0.79}, {128, 128, 0.50}};
 
 struct PromptPlan { int cfg, splitk, kt_per_split; };
 static int g_force_cfg = -1, g_force_sk = 0;         // bigdl_gemm_prompt_force (tests / sweeps)
 
 // Cost of a launch in units of (output element x 128-deep k tile) per CU: rounds of 256 concurrent tiles, every tile
 // paying its k tiles + a fixed prologue / epilogue; K splits add the fp32 slab traffic and the reduce launch.
-static PromptPlan prompt_plan(int M, int N, int K) {
+// pair: the gate / up form (two products per output column: blocks cover bn / 2 output columns, no K split)
+static PromptPlan prompt_plan(int M, int N, int K, bool pair = false) {
   const int KT = K >> 7;
   static const int env_cfg = getenv("BIGDL_PROMPT_CFG") ? atoi(getenv("BIGDL_PROMPT_CFG")) : -1;
   static const int env_sk = getenv("BIGDL_PROMPT_SPLITK") ? atoi(getenv("BIGDL_PROMPT_SPLITK")) : 0;
@@ -49,14 +50,15 @@ static PromptPlan prompt_plan(int M, int N, int K) {
   for (int c = 0; c < PROMPT_NCFG; ++c) {
     if (forced_cfg >= 0 && c != forced_cfg) continue;
     const PromptCfg& pc = kPromptCfgs[c];
-    const int64_t tiles = (int64_t)((M + pc.bm - 1) / pc.bm) * ((N + pc.bn - 1) / pc.bn);
-    for (int sk = 1; sk <= 8; ++sk) {
+    const int bno = pair ? pc.bn / 2 : pc.bn;
+    const int64_t tiles = (int64_t)((M + pc.bm - 1) / pc.bm) * ((N + bno - 1) / bno);
+    for (int sk = 1; sk <= (pair ? 1 : 8); ++sk) {
       if (forced_sk ? sk != forced_sk : (sk > 1 && KT / sk < 8)) continue;
       if (sk > KT) continue;
       const int per = (KT + sk - 1) / sk, rsk = (KT + per - 1) / per;
       const int64_t rounds = (tiles * rsk + 255) / 256;
       double cost = (double)rounds * pc.bm * pc.bn / pc.eff * (per + 1.5);
-      if (rsk > 1) cost += 0.052 * rsk * (double)M * N + 6e4;
+      if (rsk > 1) cost += 0.035 * rsk * (double)M * N + 6e4;
       if (cost < best_cost) { best_cost = cost; best = {c, rsk, per}; }
     }
   }
@@ -96,6 +98,27 @@ extern "C" int bigdl_gemm_prompt_plan(int M, int N, int K, int* cfg, int* splitk
   if (cfg) *cfg = pl.cfg;
   if (splitk) *splitk = pl.splitk;
   return 0;
+}
+
+// Gate / up pair in one launch: out[M, N] = act(x W^T + bias) * (x W2^T + bias2), both weights [N, K] of one format,
+// N % 16 == 0; 16-bit output with N % 8 == 0, ldo % 8 == 0 and a 16-byte aligned out (the staged epilogue; -7 otherwise).
+extern "C" int bigdl_gemm_prompt_pair(const void* x, const void* w, const void* w2, void* out, const void* bias,
+                                      const void* bias2, int M, int N, int K, int ldx, int ldo, int qtype, int act,
+                                      int out_type, hipStream_t stream) {
+  qtype = t16_kernel_qtype(qtype);
+  if (M <= 0 || N <= 0 || (N & 15) || K < 256 || (K & 127) || (ldx & 7) || ((uintptr_t)x & 15) || ((uintptr_t)w & 15) ||
+      w2 == nullptr || ((uintptr_t)w2 & 15))
+    return -1;
+  if ((bias != nullptr && ((uintptr_t)bias & 7)) || (bias2 != nullptr && ((uintptr_t)bias2 & 7))) return -1;
+  if (out_type != OUT_F16 && out_type != OUT_BF16) return -3;
+  if (!prompt_staged_ok(N, ldo, out_type, out, nullptr)) return -7;
+  if ((int64_t)M * ldx >= (1ll << 31)) return -6;
+  GemmArgs a = {};
+  a.x = (const _Float16*)x; a.w = w; a.w2 = w2; a.out = out; a.bias = bias; a.bias2 = bias2;
+  a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldo = ldo; a.act = act; a.out_type = out_type;
+  const PromptPlan pl = prompt_plan(M, N, K, true);
+  a.splitk = 1; a.kt_per_split = K >> 7;
+  return prompt_dispatch(a, qtype, pl.cfg, stream);
 }
 
 // x fp16 [M, ldx] (ldx % 8 == 0, 16-byte aligned), K % 128 == 0.  workspace: fp32, >= slabs * M * N floats.

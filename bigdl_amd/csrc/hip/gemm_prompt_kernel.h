@@ -88,7 +88,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_prompt_kernel(GemmArgs a
   const int wm = wave / WN, wn = wave % WN;
   const int r = lane & 15, g = lane >> 4;
   const int KT = a.K >> 7;                          // host: K % 128 == 0
-  const int nmb = (a.M + BM - 1) / BM, nnb = (a.N + BN - 1) / BN;
+  // pair form (a.w2: gate / up): the block's first RT / 2 weight tile rows come from w, the others from the same rows of
+  // w2, and the epilogue writes act(first) * second: BN / 2 output columns per block
+  const bool pair = a.w2 != nullptr;
+  const int BNO = pair ? BN / 2 : BN;
+  const int nmb = (a.M + BM - 1) / BM, nnb = (a.N + BNO - 1) / BNO;
 
   // XCD-aware tile order: blocks b and b + 8 share an L2; consecutive tile ids (row blocks of one column panel first)
   // go to one XCD (bijective also when the grid is not a multiple of 8)
@@ -102,6 +106,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_prompt_kernel(GemmArgs a
   const int kt0 = sp * a.kt_per_split, kt1 = min(KT, kt0 + a.kt_per_split);
   const int nkt = kt1 - kt0, T = 2 * nkt;            // T16 k tiles / 64-deep tiles of this workgroup
   const T16Planes pl = t16_planes(a.w, QT, a.N, a.K);
+  const T16Planes pl2 = t16_planes(pair ? a.w2 : a.w, QT, a.N, a.K);
 
   const _Float16* lut = nullptr;
   if constexpr (QT == Q_NF4) {
@@ -132,19 +137,23 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_prompt_kernel(GemmArgs a
   // last valid one and never stored) and their raw data: one whole T16 tile (128 k = two 64-deep tiles) per slot, loaded
   // once per pair of tiles with full 16-byte code loads
   const int ntiles = (a.N + 15) >> 4;
-  int slot_rt[SLOTS];
+  static_assert(RT % 2 == 0, "the pair form splits the block's tile rows in two");
+  int slot_rt[SLOTS], slot_second[SLOTS];
   int64_t slot_tile[SLOTS];
 #pragma unroll
   for (int i = 0; i < SLOTS; ++i) {
     if constexpr (HALF) slot_rt[i] = (wave >> 1) * 3 + (i < FULL ? (wave & 1) : 2);
     else slot_rt[i] = wave * FULL + i;
-    slot_tile[i] = (int64_t)min(nb * RT + slot_rt[i], ntiles - 1) * KT + kt0;
+    const int second = pair && slot_rt[i] >= RT / 2;
+    const int trow = pair ? nb * (RT / 2) + slot_rt[i] - second * (RT / 2) : nb * RT + slot_rt[i];
+    slot_tile[i] = (int64_t)min(trow, ntiles - 1) * KT + kt0;
+    slot_second[i] = second;
   }
   const int half_sel = wave & 1;                     // which k half of the shared row this wavefront expands
   Tile<QT> rawC[SLOTS], rawN[SLOTS];                 // T16 tile being expanded / the next one (in flight)
   auto fetch_raw = [&](Tile<QT> (&raw)[SLOTS], int kt) {
 #pragma unroll
-    for (int i = 0; i < SLOTS; ++i) load_tile<QT>(raw[i], pl, slot_tile[i] + kt, lane);
+    for (int i = 0; i < SLOTS; ++i) load_tile<QT>(raw[i], slot_second[i] ? pl2 : pl, slot_tile[i] + kt, lane);
   };
 
   // fragment slot of k step s for this lane: (4 s + g) ^ (r & 7); s = 1 flips bit 2
@@ -402,9 +411,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_prompt_kernel(GemmArgs a
   // ---- epilogue.  A lane holds 4 consecutive output columns (n = 16 tile + 4 g + q) of row m = 16 j + r.
   // Two forms: fp32 partial slabs (K splits, or an output the staged form does not cover: the reduce kernel of
   // gemm_lowbit.hip then applies bias / activation / residual), or the staged 16-bit output.
-  const int ocol0 = nb * BN + wn * (NTW * 16), orow0 = row0 + wm * (MTW * 16);
+  // (pair form: the wavefronts of the second column half hold the second product of the first half's columns)
+  const int wn_out = pair ? wn % (WN / 2) : wn;
+  const bool second_half = pair && wn >= WN / 2;
+  const int ocol0 = nb * BNO + wn_out * (NTW * 16), orow0 = row0 + wm * (MTW * 16);
   const int64_t mtot = a.M;
-  if (a.splitk > 1 || a.force_partial) {
+  if (!pair && (a.splitk > 1 || a.force_partial)) {
 #pragma unroll
     for (int n = 0; n < NTW; ++n) {
       const int ncol = ocol0 + 16 * n + 4 * g;
@@ -435,8 +447,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_prompt_kernel(GemmArgs a
   for (int n = 0; n < NTW; ++n) {
     const int ncol = ocol0 + 16 * n + 4 * g;
     float bias[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (a.bias != nullptr && ncol < a.N) {
-      const half4 b4 = *(const half4*)((const _Float16*)a.bias + ncol);
+    const _Float16* bsrc = (const _Float16*)(second_half ? a.bias2 : a.bias);
+    if (bsrc != nullptr && ncol < a.N) {
+      const half4 b4 = *(const half4*)(bsrc + ncol);
 #pragma unroll
       for (int q = 0; q < 4; ++q) bias[q] = (float)b4[q];
     }
@@ -458,7 +471,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_prompt_kernel(GemmArgs a
   __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(63));
   constexpr int CH = 2 * NTW;                        // 16-byte chunks per row
   static_assert((MTW * 16 * CH) % 64 == 0, "row chunks do not divide over the lanes");
-  const bool plain = a.act == ACT_NONE && a.residual == nullptr;
+  const bool plain = a.act == ACT_NONE && a.residual == nullptr && !pair;
+  const char* stg2 = stg + (WN / 2) * (MTW * 16 * RB);     // pair form: the partner wavefront's tile (same rows)
+  if (pair) {
+    __builtin_amdgcn_s_barrier();                    // the partner's tile is complete in LDS
+    if (second_half) return;
+  }
 #pragma unroll 1
   for (int it = 0; it < MTW * 16 * CH / 64; ++it) {
     const int idx = it * 64 + lane, row = idx / CH, ch = idx % CH;
@@ -466,7 +484,25 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_prompt_kernel(GemmArgs a
     if (orow0 + row >= row0 + rows || col >= a.N) continue;
     uint4v pk = *(const uint4v*)(stg + row * RB + ch * 16);
     const int64_t oi = (int64_t)(orow0 + row) * a.ldo + col;
-    if (!plain) {
+    if (pair) {
+      // act(first) * second on the rounded 16-bit values (what a separate activation kernel would read)
+      const uint4v pu = *(const uint4v*)(stg2 + row * RB + ch * 16);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float lo, hi, ulo, uhi;
+        if (a.out_type == OUT_F16) {
+          const half2v h = u2h(pk[e]), hu = u2h(pu[e]);
+          lo = (float)h[0]; hi = (float)h[1]; ulo = (float)hu[0]; uhi = (float)hu[1];
+        } else {
+          lo = bf16_bits_to_f32((uint16_t)(pk[e] & 0xffffu)); hi = bf16_bits_to_f32((uint16_t)(pk[e] >> 16));
+          ulo = bf16_bits_to_f32((uint16_t)(pu[e] & 0xffffu)); uhi = bf16_bits_to_f32((uint16_t)(pu[e] >> 16));
+        }
+        lo = act_apply(a.act, lo) * ulo;
+        hi = act_apply(a.act, hi) * uhi;
+        if (a.out_type == OUT_F16) pk[e] = h2u(half2v{(_Float16)lo, (_Float16)hi});
+        else pk[e] = (uint32_t)f32_to_bf16_bits(lo) | ((uint32_t)f32_to_bf16_bits(hi) << 16);
+      }
+    } else if (!plain) {
       uint4v rr = uint4v{0, 0, 0, 0};
       if (a.residual != nullptr) rr = *(const uint4v*)((const uint16_t*)a.residual + oi);
 #pragma unroll
@@ -499,7 +535,8 @@ static int gemm_prompt_launch_cfg(const GemmArgs& a, hipStream_t st) {
       return -101;
     attr_set = true;
   }
-  const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+  const int bno = a.w2 != nullptr ? BN / 2 : BN;
+  const int tiles = ((a.M + BM - 1) / BM) * ((a.N + bno - 1) / bno);
   hipLaunchKernelGGL((gemm_prompt_kernel<QT, WM, WN, MTW, NTW, PH>), dim3(tiles * a.splitk), dim3(64 * NW), lds, st, a);
   return HIP_CHECK_LAUNCH();
 }

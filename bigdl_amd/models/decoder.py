@@ -628,9 +628,17 @@ class NativeDecoder:
         from ..ops import hip
         cfg = self.cfg
         if cfg.gated_mlp:
-            g = self._linear_dense(x, lw.gate)
-            u = self._linear_dense(x, lw.up)
-            hip.act_mul(g, u, cfg.act)
+            gt, up = lw.gate, lw.up
+            if (gt.fused and up.fused and gt.qtype == up.qtype and gt.n == up.n and gt.n % 16 == 0 and self.prefill_fused
+                    and x.shape[0] > GEMM_MAX_ROWS and x.dtype == torch.float16 and not Lin.cache_dense and not self.prefill_fp8
+                    and hip.gemm_prompt_supported(gt.qtype, gt.k)):
+                # both input projections and act(g) * u in one launch: g and u never reach memory
+                g = hip.gemm_prompt_pair(x.contiguous(), gt.w, up.w, gt.qtype, gt.n, gt.k, bias=gt.bias, bias2=up.bias,
+                                         act=cfg.act)
+            else:
+                g = self._linear_dense(x, gt)
+                u = self._linear_dense(x, up)
+                hip.act_mul(g, u, cfg.act)
         else:
             g = _ACT_FNS[cfg.act](self._linear_dense(x, lw.up))
         return self._tp_reduce(self._linear_dense(g, lw.down))

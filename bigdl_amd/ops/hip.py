@@ -64,6 +64,7 @@ def lib():
         L.bigdl_gemm_lowbit.argtypes = [vp, vp, vp, vp, vp, vp, i64, ci, ci, ci, ci, ci, ci, ci, ci, vp]
         L.bigdl_gemm_lowbit_splitk.argtypes = [ci, ci, ci]
         L.bigdl_gemm_prompt.argtypes = [vp, vp, vp, vp, vp, vp, i64, ci, ci, ci, ci, ci, ci, ci, ci, vp]
+        L.bigdl_gemm_prompt_pair.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp]
         L.bigdl_gemm_prompt_slabs.argtypes = [ci, ci, ci, ci, ci, ci]
         L.bigdl_gemm_prompt_supported.argtypes = [ci, ci]
         L.bigdl_gemm_prompt_plan.argtypes = [ci, ci, ci, ctypes.POINTER(ci), ctypes.POINTER(ci)]
@@ -344,6 +345,39 @@ def gemm_prompt(x, w, qtype, out_features, in_features, *, bias=None, residual=N
     rc = L.bigdl_gemm_prompt(_ptr(x), _ptr(w), _ptr(out), _ptr(bias), _ptr(residual), _ptr(ws), ws_n, m, out_features, k,
                              x.stride(0), out.stride(0), qtype, ACT[act], _out_type(out_dtype), _stream())
     _check(rc, "gemm_prompt")
+    return out
+
+
+def gemm_prompt_pair(x, w, w2, qtype, out_features, in_features, *, bias=None, bias2=None, act="silu", out=None,
+                     out_dtype=None):
+    """``act(x @ dequant(w)^T + bias) * (x @ dequant(w2)^T + bias2)``: the gated MLP's two input projections and their
+    activation product in ONE launch of the prompt-sized fused GEMM (every workgroup computes the same columns of both
+    products and combines them in its epilogue: neither product is written to memory).  Role of the reference's
+    ``xe_linear.mlp_forward_xpu`` (python/llm/src/ipex_llm/transformers/models/common.py:118-133), which is limited
+    to one row.  x [M, K] fp16; w, w2: T16 buffers of one format, [out_features, in_features], out_features % 16 == 0."""
+    _need_cuda(x, w, w2, bias, bias2, out)
+    if x.dim() != 2 or x.dtype != torch.float16 or x.stride(1) != 1:
+        raise ValueError("x must be a 2-D fp16 tensor with contiguous rows")
+    m, k = x.shape
+    if k != in_features or out_features % 16:
+        raise ValueError("bad shape for the paired product")
+    if not gemm_prompt_supported(qtype, k):
+        raise ValueError(f"qtype {qtype} / K = {k} has no prompt-sized fused GEMM kernel")
+    from .host import device_nbytes
+    nb = device_nbytes(qtype, out_features, in_features)
+    if w.numel() * w.element_size() != nb or w2.numel() * w2.element_size() != nb:
+        raise ValueError("weight buffer size does not match the tiled layout")
+    out_dtype = out_dtype or (out.dtype if out is not None else torch.float16)
+    if out is None:
+        out = torch.empty((m, out_features), dtype=out_dtype, device=x.device)
+    if out.shape != (m, out_features) or out.stride(1) != 1 or out.dtype != out_dtype:
+        raise ValueError("bad out tensor")
+    for b in (bias, bias2):
+        if b is not None and (b.dtype != torch.float16 or b.numel() != out_features or not b.is_contiguous()):
+            raise ValueError("bias must be contiguous fp16 [out_features]")
+    rc = lib().bigdl_gemm_prompt_pair(_ptr(x), _ptr(w), _ptr(w2), _ptr(out), _ptr(bias), _ptr(bias2), m, out_features, k,
+                                      x.stride(0), out.stride(0), qtype, ACT[act], _out_type(out_dtype), _stream())
+    _check(rc, "gemm_prompt_pair")
     return out
 
 

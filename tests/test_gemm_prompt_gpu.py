@@ -97,3 +97,38 @@ def test_rows_of_a_larger_buffer(hip):
     hip.gemm_prompt(wide[:, 512:1536], w, qt, 512, 1024, out=outw[:, 256:768])
     assert (outw[:, 256:768].float() - ref).abs().max().item() < 2e-3 * ref.abs().max().item()
     assert outw[:, :256].abs().max().item() == 0 and outw[:, 768:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("qname", ["sym_int4", "asym_int4", "nf4", "sym_int8"])
+@pytest.mark.parametrize("cfg", [0, 1, 2])
+def test_gate_up_pair_in_one_launch(hip, qname, cfg):
+    """act(x Wg^T + bg) * (x Wu^T + bu) from one launch against the two separate products (partial row and column blocks)."""
+    from bigdl_amd.models.decoder import _random_t16
+    m, n, k = 700, 1104, 1024
+    qt = Q.ggml_tensor_qtype[qname]
+    dev = torch.device("cuda")
+    wg = _random_t16(n, k, qt, dev, torch.Generator(device="cuda").manual_seed(1), scale=0.02).data
+    wu = _random_t16(n, k, qt, dev, torch.Generator(device="cuda").manual_seed(2), scale=0.02).data
+    x = torch.randn(m, k, device="cuda", dtype=torch.float16)
+    bg = torch.randn(n, device="cuda", dtype=torch.float16) * 0.1
+    bu = torch.randn(n, device="cuda", dtype=torch.float16) * 0.1
+    g = (x.float() @ hip.dequant_t16(wg, qt, n, k).float().t() + bg.float()).half().float()
+    u = (x.float() @ hip.dequant_t16(wu, qt, n, k).float().t() + bu.float()).half().float()
+    ref = torch.nn.functional.silu(g) * u
+    hip.gemm_prompt_force(cfg, 0)
+    try:
+        got = hip.gemm_prompt_pair(x, wg, wu, qt, n, k, bias=bg, bias2=bu, act="silu").float()
+    finally:
+        hip.gemm_prompt_force()
+    assert (got - ref).abs().max().item() < 4e-3 * ref.abs().max().item() + 2e-3
+    # Llama-2-7B shape, planned configuration, no biases
+    n, k = 11008, 4096
+    wg = _random_t16(n, k, Q.SYM_INT4, dev, torch.Generator(device="cuda").manual_seed(3), scale=0.02).data
+    wu = _random_t16(n, k, Q.SYM_INT4, dev, torch.Generator(device="cuda").manual_seed(4), scale=0.02).data
+    x = torch.randn(1024, k, device="cuda", dtype=torch.float16)
+    if qname == "sym_int4" and cfg == 0:
+        g = hip.gemm_prompt(x, wg, Q.SYM_INT4, n, k).float()
+        u = hip.gemm_prompt(x, wu, Q.SYM_INT4, n, k).float()
+        ref = torch.nn.functional.silu(g) * u
+        got = hip.gemm_prompt_pair(x, wg, wu, Q.SYM_INT4, n, k).float()
+        assert (got - ref).abs().max().item() < 2e-3 * ref.abs().max().item() + 1e-3
