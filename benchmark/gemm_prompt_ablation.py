@@ -48,7 +48,7 @@ if __name__ == "__main__":
     w = _random_t16(n, k, qt, torch.device("cuda"), torch.Generator(device="cuda").manual_seed(0), scale=0.02).data
     x = torch.randn(m, k, device="cuda", dtype=torch.float16)
     out = torch.empty(m, n, device="cuda", dtype=torch.float16)
-    ws = torch.empty(8 * m * n, device="cuda", dtype=torch.float32)
+    ws = torch.empty(1 << 25, device="cuda", dtype=torch.float32)
     stream = torch.cuda.current_stream().cuda_stream
 
     def call(L):

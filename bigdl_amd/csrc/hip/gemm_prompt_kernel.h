@@ -9,20 +9,24 @@
 //  * x tile [BM][64 k] goes global -> LDS directly (global_load_lds, 16 bytes per lane), one tile ahead, two buffers.
 //    The LDS image is lane-linear as the instruction requires; the bank swizzle (16-byte slot ^= row & 7) is applied
 //    to the per-lane SOURCE address and again on the fragment reads.
-//  * the weight tile [BN][64 k] is expanded ONCE per workgroup: every wavefront owns BN / 8 / waves (tile row, k step)
-//    units, loads their raw codes + block scales two tiles ahead (HBM -> VGPR, a few bytes per lane), expands them with
-//    the register bit tricks of the skinny kernels, folds the block scale in as a packed fp16 multiply and writes the
-//    fp16 B fragments to the other LDS buffer with one 16-byte store per unit, under the MFMAs of the current tile.
+//  * the weight tile [BN][64 k] is expanded ONCE per workgroup: every wavefront owns a share of the block's 16-row weight
+//    tile rows, loads their raw T16 tiles (codes + block scales, 16-byte loads, one whole 128-deep tile per two k tiles)
+//    two tiles ahead, expands them with the register bit tricks of the skinny kernels, folds the block scale in as a
+//    packed fp16 multiply and writes the fp16 fragments to the other LDS buffer with one 16-byte store per unit.
 //    (The earlier form expanded weights per wavefront in registers: every weight was decoded by both row halves of the
 //    workgroup and the decode stood in the MFMA's issue slots.)
 //  * fragments: both operands are read with ds_read_b128 from 128-byte rows; slot ^= row & 7 makes the four 16-lane
 //    groups of the read and the eight 8-lane groups of the expansion's ds_write_b128 conflict free.
+//  * 8-wavefront tiles run their two row halves as a ping-pong pair, one segment apart: while one wavefront of a SIMD
+//    issues MFMAs its partner reads fragments, expands weights and requests the next tiles (comments at the loop).
 //  * the weight fragment is the MFMA's A operand, so a lane holds 4 consecutive output columns of one row; the epilogue
-//    stages the wavefront's tile through LDS and stores whole 128-byte row segments.
-//  * ONE workgroup barrier per 64-deep tile: waits are counted (s_waitcnt vmcnt(N) leaves the look-ahead weight loads
-//    in flight across the barrier), never a full drain inside the loop.
+//    stages the wavefront's tile through LDS and stores whole 128-byte row segments; the gate / up pair form combines the
+//    two products of a column there (act(g) * u), so neither reaches memory.
 //  * the block index is remapped so that the row blocks that share a weight column panel run on one XCD (one HBM read
 //    of the panel per L2).
+// Measured and dropped: stream-K over 256 x 256 tiles (every CU the same number of k tiles whatever the tile count; the
+// 256 KiB fp32 slab per shared tile costs more than the idle CUs it removes: 130 instead of 98 us on the qkv shape),
+// x requests or the expansion moved into the MFMA segment (no change / slower), wavefront priorities (no change).
 #pragma once
 #include "gemm_kernel.h"
 
@@ -233,6 +237,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_prompt_kernel(GemmArgs a
         const char* px = lds_x(cur, ph * SP + s);
 #pragma unroll
         for (int n = 0; n < NTW; ++n) wf[s][n] = frag(pw, n);
+        // (one phase per tile: the x fragments of the second k step are read under the first step's MFMAs: x rows belong
+        // to this row half alone, while a weight buffer may be rewritten by the other half during the compute segment)
+        if (PH == 1 && s == 1) continue;
 #pragma unroll
         for (int j = 0; j < MTW; ++j) xf[s][j] = frag(px, j);
       }
@@ -242,37 +249,28 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_prompt_kernel(GemmArgs a
         // the previous tile
         if constexpr (cur == 1 && !(PROMPT_ABL & 1)) fetch_raw(rawN, min((t >> 1) + 2, nkt - 1));
       }
-#ifndef PROMPT_EXPC
       expand(std::integral_constant<int, nxt>{}, std::integral_constant<int, ph * NUW / PH>{},
              std::integral_constant<int, (ph + 1) * NUW / PH>{});
-#endif
       seg_end();
     };
     auto comp_seg = [&](auto curc, auto phc) {
       constexpr int cur = decltype(curc)::value, ph = decltype(phc)::value;
-#ifdef PROMPT_EXPC
-      // timing experiment (results wrong: the other row half may be reading the buffer): expansion under the MFMAs
-      expand(std::integral_constant<int, cur ^ 1>{}, std::integral_constant<int, ph * NUW / PH>{},
-             std::integral_constant<int, (ph + 1) * NUW / PH>{});
-#else
       __builtin_amdgcn_s_setprio(1);
-#endif
+      if constexpr (PH == 1) {
+        const char* px = lds_x(cur, 1);
 #pragma unroll
-      for (int s = 0; s < SP; ++s)
+        for (int j = 0; j < MTW; ++j) xf[1][j] = frag(px, j);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int s = 0; s < SP; ++s) {
 #pragma unroll
         for (int j = 0; j < MTW; ++j)
 #pragma unroll
           for (int n = 0; n < NTW; ++n) mfma_or_not(acc[j][n], wf[s][n], xf[s][j]);
-#ifdef PROMPT_EXPC
-#pragma unroll
-      for (int k = 0; k < SP * MTW * NTW; ++k) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, PROMPT_EXPC, 0);
+        if constexpr (PH == 1) __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(63));
-#else
       __builtin_amdgcn_s_setprio(0);
-#endif
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (ph == PH - 1) {
         __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
