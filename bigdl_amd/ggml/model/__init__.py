@@ -70,11 +70,19 @@ class NativeModel:
         do_sample = temp is not None and temp > 0
         q: "queue.Queue" = queue.Queue()
         done = object()
+        cancel = threading.Event()
+        # one generation at a time per model: the engine's KV cache, static buffers and decode graph are shared state
+        lock = self.__dict__.setdefault("_generate_lock", threading.Lock())
+
+        class _Cancelled(Exception):
+            pass
 
         class _Tokens:                       # the streamer protocol of ``generate``: put(prompt), put(token)..., end()
             first = True
 
             def put(self, value):
+                if cancel.is_set():          # the consumer went away (stop string, abandoned iterator): stop decoding
+                    raise _Cancelled()
                 if self.first:
                     self.first = False
                     return
@@ -85,21 +93,35 @@ class NativeModel:
                 q.put(done)
 
         def run():
-            try:
-                self.model.generate(ids, max_new_tokens=max_tokens, do_sample=do_sample, temperature=temp if do_sample else None,
-                                    top_k=top_k if do_sample else None, top_p=top_p if do_sample else None,
-                                    repetition_penalty=repeat_penalty, streamer=_Tokens())
-            except Exception as e:           # surface the failure to the consumer instead of leaving it blocked
-                q.put(e)
-                q.put(done)
-        threading.Thread(target=run, daemon=True).start()
-        while True:
-            item = q.get()
-            if item is done:
-                return
-            if isinstance(item, Exception):
-                raise item
-            yield item
+            with lock:
+                try:
+                    if cancel.is_set():
+                        return
+                    self.model.generate(ids, max_new_tokens=max_tokens, do_sample=do_sample,
+                                        temperature=temp if do_sample else None, top_k=top_k if do_sample else None,
+                                        top_p=top_p if do_sample else None, repetition_penalty=repeat_penalty,
+                                        streamer=_Tokens())
+                except _Cancelled:
+                    pass
+                except Exception as e:       # surface the failure to the consumer instead of leaving it blocked
+                    q.put(e)
+                finally:
+                    q.put(done)
+        worker = threading.Thread(target=run, daemon=True)
+        worker.start()
+        try:
+            while True:
+                item = q.get()
+                if item is done:
+                    return
+                if isinstance(item, Exception):
+                    raise item
+                yield item
+        finally:
+            # reached on exhaustion, on an exception and when the consumer closes the generator early (GeneratorExit):
+            # the worker sees the flag at its next token and leaves; the next call finds the model idle
+            cancel.set()
+            worker.join()
 
     def _completion_chunks(self, prompt, toks, max_tokens, temperature, top_p, top_k, stop, repeat_penalty):
         """(text delta, finish_reason or None, tokens so far) per generated token, honouring EOS and stop strings"""

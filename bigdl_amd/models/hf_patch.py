@@ -105,6 +105,7 @@ def pad_mlp_intermediate(module, multiple: int = 128):
         lin.out_features = new
     d.weight = grown(d.weight.data, (d.out_features, new), lambda o, t: o[:, :inter].copy_(t))
     d.in_features = new
+    module._bigdl_padded_from = inter
 
 
 def fold_norm_head(model):
@@ -127,6 +128,16 @@ def optimize_pre(model, qtype=None):
     fold_norm_head(model)
     if qtype is None or qtype in Q.T16_QTYPES:
         model.apply(pad_mlp_intermediate)
+        # the padded width is what every later reader of the configuration has to see: the native engine sizes its MLP
+        # buffers from it, and a saved low-bit checkpoint must describe the tensors it holds (its skeleton is rebuilt
+        # from config.json).  The original width is kept beside it.
+        padded = {(m._bigdl_padded_from, m.gate_proj.out_features) for m in model.modules()
+                  if getattr(m, "_bigdl_padded_from", None) is not None}
+        for c in {id(x): x for x in (cfg, getattr(cfg, "text_config", None)) if x is not None}.values():
+            for old, new in padded:
+                if getattr(c, "intermediate_size", None) == old:
+                    c.intermediate_size = new
+                    c.bigdl_unpadded_intermediate_size = old
     if mt in MERGE_QKV_TYPES:
         for cls in _attention_classes(model):
             model.apply(lambda m, c=cls: merge_qkv_base(m, c))
@@ -568,6 +579,8 @@ def build_native_decoder(model):
             lw.down = _lin(mlp.down_proj)
         else:
             lw.gate, lw.up, lw.down = _lin(mlp.gate_proj), _lin(mlp.up_proj), _lin(mlp.down_proj)
+            # (what the linears hold, not what the configuration says: a padded MLP is wider than an older config)
+            dc.intermediate_size = max(dc.intermediate_size, lw.up.n)
         if mt == "gemma2":
             lw.post_attn_out_norm = f16(layer.post_attention_layernorm.weight)
             lw.pre_ffn_norm = f16(layer.pre_feedforward_layernorm.weight)

@@ -14,6 +14,7 @@ path set up and summed correctly.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import socket
 
@@ -25,15 +26,26 @@ from ..ops import hip
 DEFAULT_MAX_BYTES = 256 * 1024
 
 
+class _Failed:
+    """What a rank puts into a set-up exchange in place of its contribution when its local step raised."""
+
+    def __init__(self, why: str):
+        self.why = why
+
+
 class OneShotAllReduce:
+    """All ranks construct this together; the constructor either returns on every rank or raises on every rank."""
+
     def __init__(self, group=None, max_bytes: int = DEFAULT_MAX_BYTES, device=None):
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.max_bytes = (max_bytes + 63) // 64 * 64
-        hosts = [None] * self.world
-        dist.all_gather_object(hosts, socket.gethostname(), group=group)
+        self._own, self._opened = None, []
+        # Every rank runs the same sequence of collectives whatever fails locally: a local error is recorded, the
+        # ranks exchange what they have, and all of them raise together after the exchange.
+        hosts = self._exchange(socket.gethostname())
         if len(set(hosts)) != 1:
             raise RuntimeError("one-shot all-reduce needs all ranks in one node")
         if self.world > 16:
@@ -53,32 +65,65 @@ class OneShotAllReduce:
         L.bigdl_allreduce_twoshot.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                               ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         self.max_bytes = self._round_max_bytes(self.max_bytes)
-        with torch.cuda.device(self.device):
-            nbytes = self._buffer_bytes()
-            own = ctypes.c_void_p()
-            if L.bigdl_ar_alloc(nbytes, ctypes.byref(own)) != 0:
-                raise RuntimeError("fine-grained buffer allocation failed")
-            self._own = own
-            handle = ctypes.create_string_buffer(64)
-            if L.bigdl_ar_ipc_handle(own, handle) != 0:
-                raise RuntimeError("hipIpcGetMemHandle failed")
-            handles = [None] * self.world
-            dist.all_gather_object(handles, handle.raw, group=group)
-            self._opened = []
-            ptrs = []
-            for r, h in enumerate(handles):
-                if r == self.rank:
-                    ptrs.append(own.value)
-                    continue
-                p = ctypes.c_void_p()
-                if L.bigdl_ar_ipc_open(h, ctypes.byref(p)) != 0:
-                    raise RuntimeError(f"hipIpcOpenMemHandle failed for rank {r}")
-                self._opened.append(p)
-                ptrs.append(p.value)
+        with (torch.cuda.device(self.device) if self.device.type == "cuda" else contextlib.nullcontext()):
+            # phase 1: own buffer + its handle
+            mine = None
+            try:
+                mine = self._alloc_and_export()
+            except Exception as e:
+                mine = _Failed(f"rank {self.rank}: {e}")
+            handles = self._exchange(mine)
+            self._raise_together(handles)
+            # phase 2: map every peer's buffer
+            opened = None
+            try:
+                ptrs = self._open_peers(handles)
+            except Exception as e:
+                opened = _Failed(f"rank {self.rank}: {e}")
+            self._raise_together(self._exchange(opened))
             self._peers = (ctypes.c_int64 * self.world)(*ptrs)
-            self.epoch = torch.zeros(self._epoch_words(), dtype=torch.int32, device=self.device)
-            self.error = torch.zeros(1, dtype=torch.int32, device=self.device)
-        dist.barrier(group=group)          # every buffer is mapped everywhere before the first call
+            # phase 3: per-rank device state
+            state = None
+            try:
+                self.epoch = torch.zeros(self._epoch_words(), dtype=torch.int32, device=self.device)
+                self.error = torch.zeros(1, dtype=torch.int32, device=self.device)
+            except Exception as e:
+                state = _Failed(f"rank {self.rank}: {e}")
+            self._raise_together(self._exchange(state))   # doubles as "every buffer is mapped everywhere"
+
+    def _exchange(self, obj):
+        out = [None] * self.world
+        dist.all_gather_object(out, obj, group=self.group)
+        return out
+
+    def _raise_together(self, gathered):
+        bad = [g.why for g in gathered if isinstance(g, _Failed)]
+        if bad:
+            self.close()
+            raise RuntimeError("IPC all-reduce set-up failed: " + "; ".join(bad))
+
+    def _alloc_and_export(self) -> bytes:
+        own = ctypes.c_void_p()
+        if self.lib.bigdl_ar_alloc(self._buffer_bytes(), ctypes.byref(own)) != 0:
+            raise RuntimeError("fine-grained buffer allocation failed")
+        self._own = own
+        handle = ctypes.create_string_buffer(64)
+        if self.lib.bigdl_ar_ipc_handle(own, handle) != 0:
+            raise RuntimeError("hipIpcGetMemHandle failed")
+        return handle.raw
+
+    def _open_peers(self, handles):
+        ptrs = []
+        for r, h in enumerate(handles):
+            if r == self.rank:
+                ptrs.append(self._own.value)
+                continue
+            p = ctypes.c_void_p()
+            if self.lib.bigdl_ar_ipc_open(h, ctypes.byref(p)) != 0:
+                raise RuntimeError(f"hipIpcOpenMemHandle failed for rank {r}")
+            self._opened.append(p)
+            ptrs.append(p.value)
+        return ptrs
 
     def _round_max_bytes(self, n):
         return n
@@ -160,46 +205,56 @@ class XgmiAllReduce:
     def __init__(self, group=None, small_bytes: int = DEFAULT_MAX_BYTES, large_bytes: int = 64 << 20, device=None):
         self.group = group
         self.small = OneShotAllReduce(group, small_bytes, device)
-        self.large = TwoShotAllReduce(group, large_bytes, device)
+        try:
+            self.large = TwoShotAllReduce(group, large_bytes, device)
+        except Exception:
+            self.small.close()
+            raise
 
     @classmethod
     def create_verified(cls, group=None, device=None, **kw):
         """Set up, run a self-check against ``dist.all_reduce`` and return the object, or None when any rank failed to
-        set up or saw a wrong sum (every rank takes the same decision)."""
+        set up or saw a wrong sum.  Every rank takes the same decision after every step: the constructors raise on
+        all ranks or on none, and each self-check size ends in a vote, so no rank is left inside a collective that a
+        failed peer never enters."""
         import warnings
-        ok, obj, why = 1, None, ""
+        dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+
+        def all_ok(ok: int) -> bool:
+            flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            return int(flag.item()) == 1
+
+        def give_up(obj, why):
+            if obj is not None:
+                obj.close()
+            warnings.warn("IPC all-reduce disabled, using the process group's all-reduce"
+                          + (f" ({why})" if why else " (a peer rank failed its self-check)"))
+            return None
+
         try:
             obj = cls(group, device=device, **kw)
         except Exception as e:            # IPC not permitted, ranks on different hosts, allocation failure, ...
-            ok, why = 0, f"set-up failed: {e}"
-        dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
-        if ok:
+            return give_up(None, f"set-up failed: {e}")
+        rank = dist.get_rank(group)
+        for n in (4096, 1 << 19):                             # 8 KB: one-shot; 1 MB: two-shot
+            ok, why = 1, ""
+            base = torch.arange(n, device=dev, dtype=torch.float32).remainder_(13).add_(rank + 1).to(torch.float16)
+            want = base.clone()
+            dist.all_reduce(want, group=group)
             try:
-                rank = dist.get_rank(group)
-                for n in (4096, 1 << 19):                     # 8 KB: one-shot; 1 MB: two-shot
-                    base = torch.arange(n, device=dev, dtype=torch.float32).remainder_(13).add_(rank + 1).to(torch.float16)
-                    want = base.clone()
-                    dist.all_reduce(want, group=group)
-                    got = base.clone()
-                    for _ in range(3):                        # repeated calls walk the epoch counters
-                        got.copy_(base)
-                        obj(got)
-                    if not torch.equal(got, want):
-                        ok, why = 0, f"wrong sum at {n} elements"
-                        break
-                if ok:
-                    obj.check()
+                got = base.clone()
+                for _ in range(3):                            # repeated calls walk the epoch counters
+                    got.copy_(base)
+                    obj(got)
+                obj.check()
+                if not torch.equal(got, want):
+                    ok, why = 0, f"wrong sum at {n} elements"
             except Exception as e:
                 ok, why = 0, f"self-check raised: {e}"
-        flag = torch.tensor([ok], device=dev, dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-        if int(flag.item()) == 1:
-            return obj
-        if obj is not None:
-            obj.close()
-        warnings.warn("IPC all-reduce disabled, using the process group's all-reduce"
-                      + (f" ({why})" if why else " (a peer rank failed its self-check)"))
-        return None
+            if not all_ok(ok):
+                return give_up(obj, why)
+        return obj
 
     def usable(self, t):
         return self.small.usable(t) or self.large.usable(t)

@@ -506,8 +506,6 @@ class _BaseAutoModelClass:
                 dt = torch.bfloat16
         else:
             dt = torch_dtype
-        for key in ("bigdl_transformers_low_bit", "bigdl_disk_embedding", "bigdl_lcmu_enabled"):
-            pass
         # 1. skeleton on the meta device
         with torch.device("meta"):
             model = cls.HF_Model.from_config(config, dtype=dt, trust_remote_code=trust_remote_code)
@@ -568,6 +566,11 @@ class _BaseAutoModelClass:
                     pretrained_model_name_or_path, subfolder=subfolder)
             except Exception:
                 pass
+        # the options this module tree was actually built with (keyword overrides included), so that a save_low_bit of
+        # the loaded model describes itself and a later plain load_low_bit rebuilds the same skeleton
+        model.config.update({"bigdl_convert_options": {"optimize_model": bool(optimize_model),
+                                                       "modules_to_not_convert": list(modules_to_not_convert or []),
+                                                       "mixed_precision": bool(mixed_precision)}})
         model.save_low_bit = types.MethodType(save_low_bit, model)
         if pipeline_parallel_stages > 1 or _one_rank_pipeline(pipeline_parallel_stages):
             from .pipeline_parallel import pipeline_parallel, pipeline_parallel_generate

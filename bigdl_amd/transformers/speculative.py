@@ -65,9 +65,11 @@ def _engine_pair(model, draft_model, do_sample, kwargs):
     if not (native_engine_supported(model) and native_engine_supported(draft_model)):
         return None
     pair = getattr(model, "_spec_engine", None)
-    if pair is None:
+    target_engine, draft_engine = get_native_engine(model), get_native_engine(draft_model)
+    if pair is None or pair.target is not target_engine or pair.draft is not draft_engine:
+        # a different draft model (or a rebuilt engine) gets its own pair; the old pair's buffers go with it
         from ..models.spec_engine import SelfSpeculativeEngine
-        pair = SelfSpeculativeEngine(get_native_engine(model), get_native_engine(draft_model))
+        pair = SelfSpeculativeEngine(target_engine, draft_engine)
         object.__setattr__(model, "_spec_engine", pair)
     return pair
 

@@ -338,8 +338,11 @@ def test_mlp_padding_and_norm_head_folding(tmp_path):
     assert mlp.gate_proj.out_len == 256 and mlp.down_proj.in_len == 256 and type(mlp.down_proj).__name__ == "LowBitLinear"
     got = model(ids).logits
     assert torch.nn.functional.cosine_similarity(got.flatten(), want.flatten(), dim=0) > 0.999
+    # the configuration describes what the modules hold (the native engine and a reloaded skeleton size their MLP from it)
+    assert model.config.intermediate_size == 256 and model.config.bigdl_unpadded_intermediate_size == 200
     model.save_low_bit(str(tmp_path))
     again = AutoModelForCausalLM.load_low_bit(str(tmp_path))
+    assert again.config.intermediate_size == 256
     torch.testing.assert_close(again(ids).logits, got)
 
     class NormHead(nn.Module):
@@ -442,3 +445,32 @@ def test_low_bit_checkpoint_describes_how_it_was_converted(tmp_path, tied, kw):
     with torch.no_grad():
         assert torch.equal(r(ids).logits, out)
     assert [n for n, _ in r.named_modules()] == [n for n, _ in q.named_modules()]
+
+
+def test_load_override_is_recorded_for_the_next_save(tmp_path):
+    """A checkpoint from before the conversion options were recorded needs ``optimize_model=False`` spelled out at load;
+    saving the loaded model again must record that, so the copy reloads with no arguments."""
+    import json
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from bigdl_amd.transformers import AutoModelForCausalLM
+    torch.manual_seed(0)
+    cfg = LlamaConfig(vocab_size=320, hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=4,
+                      num_key_value_heads=2)
+    LlamaForCausalLM(cfg).eval().save_pretrained(tmp_path / "hf")
+    q = AutoModelForCausalLM.from_pretrained(str(tmp_path / "hf"), load_in_low_bit="sym_int4", optimize_model=False)
+    ids = torch.randint(0, 320, (1, 8))
+    with torch.no_grad():
+        out = q(ids).logits
+    q.save_low_bit(str(tmp_path / "old"))
+    cfg_file = tmp_path / "old" / "config.json"
+    doc = json.loads(cfg_file.read_text())
+    del doc["bigdl_convert_options"]                               # what an older writer produced
+    cfg_file.write_text(json.dumps(doc))
+    with pytest.raises(Exception):
+        AutoModelForCausalLM.load_low_bit(str(tmp_path / "old"))  # default optimize_model=True builds merged qkv
+    r = AutoModelForCausalLM.load_low_bit(str(tmp_path / "old"), optimize_model=False)
+    assert r.config.bigdl_convert_options["optimize_model"] is False
+    r.save_low_bit(str(tmp_path / "new"))
+    again = AutoModelForCausalLM.load_low_bit(str(tmp_path / "new"))
+    with torch.no_grad():
+        assert torch.equal(again(ids).logits, out)

@@ -70,6 +70,26 @@ def test_native_generate_matches_module_path(tiny):
     assert _rel(lg[:, :9].float(), ref) < 0.02
 
 
+def test_padded_mlp_runs_on_the_engine_and_round_trips(tmp_path):
+    """An intermediate size that is not a multiple of 128 (320 here) is zero-padded at conversion; the engine's MLP buffers
+    follow the padded width, generation matches the module path, and a checkpoint saved from the GPU reloads."""
+    from ipex_llm.transformers import AutoModelForCausalLM
+    torch.manual_seed(0)
+    cfg = LlamaConfig(vocab_size=320, hidden_size=256, intermediate_size=320, num_hidden_layers=2, num_attention_heads=4,
+                      num_key_value_heads=2, head_dim=64, max_position_embeddings=512, tie_word_embeddings=False)
+    LlamaForCausalLM(cfg).eval().save_pretrained(str(tmp_path / "src"))
+    q = AutoModelForCausalLM.from_pretrained(str(tmp_path / "src"), load_in_4bit=True).half().to("cuda")
+    assert q.config.intermediate_size == 384
+    ids = torch.randint(0, 320, (1, 20)).cuda()
+    out_native = q.generate(ids, max_new_tokens=10, do_sample=False)
+    assert hasattr(q, "_native_engine") and q._native_engine.cfg.intermediate_size == 384
+    out_hf = q._hf_generate(ids, max_new_tokens=10, do_sample=False)
+    assert (out_native == out_hf).float().mean() > 0.9
+    q.save_low_bit(str(tmp_path / "low"))
+    again = AutoModelForCausalLM.load_low_bit(str(tmp_path / "low")).half().to("cuda")
+    assert torch.equal(again.generate(ids, max_new_tokens=10, do_sample=False), out_native)
+
+
 def test_save_from_gpu_and_reload(tiny, tmp_path):
     from ipex_llm.transformers import AutoModelForCausalLM
     d, _ = tiny

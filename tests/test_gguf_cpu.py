@@ -241,6 +241,22 @@ def test_llm_convert_and_native_wrappers(tmp_path):
     from bigdl_amd.ggml.model import Bloom
     with pytest.raises(ValueError, match="bloom"):
         Bloom(out)
+    # a completion cut short by a stop string leaves no generation running behind it: the worker is cancelled and
+    # joined, so the next completion has the model (KV cache, decode graph) to itself and reproduces the first one
+    import threading
+    full = llm("w1 w2 w3", max_tokens=12, temperature=0.0)["choices"][0]["text"]
+    words = full.split()
+    if len(words) >= 3:
+        before = threading.active_count()
+        cut = llm("w1 w2 w3", max_tokens=12, temperature=0.0, stop=[words[1]])
+        assert cut["choices"][0]["finish_reason"] == "stop" and words[1] not in cut["choices"][0]["text"]
+        assert threading.active_count() <= before
+        again = llm("w1 w2 w3", max_tokens=12, temperature=0.0)["choices"][0]["text"]
+        assert again == full
+    it = llm.generate(llm.tokenize("w1 w2 w3"), temp=0.0, max_tokens=64)
+    next(it)
+    it.close()                                      # abandoned iterator: GeneratorExit cancels the worker
+    assert llm("w1 w2 w3", max_tokens=12, temperature=0.0)["choices"][0]["text"] == full
 
 
 def test_gptq_checkpoint_loads_without_auto_gptq(tmp_path):

@@ -309,3 +309,91 @@ def _cp_worker(rank, port):
 
 def test_context_parallel_kv_gather():
     _run(_cp_worker)
+
+
+# ------------------------------------------------------------------------------------------------
+class _FakeArLib:
+    """Stands in for the native library's IPC entry points: buffers are host allocations, handles are their addresses.
+    ``fail`` names the step that fails on this rank."""
+
+    def __init__(self, fail=None):
+        import ctypes
+        self.fail, self.live, self.opened, self._ct = fail, {}, 0, ctypes
+
+        class _Fn:
+            def __init__(s, f):
+                s.f = f
+
+            def __call__(s, *a):
+                return s.f(*a)
+        for name in ("bigdl_ar_buffer_bytes", "bigdl_ar_alloc", "bigdl_ar_free", "bigdl_ar_ipc_handle", "bigdl_ar_ipc_open",
+                     "bigdl_ar_ipc_close", "bigdl_allreduce_oneshot", "bigdl_ar2_buffer_bytes", "bigdl_allreduce_twoshot",
+                     "bigdl_ar2_epoch_words"):
+            setattr(self, name, _Fn(getattr(self, "_" + name, lambda *a: 0)))
+
+    def _bigdl_ar_buffer_bytes(self, world, n):
+        return world * n + 64
+
+    _bigdl_ar2_buffer_bytes = _bigdl_ar_buffer_bytes
+
+    def _bigdl_ar2_epoch_words(self):
+        return 2
+
+    def _bigdl_ar_alloc(self, n, out):
+        if self.fail == "alloc":
+            return 1
+        buf = self._ct.create_string_buffer(64)
+        self.live[self._ct.addressof(buf)] = buf
+        out._obj.value = self._ct.addressof(buf)
+        return 0
+
+    def _bigdl_ar_free(self, p):
+        self.live.pop(p.value, None)
+
+    def _bigdl_ar_ipc_handle(self, p, handle):
+        return 1 if self.fail == "handle" else 0
+
+    def _bigdl_ar_ipc_open(self, h, out):
+        if self.fail == "open":
+            return 1
+        self.opened += 1
+        out._obj.value = 4096 * self.opened
+        return 0
+
+    def _bigdl_ar_ipc_close(self, p):
+        self.opened -= 1
+
+
+def _ipc_setup_worker(rank, port, fail):
+    _boot(rank, port)
+    from bigdl_amd.ops import hip
+    from bigdl_amd.parallel import xgmi_allreduce as xa
+    fake = _FakeArLib(fail if rank == WORLD - 1 else None)
+    hip.lib = lambda: fake
+    if fail is None:
+        ar = xa.XgmiAllReduce(device="cpu")
+        assert len(fake.live) == 2 and fake.opened == 2 * (WORLD - 1)
+        ar.close()
+    elif fail == "second":                     # one-shot builds everywhere, the two-shot member fails on one rank
+        real = xa.TwoShotAllReduce._alloc_and_export
+
+        def broken(self):
+            if rank == WORLD - 1:
+                raise RuntimeError("no room for the large buffer")
+            return real(self)
+        xa.TwoShotAllReduce._alloc_and_export = broken
+        with pytest.raises(RuntimeError, match="no room for the large buffer"):
+            xa.XgmiAllReduce(device="cpu")
+    else:                                      # one rank fails a step: every rank raises, naming that rank
+        with pytest.raises(RuntimeError, match=f"rank {WORLD - 1}"):
+            xa.OneShotAllReduce(device="cpu")
+    assert not fake.live and fake.opened == 0, (fake.live, fake.opened)     # nothing left mapped or allocated
+    dist.barrier()                             # the group is still in step after the failure
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail", [None, "alloc", "handle", "open", "second"])
+def test_ipc_allreduce_setup_fails_on_every_rank_together(fail):
+    """A set-up error on one rank must not leave its peers inside a collective it never enters
+    (parallel/xgmi_allreduce.py: every phase ends in an exchange and all ranks raise after it)."""
+    _run(_ipc_setup_worker, fail)
