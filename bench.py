@@ -225,7 +225,9 @@ def native_engine(args, rank, local_rank, world, dist):
             ref.sum()
         torch.cuda.synchronize()
     if rank == 0:
-        report(args, world, par, label, stats, floor_ms=model.weight_bytes() / 8e12 * 1e3)
+        # bytes a decoded token must stream (routed experts: only the activated ones) over the HBM peak
+        read = model.decode_read_bytes() if hasattr(model, "decode_read_bytes") else model.weight_bytes()
+        report(args, world, par, label, stats, floor_ms=read / 8e12 * 1e3)
 
 
 def cpu_module_path(args, rank, local_rank, world, dist):

@@ -1476,6 +1476,23 @@ class NativeDecoder:
                 tot += sum(lin.nbytes for lin in lw.mla.lins())
         return tot
 
+    def decode_read_bytes(self):
+        """Weight bytes one decoded token has to stream from HBM: every dense product once, the routed experts a token
+        activates (not all of them), the head; the embedding contributes one row.  The denominator of a bandwidth
+        floor for batch-1 decode."""
+        tot = 0 if self.lm_head is None else self.lm_head.nbytes
+        if self.embed is not None:
+            tot += self.embed.shape[-1] * self.embed.element_size()
+        for lw in self.layers:
+            for lin in (lw.qkv, lw.o, lw.gate, lw.up, lw.down):
+                if lin is not None:
+                    tot += lin.nbytes
+            if lw.moe is not None:
+                tot += lw.moe.active_bytes()
+            if lw.mla is not None:
+                tot += sum(lin.nbytes for lin in lw.mla.lins())
+        return tot
+
 
 def sample_logits(logits, temperature=1.0, top_k=0, top_p=1.0):
     if temperature and temperature != 1.0:
@@ -1518,6 +1535,41 @@ def _random_t16(n, k, qtype, device, gen, scale=0.02):
         buf[code_bytes + nscale * 2:] = mn.view(torch.uint8)
     p = FP4Params(buf, quantized=True, _shape=(n, k), qtype=qtype, qlayout="t16")
     return p
+
+
+@torch.no_grad()
+def dense_reference_logits(model: "NativeDecoder", ids: torch.Tensor) -> torch.Tensor:
+    """Logits [B, S, V] of a plain fp32 PyTorch forward over the dequantized weights of a llama-shaped engine (RMSNorm,
+    half-split rotary, gated MLP, no biases): the oracle of the engine tests and of ``__graft_entry__.smoke``."""
+    cfg = model.cfg
+    dev = ids.device
+    h = model.embed[ids].float() * cfg.embed_scale
+    b, s = ids.shape
+    hq, hkv, d = cfg.num_heads, cfg.num_kv_heads, cfg.head_dim
+    ang = torch.arange(s, device=dev).float()[:, None] * model.inv_freq.float()[None]
+    cos, sin = ang.cos(), ang.sin()
+
+    def norm(x, w):
+        return x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + cfg.rms_eps) * (w.float() + cfg.norm_offset)
+
+    def rope(x):
+        x0, x1 = x[..., : d // 2], x[..., d // 2:]
+        return torch.cat([x0 * cos - x1 * sin, x1 * cos + x0 * sin], -1)
+
+    future = torch.triu(torch.ones(s, s, dtype=torch.bool, device=dev), 1)
+    for lw in model.layers:
+        x = norm(h, lw.input_norm)
+        qkv = x @ lw.qkv.dense(torch.float32).t()
+        q = rope(qkv[..., : hq * d].view(b, s, hq, d).transpose(1, 2))
+        k = rope(qkv[..., hq * d:(hq + hkv) * d].view(b, s, hkv, d).transpose(1, 2)).repeat_interleave(hq // hkv, 1)
+        v = qkv[..., (hq + hkv) * d:].view(b, s, hkv, d).transpose(1, 2).repeat_interleave(hq // hkv, 1)
+        sc = (q @ k.transpose(-1, -2) / math.sqrt(d)).masked_fill(future, float("-inf"))
+        a = (torch.softmax(sc, -1) @ v).transpose(1, 2).reshape(b, s, hq * d)
+        h = h + a @ lw.o.dense(torch.float32).t()
+        x = norm(h, lw.post_norm)
+        g = F.silu(x @ lw.gate.dense(torch.float32).t()) * (x @ lw.up.dense(torch.float32).t())
+        h = h + g @ lw.down.dense(torch.float32).t()
+    return norm(h, model.final_norm) @ model.lm_head.dense(torch.float32).t()
 
 
 def build_random_decoder(cfg: DecoderConfig, qtype: int = Q.SYM_INT4, device="cuda", seed: int = 0,

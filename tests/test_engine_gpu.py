@@ -19,39 +19,8 @@ def _tiny(**kw):
 
 def _dense_reference(model, ids):
     """fp32 forward over the dequantized weights: logits for every position."""
-    cfg = model.cfg
-    dev = ids.device
-    h = model.embed[ids].float() * cfg.embed_scale
-    b, s = ids.shape
-    hq, hkv, d = cfg.num_heads, cfg.num_kv_heads, cfg.head_dim
-    inv = model.inv_freq.float()
-    pos = torch.arange(s, device=dev).float()
-    ang = pos[:, None] * inv[None]
-    cos, sin = ang.cos(), ang.sin()
-
-    def norm(x, w):
-        return x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + cfg.rms_eps) * (w.float() + cfg.norm_offset)
-
-    def rope(x):
-        x0, x1 = x[..., : d // 2], x[..., d // 2:]
-        return torch.cat([x0 * cos - x1 * sin, x1 * cos + x0 * sin], -1)
-
-    for lw in model.layers:
-        x = norm(h, lw.input_norm)
-        qkv = x @ lw.qkv.dense(torch.float32).t()
-        q = rope(qkv[..., : hq * d].view(b, s, hq, d).transpose(1, 2))
-        k = rope(qkv[..., hq * d:(hq + hkv) * d].view(b, s, hkv, d).transpose(1, 2))
-        v = qkv[..., (hq + hkv) * d:].view(b, s, hkv, d).transpose(1, 2)
-        k = k.repeat_interleave(hq // hkv, 1)
-        v = v.repeat_interleave(hq // hkv, 1)
-        sc = q @ k.transpose(-1, -2) / math.sqrt(d)
-        sc = sc.masked_fill(torch.triu(torch.ones(s, s, dtype=torch.bool, device=dev), 1), float("-inf"))
-        a = (torch.softmax(sc, -1) @ v).transpose(1, 2).reshape(b, s, hq * d)
-        h = h + a @ lw.o.dense(torch.float32).t()
-        x = norm(h, lw.post_norm)
-        g = torch.nn.functional.silu(x @ lw.gate.dense(torch.float32).t()) * (x @ lw.up.dense(torch.float32).t())
-        h = h + g @ lw.down.dense(torch.float32).t()
-    return norm(h, model.final_norm) @ model.lm_head.dense(torch.float32).t()
+    from bigdl_amd.models.decoder import dense_reference_logits
+    return dense_reference_logits(model, ids)
 
 
 @pytest.mark.parametrize("qt", ["sym_int4", "asym_int4", "fp8_e5m2", "nf4", "fp6"])

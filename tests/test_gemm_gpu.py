@@ -139,3 +139,57 @@ def test_gemm_ex_gate_up_pair(hip, m):
     out = hip.gemm_lowbit_ex(x.cuda(), dg, qt, n, k, w2=du, gamma=gamma.cuda(), gamma_offset=1.0, eps=eps,
                              row_ssq=x.float().square().sum(-1).cuda(), act="silu")
     torch.testing.assert_close(out.cpu().float(), ref, rtol=8e-3, atol=8e-3)
+
+
+def _random_dev_weight(n, k, qt, seed):
+    """Random packed weight in device layout plus its fp32 expansion (built on the GPU: host quantization of a
+    production-sized matrix would dominate the test)."""
+    from bigdl_amd.models.decoder import _random_t16
+    from bigdl_amd.transformers.low_bit_linear import dequant_weight
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(seed)
+    p = _random_t16(n, k, qt, torch.device("cuda"), gen, scale=1.0 / k ** 0.5)
+    return p, dequant_weight(p).float()
+
+
+@pytest.mark.parametrize("shape", [(12288, 4096), (4096, 11008), (4096, 4096), (22016, 4096)], ids=lambda s: f"{s[0]}x{s[1]}")
+@pytest.mark.parametrize("m", [24, 64, 256])
+def test_gemm_at_serving_shapes(hip, m, shape):
+    """The 17..256-row kernel at the Llama-2-7B products of a batched decode / chunked prompt step."""
+    n, k = shape
+    qt = Q.SYM_INT4
+    p, ref_w = _random_dev_weight(n, k, qt, 11)
+    torch.manual_seed(m)
+    x = torch.randn(m, k, device="cuda").half()
+    out = hip.gemm_lowbit(x, p.data, qt, n, k, out_dtype=torch.float32)
+    ref = x.float() @ ref_w.t()
+    torch.testing.assert_close(out, ref, rtol=4e-3, atol=4e-3)
+
+
+@pytest.mark.parametrize("rows_total", [64, 512, 2048])
+def test_grouped_gemm_at_mixtral_shapes(hip, rows_total):
+    """E = 8 experts of 14336 x 4096 (w1/w3) and 4096 x 14336 (w2), top-2 routing, 64..2048 routed rows."""
+    e, top_k, bm = 8, 2, 64
+    qt = Q.SYM_INT4
+    t = rows_total // top_k
+    torch.manual_seed(rows_total)
+    for n, k in ((14336, 4096), (4096, 14336)):
+        p, ref_w = _random_dev_weight(e * n, k, qt, 13)
+        x = torch.randn(t, k, device="cuda").half()
+        ids = torch.stack([torch.randperm(e)[:top_k] for _ in range(t)]).int().cuda()
+        flat = ids.view(-1).long()
+        order = torch.argsort(flat, stable=True)
+        counts = torch.bincount(flat, minlength=e)
+        tok = torch.div(order, top_k, rounding_mode="floor").int()
+        scale = torch.rand(t * top_k, device="cuda")
+        rows = t * top_k
+        table = hip.moe_block_table(counts, bm, (rows + bm - 1) // bm + e)
+        out = hip.gemm_lowbit_grouped(x, p.data, qt, e, n, k, table, rows, bm, x_rows=tok, row_scale=scale[order].contiguous())
+        experts = flat[order]
+        ref = torch.empty(rows, n, device="cuda")
+        for j in range(e):
+            sel = (experts == j).nonzero().squeeze(1)
+            if sel.numel():
+                ref[sel] = (x[tok[sel].long()].float() @ ref_w[j * n:(j + 1) * n].t()) * scale[order][sel, None]
+        torch.testing.assert_close(out.float(), ref, rtol=6e-3, atol=6e-3)
+        del p, ref_w, ref, out
