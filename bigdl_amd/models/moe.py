@@ -23,6 +23,8 @@ models/qwen2_moe.py:104-149, models/common.py:339-354 (``moe_group_topk`` / ``mo
 """
 from __future__ import annotations
 
+import math
+import os
 from typing import Optional
 
 import torch
@@ -78,6 +80,8 @@ class MoEWeights:
         self.group = group                      # process group for the expert-parallel all-reduce
         self.n_local = num_experts if expert_range is None else expert_range[1] - expert_range[0]
         self.ep_mode = "allreduce"              # "a2a": tokens are sharded over the expert-parallel ranks
+        self.ep_capacity_factor = None          # > 0: fixed-shape prompt exchange (None: BIGDL_EP_CAPACITY_FACTOR)
+        self.ep_dropped = 0                     # rows the fixed-shape exchange could not place (device counter)
         self.ep_rank, self.ep_world = 0, 1
         # group-limited routing (DeepSeek-V2): experts in n_group groups, only the topk_group best groups compete
         self.n_group, self.topk_group = 1, 1
@@ -284,9 +288,13 @@ class MoEWeights:
         The fixed-shape alternative (every rank sends a capacity-padded block to every peer) would either move
         world/capacity_factor times the bytes over links that are the bottleneck of this exchange (xGMI is
         point-to-point: an all-to-all is bound per link) or drop rows that overflow; at prompt sizes one host read
-        (~50 us) per layer is the cheaper of the two.  Decode steps use ``forward_gather_scatter`` (fixed shape,
-        graph-captured)."""
+        (~50 us) per layer is the cheaper of the two by default.  ``forward_a2a_capacity`` is that alternative, for
+        callers that want the prompt pass free of host reads.  Decode steps use ``forward_gather_scatter`` (fixed
+        shape, graph-captured)."""
         import torch.distributed as dist
+        cap = float(os.environ.get("BIGDL_EP_CAPACITY_FACTOR", "0") or 0) if self.ep_capacity_factor is None else self.ep_capacity_factor
+        if cap > 0:
+            return self.forward_a2a_capacity(x, cap)
         t, k = x.shape[0], self.top_k
         hdim = x.shape[1]
         per = self.n_local
@@ -317,6 +325,51 @@ class MoEWeights:
         dist.all_to_all_single(back, y.contiguous(), send_n, recv_n, group=self.group)
         out = torch.zeros_like(x)
         out.index_add_(0, tok, back * w.reshape(-1)[order].to(x.dtype)[:, None])
+        return out
+
+    def forward_a2a_capacity(self, x, factor: float):
+        """The same exchange with no host read: every rank sends a block of ``capacity = ceil(factor * T * top_k /
+        world)`` rows to every peer (unused rows carry expert id -1 and cost no FFN work), so both all-to-alls have
+        equal, known splits and the whole layer stays on the device (it can sit inside a captured graph).  A rank
+        that routes more than ``capacity`` rows to one peer drops the excess (they contribute zero, as in
+        capacity-factor MoE training); ``factor = world`` can never drop.  ``self.ep_dropped`` counts dropped rows on
+        the device.  Selected by ``BIGDL_EP_CAPACITY_FACTOR`` or ``ep_capacity_factor``; bytes over the links grow by
+        ``factor`` over the balanced case."""
+        import torch.distributed as dist
+        t, k, W = x.shape[0], self.top_k, self.ep_world
+        hdim, per = x.shape[1], self.n_local
+        n = t * k
+        C = min(n, max(1, math.ceil(factor * n / W)))
+        ids, w = self.route(x, local_only=False)
+        flat = ids.reshape(-1).long()
+        dest = torch.div(flat, per, rounding_mode="floor")
+        order = torch.argsort(dest, stable=True)
+        tok = torch.div(order, k, rounding_mode="floor")
+        dsort = dest[order]
+        counts = torch.zeros(W, dtype=torch.long, device=x.device).scatter_add_(0, dest, torch.ones_like(dest))
+        start = counts.cumsum(0) - counts
+        pos = torch.arange(n, device=x.device) - start[dsort]
+        keep = pos < C
+        slot = torch.where(keep, dsort * C + pos, torch.full_like(pos, W * C))        # row W*C: where the excess lands
+        pad = 8 if x.element_size() == 2 else 4
+        ew = 4 // x.element_size()
+        send = x.new_zeros((W * C + 1, hdim + pad))
+        send[:, hdim:hdim + ew] = torch.full((1,), -1, dtype=torch.int32, device=x.device).view(x.dtype)
+        rows = x.new_empty((n, hdim + pad))
+        rows[:, :hdim] = x[tok]
+        rows[:, hdim:hdim + ew] = (flat[order] % per).to(torch.int32).view(-1, 1).view(x.dtype)
+        rows[:, hdim + ew:] = 0
+        send.index_copy_(0, slot, rows)
+        recv = x.new_empty((W * C, hdim + pad))
+        dist.all_to_all_single(recv, send[:W * C], group=self.group)
+        recv_e = recv[:, hdim:hdim + ew].contiguous().view(torch.int32).view(-1, 1)
+        y = self.local_ffn(recv[:, :hdim].contiguous(), recv_e, torch.ones(W * C, 1, device=x.device))
+        back = x.new_empty((W * C + 1, hdim))
+        dist.all_to_all_single(back[:W * C], y.contiguous(), group=self.group)
+        back[W * C] = 0
+        self.ep_dropped = self.ep_dropped + (~keep).sum()
+        out = torch.zeros_like(x)
+        out.index_add_(0, tok, back[slot] * w.reshape(-1)[order].to(x.dtype)[:, None])
         return out
 
     def forward_gather_scatter(self, x):

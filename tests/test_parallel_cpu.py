@@ -220,6 +220,26 @@ def _ep_worker(rank, port):
     assert ep.n_local == e // WORLD and ep.gate.shape[0] == e // WORLD
     torch.testing.assert_close(ep.forward_a2a(mine), want[rank * 5:(rank + 1) * 5], rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(ep.forward_gather_scatter(mine), want[rank * 5:(rank + 1) * 5], rtol=1e-4, atol=1e-5)
+    # fixed-shape dispatch (no split sizes on the host): exact when the capacity covers the worst case ...
+    ep.ep_capacity_factor = float(WORLD)
+    torch.testing.assert_close(ep.forward_a2a(mine), want[rank * 5:(rank + 1) * 5], rtol=1e-4, atol=1e-5)
+    assert int(ep.ep_dropped) == 0
+    # ... and with a tight capacity the rows over it are dropped, counted, and only their terms are missing
+    ep.ep_capacity_factor = 0.4                              # capacity = ceil(0.4 * 10 / WORLD) rows per peer
+    cap = -(-int(0.4 * 10 * 1000) // (WORLD * 1000))
+    got = ep.forward_a2a(mine)
+    ids_m, w_m = full.route(mine, local_only=False)
+    dest = (ids_m.reshape(-1) // ep.n_local)
+    order = torch.argsort(dest, stable=True)
+    seen, kept = {}, torch.zeros(10, dtype=torch.bool)
+    for j in order.tolist():
+        d = int(dest[j])
+        seen[d] = seen.get(d, 0) + 1
+        kept[j] = seen[d] <= cap
+    assert int(ep.ep_dropped) == int((~kept).sum()) > 0
+    partial = full.local_ffn(mine, torch.where(kept.view(5, 2), ids_m, torch.full_like(ids_m, -1)), w_m)
+    torch.testing.assert_close(got, partial, rtol=1e-4, atol=1e-5)
+    ep.ep_capacity_factor = None
     # tokens replicated: partial sums + all-reduce
     rep = make().shard_experts(rank, WORLD, None, mode="allreduce")
     ids_l, w_l = rep.route(x_all, local_only=True)
