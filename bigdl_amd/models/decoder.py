@@ -1380,14 +1380,19 @@ class NativeDecoder:
     @torch.no_grad()
     def generate(self, input_ids: torch.Tensor, max_new_tokens: int = 32, min_new_tokens: int = 0, do_sample=False,
                  temperature=1.0, top_k=0, top_p=1.0, repetition_penalty=1.0, eos_token_id=None, pad_token_id=None,
-                 streamer=None, kv_fp8: bool = False, stopping=None, inputs_embeds=None, mrope_positions=None):
+                 streamer=None, kv_fp8: bool = False, stopping=None, inputs_embeds=None, mrope_positions=None,
+                 attention_mask=None):
         """Greedy / sampling generation with per-token timing in the reference benchmark's terms.  ``inputs_embeds``
         [B, S, hidden] / ``mrope_positions`` [3, B, S]: a multimodal prompt as its wrapper model prepared it (the
-        token ids are still what is returned in front of the generated tokens)."""
+        token ids are still what is returned in front of the generated tokens).  ``attention_mask`` [B, S] with
+        padding (left or right): every row becomes a cache slot with its own length -- the prompts run packed in one
+        pass without their pad tokens, positions count from each row's first real token, and the decode steps read
+        the per-slot lengths on the device."""
         from ..ops import hip
         dev = self.device
         input_ids = input_ids.to(dev)
         b, s = input_ids.shape
+        ragged = attention_mask is not None and not bool(attention_mask.all())
         self.ensure_cache(b, s + max_new_tokens + 1, fp8=kv_fp8)
         self.cache.reset()
         eos = set([eos_token_id] if isinstance(eos_token_id, int) else (eos_token_id or []))
@@ -1395,7 +1400,17 @@ class NativeDecoder:
         torch.cuda.synchronize()
         torch.cuda.reset_peak_memory_stats()
         t0 = time.perf_counter()
-        logits = self.prefill(input_ids, inputs_embeds=inputs_embeds, mrope_positions=mrope_positions)[:, -1, :]
+        if ragged:
+            assert inputs_embeds is None and mrope_positions is None, "padded batches carry token ids only"
+            keep = attention_mask.to(dev).bool()
+            prompts = [input_ids[i][keep[i]].tolist() for i in range(b)]
+            assert all(prompts), "a batch row without any real token"
+            self.cache.enable_slots()
+            logits = self.prefill_packed(prompts, list(range(b)))
+            for i in range(b):
+                self.cache.set_active(i, True)
+        else:
+            logits = self.prefill(input_ids, inputs_embeds=inputs_embeds, mrope_positions=mrope_positions)[:, -1, :]
         out = [input_ids]
         unfinished = torch.ones(b, dtype=torch.bool, device=dev)
         all_ids = input_ids

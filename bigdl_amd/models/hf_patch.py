@@ -678,8 +678,9 @@ def native_generate(self, inputs=None, **kwargs):
                   and plain_keys <= _PLAIN_GENERATE_KEYS and kwargs.get("num_beams", 1) == 1
                   and not kwargs.get("return_dict_in_generate", False) and native_engine_supported(self))
     am = kwargs.get("attention_mask")
-    if try_native and am is not None and not bool(am.all()):
-        try_native = False  # left-padded batches go through the HF path
+    ragged = try_native and am is not None and not bool(am.all())
+    if ragged and (vl_inputs or am.shape != input_ids.shape or not bool(am.any(-1).all())):
+        try_native = False  # padded multimodal prompts / an all-padding row: HF path
     if not try_native:
         if input_ids is not None:
             kwargs["input_ids"] = input_ids
@@ -697,7 +698,7 @@ def native_generate(self, inputs=None, **kwargs):
         extra = dict(inputs_embeds=embeds, mrope_positions=pos if pos is not None and pos.dim() == 3 else None)
     # IPEX_LLM_COMPRESS_KV_CACHE=1: SnapKV selection at the end of every layer's prompt pass (engine prefill)
     eng.compress_kv = dict(window_size=32, max_capacity_prompt=1024, kernel_size=7, pooling="maxpool") \
-        if should_use_compresskv(None, input_ids.shape[1]) else None
+        if should_use_compresskv(None, input_ids.shape[1]) and not ragged else None
     out = eng.generate(
         input_ids, max_new_tokens=max_new, min_new_tokens=kwargs.get("min_new_tokens", 0) or 0,
         do_sample=kwargs.get("do_sample", getattr(gc, "do_sample", False)) or False,
@@ -707,7 +708,7 @@ def native_generate(self, inputs=None, **kwargs):
         repetition_penalty=kwargs.get("repetition_penalty", getattr(gc, "repetition_penalty", 1.0)) or 1.0,
         eos_token_id=kwargs.get("eos_token_id", getattr(gc, "eos_token_id", None)),
         pad_token_id=kwargs.get("pad_token_id", getattr(gc, "pad_token_id", None)),
-        streamer=kwargs.get("streamer"), kv_fp8=engine_kv_mode(), **extra)
+        streamer=kwargs.get("streamer"), kv_fp8=engine_kv_mode(), attention_mask=am if ragged else None, **extra)
     for attr in ("first_cost", "rest_cost_mean", "first_token_time", "last_token_time", "peak_memory"):
         object.__setattr__(self, attr, getattr(eng, attr))
     return out

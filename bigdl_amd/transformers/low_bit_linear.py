@@ -451,12 +451,31 @@ class _HalfLinear(nn.Linear):
             self.weight.data = self.weight.data.to(self._dtype)
         if self.bias is not None and self.bias.dtype != self._dtype:
             self.bias.data = self.bias.data.to(self._dtype)
-        result = F.linear(x.to(self._dtype), self.weight)
+        result = self._skinny(x)
+        if result is None:
+            result = F.linear(x.to(self._dtype), self.weight)
+            if self.mp_group is None and self.bias is not None:
+                result = result + self.bias
         if self.mp_group is not None:
             result = _all_reduce(result, self.mp_group)
-        if self.bias is not None:
-            result = result + self.bias
+            if self.bias is not None:
+                result = result + self.bias
         return result.to(x.dtype)
+
+    def _skinny(self, x):
+        """The decode-sized product (<= 16 rows) on this repo's streaming fp16 kernel (csrc/hip/gemv_f16.hip; bias in
+        its epilogue unless a tensor-parallel sum comes first) instead of a library GEMM.  None: not applicable."""
+        if self._dtype != torch.float16 or x.device.type != "cuda" or (torch.is_grad_enabled() and x.requires_grad):
+            return None
+        rows = x.numel() // x.shape[-1] if x.shape[-1] else 0
+        from ..ops import hip
+        if not hip.gemv_f16_ok(rows, self.out_len, self.in_len) or not self.weight.is_contiguous():
+            return None
+        x2 = x.reshape(rows, self.in_len).to(torch.float16)
+        if x2.stride(1) != 1:
+            x2 = x2.contiguous()
+        y = hip.gemv_f16(x2, self.weight.data, bias=self.bias.data if self.bias is not None and self.mp_group is None else None)
+        return y.view(*x.shape[:-1], self.out_len)
 
 
 class FP16Linear(_HalfLinear):

@@ -90,6 +90,61 @@ def test_padded_mlp_runs_on_the_engine_and_round_trips(tmp_path):
     assert torch.equal(again.generate(ids, max_new_tokens=10, do_sample=False), out_native)
 
 
+@pytest.mark.parametrize("side", ["left", "right"])
+def test_padded_batch_generates_on_the_engine(tiny, side):
+    """A batch with padding goes to the engine (one cache slot per row, prompts packed without their pad tokens):
+    every row continues exactly as it does alone, and as HuggingFace's generate continues the left-padded batch."""
+    from ipex_llm.transformers import AutoModelForCausalLM
+    d, _ = tiny
+    q = AutoModelForCausalLM.from_pretrained(d, load_in_4bit=True).half().to("cuda")
+    q.generation_config.pad_token_id = 0
+    torch.manual_seed(1)
+    lens = [20, 7, 13, 20]
+    S = max(lens)
+    ids = torch.zeros(4, S, dtype=torch.long)
+    mask = torch.zeros(4, S, dtype=torch.long)
+    rows = [torch.randint(3, 320, (n,)) for n in lens]
+    for i, r in enumerate(rows):
+        sl = slice(S - len(r), S) if side == "left" else slice(0, len(r))
+        ids[i, sl], mask[i, sl] = r, 1
+    ids, mask = ids.cuda(), mask.cuda()
+    out = q.generate(ids, attention_mask=mask, max_new_tokens=8, do_sample=False)
+    eng = q._native_engine
+    assert eng.cache.slot_len is not None and sorted(eng.cache.slot_len) == sorted(n + 7 for n in lens)   # engine, slot mode
+    assert out.shape == (4, S + 8) and torch.equal(out[:, :S], ids)
+    for i, r in enumerate(rows):
+        alone = q.generate(r.view(1, -1).cuda(), max_new_tokens=8, do_sample=False)
+        assert (alone[0, len(r):] == out[i, S:]).float().mean() >= 0.85, (i, alone[0, len(r):], out[i, S:])
+    if side == "left":
+        hf = q._hf_generate(ids, attention_mask=mask, max_new_tokens=8, do_sample=False)
+        assert (hf[:, S:] == out[:, S:]).float().mean() > 0.85
+
+
+@pytest.mark.parametrize("rows,bias", [(1, False), (5, True), (16, True), (17, True)])
+def test_fp16_linear_decode_rows_use_the_streaming_kernel(rows, bias):
+    """FP16Linear with <= 16 rows runs hip.gemv_f16 (bias in the epilogue); more rows take the dense product."""
+    from bigdl_amd.ops import hip
+    from bigdl_amd.transformers.low_bit_linear import FP16Linear
+    torch.manual_seed(rows)
+    lin = FP16Linear(512, 384, bias=bias)
+    lin.weight.data = (torch.randn(384, 512) * 0.05).half()
+    if bias:
+        lin.bias.data = (torch.randn(384) * 0.1).half()
+    lin = lin.cuda()
+    x = torch.randn(1, rows, 512).half().cuda()
+    seen = []
+    real = hip.gemv_f16
+    hip.gemv_f16 = lambda *a, **k: (seen.append(1), real(*a, **k))[1]
+    try:
+        y = lin(x)
+    finally:
+        hip.gemv_f16 = real
+    assert len(seen) == (1 if rows <= 16 else 0)
+    ref = x.float() @ lin.weight.float().t() + (lin.bias.float() if bias else 0)
+    assert y.shape == (1, rows, 384) and y.dtype == torch.float16
+    torch.testing.assert_close(y.float(), ref, rtol=5e-3, atol=5e-3)
+
+
 def test_save_from_gpu_and_reload(tiny, tmp_path):
     from ipex_llm.transformers import AutoModelForCausalLM
     d, _ = tiny
