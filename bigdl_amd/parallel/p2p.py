@@ -63,6 +63,14 @@ class PipelineLink:
     def recv_tokens(self, t):
         return self._recv(t, self.tail, self.back)
 
+    def broadcast_from_head(self, t):
+        """``t`` of the first stage to every stage (same shape everywhere); returns the tensor on ``t``'s device."""
+        if self.n == 1:
+            return t
+        x = t.cpu() if self.host_staged and t.is_cuda else t
+        dist.broadcast(x, src=self.head, group=self.fwd)
+        return x.to(t.device)
+
 
 class _Done:
     def wait(self):

@@ -14,7 +14,9 @@ What is different here, and why:
   ring; a broadcast of every token would make the middle stages wait for the tail.  With two communicators the
   forward chain is acyclic (the tail never sends on it) and nothing else synchronises the stages.
 * ``micro_batches`` sequences groups are in flight at once (shallow copies of the stage share the weights and own a
-  cache + graph each), so with as many micro-batches as stages every GPU is busy every tick.
+  cache + graph each).  The first stage takes a micro-batch's token right before that micro-batch's next step and
+  waits for nothing else, so with as many micro-batches as stages every GPU is busy every tick
+  (tests/test_pipeline_schedule_cpu.py measures the first stage's idle share on a timed stand-in).
 * sends are asynchronous: a message buffer is only waited on right before its next reuse, one full pipeline round
   later.
 * the stop decision (all sequences hit EOS) is taken on the first stage and rides in 8 spare halves at the end of the
@@ -165,18 +167,40 @@ class EnginePipeline:
             if streamer is not None:
                 streamer.put(input_ids.cpu())
                 streamer.put(torch.cat([t[-1] for t in toks]).view(bsz, 1).cpu())
+        streamed = 1                          # generated positions already handed to the streamer
 
-        # ---- decode steps: one graph replay per (step, micro-batch) on every stage
+        # ---- decode steps: one graph replay per (step, micro-batch) on every stage.  The first stage takes lane m's
+        # token right before lane m's next step and nothing else waits: while it waits for lane 0, the later stages are
+        # still working on lanes 1.., so with as many lanes as stages no stage idles.  No host synchronisation per
+        # step; step times come from events.
         unfinished = [torch.ones(c.shape[0], dtype=torch.bool) for c in chunks]
+        scanned = [0] * nmb                   # tokens of each lane already looked at for EOS
         stop_host = False
         steps_done = 1
-        for step in range(1, max_new_tokens):
-            if link.first and eos and step >= min_new_tokens:
-                for m in range(nmb):
-                    for i, t in enumerate(toks[m][-1].tolist()):
+        on_gpu = dev.type == "cuda"
+        marks = []                            # first stage: one event (GPU) / host time (CPU) per step
+        self.wait_s = 0.0                     # host time this stage spent blocked on a receive (decode phase)
+        loop_t0 = time.perf_counter()
+        if on_gpu:
+            loop_ev = torch.cuda.Event(enable_timing=True)
+            loop_ev.record()
+
+        def collect(m):
+            t = torch.empty(chunks[m].shape[0], dtype=torch.int64, device=dev)
+            tic = time.perf_counter()
+            link.recv_tokens(t).wait()
+            self.wait_s += time.perf_counter() - tic
+            toks[m].append(t)
+
+        def scan_eos(m):
+            for j in range(scanned[m], len(toks[m])):
+                if j + 1 >= max(min_new_tokens, 1):
+                    for i, t in enumerate(toks[m][j].tolist()):
                         if t in eos:
                             unfinished[m][i] = False
-                stop_host = not any(bool(u.any()) for u in unfinished)
+            scanned[m] = len(toks[m])
+
+        for step in range(1, max_new_tokens):
             check = step % STOP_CHECK_EVERY == STOP_CHECK_EVERY - 1
             stop_seen = False
             for m, e in enumerate(lanes):
@@ -187,11 +211,18 @@ class EnginePipeline:
                     pending[m][0].wait()
                     pending[m] = None
                 if link.first:
+                    if link.n > 1 and len(toks[m]) < step:
+                        collect(m)
+                    if eos and check:            # (host read of the tokens: only every few steps)
+                        scan_eos(m)
+                        stop_host = m == nmb - 1 and not any(bool(u.any()) for u in unfinished)
                     st["tokens"].copy_(toks[m][-1].view(b, 1))
                     if stop_host:
                         msg[-FLAG_HALVES:].fill_(1.0)
                 else:
+                    tic = time.perf_counter()
                     link.recv_hidden(msg).wait()
+                    self.wait_s += time.perf_counter() - tic
                 e.decode(None, 1, chain=False)
                 self.ticks_busy += 1
                 if link.last:
@@ -204,24 +235,45 @@ class EnginePipeline:
                     pending[m] = (link.send_hidden(msg), msg)
                 if check and float(msg[-FLAG_HALVES]) != 0.0:      # (host read: only every few steps)
                     stop_seen = True
-            if link.first and link.n > 1:
-                for m in range(nmb):
-                    t = torch.empty(chunks[m].shape[0], dtype=torch.int64, device=dev)
-                    link.recv_tokens(t).wait()
-                    toks[m].append(t)
             steps_done += 1
             if link.first:
-                if streamer is not None:
-                    streamer.put(torch.cat([t[-1] for t in toks]).view(bsz, 1).cpu())
-                sync()
-                t1 = time.perf_counter()
-                times.append(t1 - t0)
-                t0 = t1
+                if streamer is not None:         # one step behind: the tokens every lane has already delivered
+                    have = min(len(t) for t in toks)
+                    while streamed < have:
+                        streamer.put(torch.cat([t[streamed] for t in toks]).view(bsz, 1).cpu())
+                        streamed += 1
+                if on_gpu:
+                    ev = torch.cuda.Event(enable_timing=True)
+                    ev.record()
+                    marks.append(ev)
+                else:
+                    marks.append(time.perf_counter())
             if stop_seen:
                 break
+        if link.first and link.n > 1:
+            for m in range(nmb):
+                if len(toks[m]) < steps_done:
+                    collect(m)
         for p in pending:
             if p is not None:
                 p[0].wait()
+        if link.first:
+            if streamer is not None:
+                while streamed < steps_done:
+                    streamer.put(torch.cat([t[streamed] for t in toks]).view(bsz, 1).cpu())
+                    streamed += 1
+            sync()
+            if on_gpu and marks:
+                prev = loop_ev
+                for mk in marks:
+                    times.append(prev.elapsed_time(mk) * 1e-3)
+                    prev = mk
+            elif marks:
+                prev = t0
+                for mk in marks:
+                    times.append(mk - prev)
+                    prev = mk
+        self.decode_wall_s = time.perf_counter() - loop_t0
         for e in lanes:                       # a flag left in a message buffer must not stop the next call
             for st in e._static.values():
                 st["msg"][-FLAG_HALVES:].zero_()
@@ -244,17 +296,13 @@ class EnginePipeline:
         else:
             shape = torch.zeros(1, dtype=torch.int64, device=dev)
         if link.n > 1:
-            shape_x = shape.cpu() if link.host_staged else shape
-            dist.broadcast(shape_x, src=link.head, group=link.fwd)
+            width = int(link.broadcast_from_head(shape))
             if not link.first:
-                out_ids = torch.empty(bsz, int(shape_x), dtype=torch.int64, device=dev)
-            out_x = out_ids.cpu() if link.host_staged else out_ids
-            dist.broadcast(out_x, src=link.head, group=link.fwd)
-            out_ids = out_x.to(dev)
-            stats = torch.tensor([times[0] if times else 0.0, sum(times[1:]) / max(1, len(times) - 1)], dtype=torch.float64)
-            stats_x = stats if link.host_staged else stats.to(dev)
-            dist.broadcast(stats_x, src=link.head, group=link.fwd)
-            first, rest = stats_x.tolist()
+                out_ids = torch.empty(bsz, width, dtype=torch.int64, device=dev)
+            out_ids = link.broadcast_from_head(out_ids)
+            stats = torch.tensor([times[0] if times else 0.0, sum(times[1:]) / max(1, len(times) - 1)], dtype=torch.float64,
+                                 device=dev)
+            first, rest = link.broadcast_from_head(stats).tolist()
         else:
             first, rest = times[0], sum(times[1:]) / max(1, len(times) - 1)
         if streamer is not None and link.first:
