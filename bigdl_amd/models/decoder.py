@@ -827,15 +827,23 @@ class NativeDecoder:
     packed_with_decode = True            # prefill_packed(with_decode=True) exists (serving/continuous.py asks)
 
     @torch.no_grad()
-    def prefill_packed(self, prompts, slots, with_decode: bool = False):
+    def prefill_packed(self, prompts, slots, with_decode: bool = False, hidden: Optional[torch.Tensor] = None,
+                       lens: Optional[list] = None):
         """Several whole prompts (lists of token ids) into empty cache slots in ONE pass: norms, projections and the MLP
         run over the concatenated rows (one read of the weights for all prompts, what short chat prompts need: a
         32-token prompt alone costs 6 ms on a 7B model, mostly weight traffic), attention and the cache append run per
         prompt.  Returns the last-position logits [len(prompts), V].  The reference batches the prompt phase of
         several requests the same way (``max_prefilled_seqs``,
-        python/llm/src/ipex_llm/transformers/pipeline_parallel.py:807-927)."""
+        python/llm/src/ipex_llm/transformers/pipeline_parallel.py:807-927).
+
+        Pipeline stages: a later stage passes ``prompts=None`` with ``hidden`` [rows, hidden] (the previous stage's
+        output for the same packed rows) and ``lens``; a stage that is not the last returns its [rows, hidden] output
+        instead of logits."""
         from ..ops import hip
         cfg, cache = self.cfg, self.cache
+        if not self.stage_first:
+            assert hidden is not None and lens is not None and not with_decode, "a later stage is fed packed hidden rows"
+            prompts = [None] * len(lens)
         assert cache.slot_len is not None and len(prompts) == len(slots) > 0
         nd, st = 0, None
         if with_decode:
@@ -844,22 +852,25 @@ class NativeDecoder:
             assert max(cache.slot_len) + 1 <= cache.capacity, "KV cache capacity exceeded"
             nd = cache.batch
             st = self._get_graph(nd, 1, True)[1]
-        lens = [len(p) for p in prompts]
+        lens = [len(p) for p in prompts] if self.stage_first else [int(n) for n in lens]
         assert all(cache.slot_len[sl] == 0 and not cache.active_host[sl] for sl in slots), "packed prompts go to empty slots"
         assert max(lens) <= cache.capacity, "KV cache capacity exceeded"
         offs = [0]
         for n in lens:
             offs.append(offs[-1] + n)
-        ids = torch.tensor([t for p in prompts for t in p], dtype=torch.int64, device=self.device)
-        h = F.embedding(ids, self.embed).to(torch.float16)
-        if cfg.embed_scale != 1.0:
-            h = h * cfg.embed_scale
-        pos = torch.cat([torch.arange(n, device=self.device) for n in lens])
-        if nd:
-            hd = F.embedding(st["tokens"].view(-1), self.embed).to(torch.float16)
-            h = torch.cat([h, hd * cfg.embed_scale if cfg.embed_scale != 1.0 else hd])
-            pos = torch.cat([pos, cache.past_len.to(torch.int64)])
-        h = self._embed_extras(h, pos)
+        if self.stage_first:
+            ids = torch.tensor([t for p in prompts for t in p], dtype=torch.int64, device=self.device)
+            h = F.embedding(ids, self.embed).to(torch.float16)
+            if cfg.embed_scale != 1.0:
+                h = h * cfg.embed_scale
+            pos = torch.cat([torch.arange(n, device=self.device) for n in lens])
+            if nd:
+                hd = F.embedding(st["tokens"].view(-1), self.embed).to(torch.float16)
+                h = torch.cat([h, hd * cfg.embed_scale if cfg.embed_scale != 1.0 else hd])
+                pos = torch.cat([pos, cache.past_len.to(torch.int64)])
+            h = self._embed_extras(h, pos)
+        else:
+            h = hidden.to(torch.float16).reshape(offs[-1], cfg.hidden_size)
         hq, hkv, d = cfg.num_heads, cfg.num_kv_heads, cfg.head_dim
         rot = cfg.rot_dim or d
         for li, lw in enumerate(self.layers):
@@ -906,6 +917,8 @@ class NativeDecoder:
         for j, slot in enumerate(slots):
             cache.past_len[slot] += lens[j]
             cache.slot_len[slot] += lens[j]
+        if not self.stage_last:
+            return h
         last = torch.tensor([o - 1 for o in offs[1:]] + list(range(offs[-1], offs[-1] + nd)), device=self.device)
         x = self._norm(h[last], self.final_norm, self.final_norm_b)
         logits = self._finish_logits(self._linear_dense(x, self.lm_head).float())

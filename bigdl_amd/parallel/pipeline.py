@@ -37,8 +37,9 @@ import torch
 import torch.distributed as dist
 
 from .p2p import PipelineLink  # noqa: F401
-from ..transformers.pipeline_parallel import (PPModelWorker, init_pipeline_parallel, layer_range,  # noqa: F401
-                                              pipeline_parallel, pipeline_parallel_generate)
+from ..transformers.pipeline_parallel import (HEADER_FIXED, KIND_FREE, KIND_STEP, BatchTask, PPModelWorker,  # noqa: F401
+                                              init_pipeline_parallel, layer_range, pipeline_parallel,
+                                              pipeline_parallel_generate)
 
 STOP_CHECK_EVERY = 4
 FLAG_HALVES = 8          # tail of every hidden-state message: [stop, 7 spare] (fp16)
@@ -313,3 +314,207 @@ class EnginePipeline:
         if dev.type == "cuda":
             self.peak_memory = torch.cuda.max_memory_reserved() / (1024 ** 3)
         return out_ids
+
+
+class EnginePPWorker(PPModelWorker):
+    """The continuous-batching pipeline worker (``PPModelWorker``: admission, headers that travel with the data, up to
+    ``world_size`` micro-batches in flight, text streaming) with every stage step run by a native engine stage instead
+    of HuggingFace modules: a decode step of a micro-batch is one hipGraph replay over that micro-batch's cache slots,
+    and a prompt pass runs the admitted prompts packed, without padding.
+
+    Partial prefill: with ``max_prefilled_seqs = P`` a micro-batch of B > P admitted sequences goes through its prompt
+    phase in pieces of P sequences.  Every piece travels round the pipeline as a step of its own (other micro-batches'
+    decode steps run in between, so one large admission never blocks the stages for a whole B-prompt pass), fills its
+    own cache slots on every stage -- the "joined" cache is simply the micro-batch's slot-mode cache once all pieces are
+    in -- and returns the first token of its sequences to the head; when the last piece is back the micro-batch starts
+    decoding all B sequences together.  Reference: ``max_prefilled_seqs`` / ``partial_prefilling`` / ``cat_kv_cache``
+    in python/llm/src/ipex_llm/transformers/pipeline_parallel.py:545-591, 621-700, 807-927.
+    """
+
+    def __init__(self, stage_engine, rank, world_size, max_num_seqs, max_prefilled_seqs=0, tokenizer=None, link=None,
+                 max_seq_len: int = 2048, kv_fp8=False):
+        self.engine = stage_engine
+        self.model = None
+        self.dtype = torch.float16
+        self.device = stage_engine.device
+        self.max_seq_len, self.kv_fp8 = max_seq_len, kv_fp8
+        self.lanes = {}                     # serial -> [engine view, decoding?]
+        self._idle_lanes = []
+        self.prompt_passes = 0              # prompt pieces this stage has run
+        self._init_state(rank, world_size, max_num_seqs, max_prefilled_seqs, tokenizer, link)
+
+    # -- per-micro-batch engine views -----------------------------------------------------------
+    def _lane(self, serial):
+        ent = self.lanes.get(serial)
+        if ent is None:
+            if self._idle_lanes:
+                e = self._idle_lanes.pop()
+            else:
+                e = copy.copy(self.engine)
+                e.cache, e._graphs, e._static = None, {}, {}
+            e.ensure_cache(self.max_num_seqs, self.max_seq_len, fp8=self.kv_fp8)
+            e.cache.enable_slots()
+            ent = self.lanes[serial] = [e, False]
+        return ent
+
+    def clear_batch(self, cur_id):
+        super().clear_batch(cur_id)
+        ent = self.lanes.pop(int(str(cur_id).rsplit("_", 1)[-1]), None)
+        if ent is not None:
+            self._idle_lanes.append(ent[0])
+
+    def clean_cache(self):
+        super().clean_cache()
+        for ent in getattr(self, "lanes", {}).values():
+            self._idle_lanes.append(ent[0])
+        if hasattr(self, "lanes"):
+            self.lanes.clear()
+
+    # -- stage steps ----------------------------------------------------------------------------
+    def _prompt_piece(self, serial, start, lens, prompts=None, hidden=None):
+        e = self._lane(serial)[0]
+        slots = list(range(start, start + len(lens)))
+        self.prompt_passes += 1
+        if self.pp_config.is_head:
+            out = e.prefill_packed(prompts, slots)
+        else:
+            out = e.prefill_packed(None, slots, hidden=hidden, lens=lens)
+        if self.pp_config.is_tail:
+            return out.argmax(-1)                                   # [count] first tokens
+        return out                                                  # [rows, hidden]
+
+    def _decode(self, serial, bs, tokens=None):
+        ent = self._lane(serial)
+        e = ent[0]
+        if not ent[1]:                                              # first decode step: every sequence is in its slot
+            for sl in range(bs):
+                e.cache.set_active(sl, True)
+            ent[1] = True
+        g, st = e._get_graph(self.max_num_seqs, 1, False)
+        if tokens is not None:
+            st["tokens"][:bs].copy_(tokens.view(bs, 1))
+        return e, st
+
+    # -- head -----------------------------------------------------------------------------------
+    def _admit(self):
+        reqs = []
+        while len(reqs) < self.max_num_seqs and not self.waiting_requests.empty():
+            reqs.append(self.waiting_requests.get_nowait())
+        if not reqs:
+            return None, None
+        lens = [len(r[1]) for r in reqs]
+        self._serial += 1
+        room = [max(1, self.max_seq_len - n - 1) for n in lens]
+        task = BatchTask(batch_id=f"batch_{self._serial}", request_ids=[r[0] for r in reqs],
+                         max_tokens=max(min(r[2], rm) for r, rm in zip(reqs, room)), batch_size=len(reqs),
+                         input_len=max(lens), prompt_lengths=lens)
+        task.request_max = [min(r[2], rm) for r, rm in zip(reqs, room)]
+        task.serial, task.step_no = self._serial, 0
+        task.prompts = [list(r[1]) for r in reqs]
+        p = self.max_prefilled_seqs if self.max_prefilled_seqs and self.max_prefilled_seqs > 0 else len(reqs)
+        task.pieces = [(i, min(p, len(reqs) - i)) for i in range(0, len(reqs), p)]
+        task.next_piece = 0
+        task.first_tokens = []
+        return task, None
+
+    @torch.no_grad()
+    def _head_step(self, task, inp):
+        self.trace.append((task.serial, task.step_no))
+        if task.next_piece < len(task.pieces):
+            start, count = task.pieces[task.next_piece]
+            lens = task.prompt_lengths[start:start + count]
+            out = self._prompt_piece(task.serial, start, lens, prompts=task.prompts[start:start + count])
+            if self.link is None:
+                self._local_tokens.append(out.view(-1, 1))
+            else:
+                self._send_header(KIND_STEP, task, n_tokens=sum(lens), step_no=0, piece=(start, count))
+                out = out.contiguous()
+                self._post(self.link.send_hidden(out), out)
+        else:
+            e, st = self._decode(task.serial, task.batch_size, inp)
+            e.decode(None, 1, chain=False)
+            if self.link is None:
+                self._local_tokens.append(st["next"][:task.batch_size].clone().view(-1, 1))
+            else:
+                self._send_header(KIND_STEP, task, n_tokens=0, step_no=task.step_no)
+                # (the lane's message buffer is next written by this micro-batch's next step, a full round trip away)
+                self._post(self.link.send_hidden(st["msg"]), st["msg"])
+        self.inflight.append(task)
+        self.max_inflight = max(self.max_inflight, len(self.inflight))
+
+    def _head_collect(self):
+        task = self.inflight.popleft()
+        prompt_phase = task.next_piece < len(task.pieces)
+        n = task.pieces[task.next_piece][1] if prompt_phase else task.batch_size
+        if self.link is None:
+            next_ids = self._local_tokens.popleft()
+        else:
+            next_ids = torch.empty(n, 1, dtype=torch.int64, device=self.device)
+            self.link.recv_tokens(next_ids).wait()
+        if prompt_phase:
+            start = task.pieces[task.next_piece][0]
+            task.first_tokens.append(next_ids)
+            self._emit(task, next_ids.view(-1).tolist(), 0, first=start)       # first tokens stream as their piece returns
+            task.next_piece += 1
+            if task.next_piece < len(task.pieces):
+                self._head_step(task, None)
+                return None
+            next_ids = torch.cat(task.first_tokens)
+            self.tokens.setdefault(task.batch_id, []).append(next_ids)
+            done = all(self.is_finish.get(rid) for rid in task.request_ids)
+        else:
+            self.tokens.setdefault(task.batch_id, []).append(next_ids)
+            done = self._emit(task, next_ids.view(-1).tolist(), task.step_no)
+        if done:
+            gen = torch.cat(self.tokens[task.batch_id], 1)
+            self.results[task.batch_id] = gen
+            self.clear_batch(task.batch_id)
+            if self.link is not None:
+                self._send_header(KIND_FREE, task)
+            return gen
+        task.step_no += 1
+        self._head_step(task, next_ids)
+        return None
+
+    # -- later stages ---------------------------------------------------------------------------
+    @torch.no_grad()
+    def _serve_one(self):
+        h = self._recv_header()
+        kind, serial, bs, n, step_no, max_tokens, start, count = h[:HEADER_FIXED]
+        task = BatchTask(batch_id=f"batch_{serial}", request_ids=[], max_tokens=max_tokens, batch_size=bs, input_len=n,
+                         prompt_lengths=h[HEADER_FIXED: HEADER_FIXED + (count or bs)])
+        task.serial, task.step_no = serial, step_no
+        if kind != KIND_STEP:
+            if kind == KIND_FREE:
+                self.clear_batch(task.batch_id)
+            else:
+                self.stopped = True
+            if not self.pp_config.is_tail:
+                self._send_header(kind, task)
+            return kind
+        self.trace.append((serial, step_no))
+        hidden_size = self.engine.cfg.hidden_size
+        if n > 0:                                                   # a prompt piece
+            hidden = torch.empty(n, hidden_size, device=self.device, dtype=torch.float16)
+            self.link.recv_hidden(hidden).wait()
+            lens = task.prompt_lengths[:count]
+            out = self._prompt_piece(serial, start, lens, hidden=hidden)
+            if self.pp_config.is_tail:
+                out = out.view(-1, 1).contiguous()
+                self._post(self.link.send_tokens(out), out)
+            else:
+                task.prompt_lengths = [0] * start + list(lens)      # (_send_header slices the piece out again)
+                self._send_header(KIND_STEP, task, n_tokens=n, step_no=0, piece=(start, count))
+                out = out.contiguous()
+                self._post(self.link.send_hidden(out), out)
+            return kind
+        e, st = self._decode(serial, bs)
+        self.link.recv_hidden(st["msg"]).wait()
+        e.decode(None, 1, chain=False)
+        if self.pp_config.is_tail:
+            out = st["next"][:bs].clone().view(-1, 1)
+            self._post(self.link.send_tokens(out), out)
+        else:
+            self._send_header(KIND_STEP, task, n_tokens=0, step_no=step_no)
+            self._post(self.link.send_hidden(st["msg"]), st["msg"])
+        return kind

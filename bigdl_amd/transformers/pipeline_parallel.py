@@ -268,7 +268,7 @@ def make_attention_mask(prompt_lengths, device):
 
 
 KIND_STEP, KIND_FREE, KIND_STOP = 1, 2, 3
-HEADER_FIXED = 8          # [kind, serial, batch_size, n_tokens, step_no, max_tokens, 0, 0] + prompt lengths
+HEADER_FIXED = 8          # [kind, serial, batch_size, n_tokens, step_no, max_tokens, piece start, piece count] + prompt lengths
 
 
 class PPModelWorker:
@@ -288,16 +288,19 @@ class PPModelWorker:
 
     def __init__(self, checkpoint, rank, world_size, low_bit, max_num_seqs, max_prefilled_seqs=0,
                  torch_dtype=torch.float16, model=None, tokenizer=None, link=None):
+        self.dtype = torch_dtype
+        self.model = model if model is not None else self.load_model(checkpoint, world_size, low_bit)
+        self.device = next(p for p in self.model.parameters() if p.numel() > 0).device
+        self._init_state(rank, world_size, max_num_seqs, max_prefilled_seqs, tokenizer, link)
+
+    def _init_state(self, rank, world_size, max_num_seqs, max_prefilled_seqs, tokenizer, link):
         from collections import deque
         from ..parallel.p2p import PipelineLink
         self.pp_config = PPConfig(rank, world_size)
-        self.dtype = torch_dtype
         self.rank, self.world_size = rank, world_size
         self.pre_rank, self.next_rank = (rank - 1) % world_size, (rank + 1) % world_size
         self.max_num_seqs = max_num_seqs
         self.max_prefilled_seqs = max_prefilled_seqs
-        self.model = model if model is not None else self.load_model(checkpoint, world_size, low_bit)
-        self.device = next(p for p in self.model.parameters() if p.numel() > 0).device
         self.tokenizer = tokenizer
         self.link = link if link is not None else (PipelineLink(stage=rank) if world_size > 1 else None)
         self.waiting_requests = asyncio.Queue()
@@ -385,12 +388,15 @@ class PPModelWorker:
         while self._sends and self._sends[0][0].is_completed():
             self._sends.popleft()
 
-    def _send_header(self, kind, task: Optional[BatchTask] = None, n_tokens=0, step_no=0):
+    def _send_header(self, kind, task: Optional[BatchTask] = None, n_tokens=0, step_no=0, piece=(0, 0)):
+        """``piece`` = (first sequence, count) of a partial prompt pass; the lengths that follow are that piece's."""
         h = torch.zeros(HEADER_FIXED + self.max_num_seqs, dtype=torch.int64)
         h[0] = kind
         if task is not None:
             h[1], h[2], h[3], h[4], h[5] = task.serial, task.batch_size, n_tokens, step_no, task.max_tokens
-            h[HEADER_FIXED: HEADER_FIXED + task.batch_size] = torch.tensor(task.prompt_lengths)
+            h[6], h[7] = piece
+            lens = task.prompt_lengths[piece[0]: piece[0] + piece[1]] if piece[1] else task.prompt_lengths
+            h[HEADER_FIXED: HEADER_FIXED + len(lens)] = torch.tensor(lens)
         h = h.to(self._header_device())
         self._post(self.link.send_hidden(h), h)
 
@@ -458,17 +464,19 @@ class PPModelWorker:
             self.print_len[request_id] = plen + len(out)
         return out
 
-    def _emit(self, task: BatchTask, next_ids, step_no):
-        """Head: record the sampled tokens, stream text deltas, report whether the batch is done."""
+    def _emit(self, task: BatchTask, next_ids, step_no, first=0):
+        """Head: record the sampled tokens (``next_ids[j]`` belongs to sequence ``first + j`` of the micro-batch), stream
+        text deltas, report whether every sequence they belong to is done."""
         eos = getattr(self.tokenizer, "eos_token_id", None)
         all_done = True
-        for i, rid in enumerate(task.request_ids):
+        for i, rid in enumerate(task.request_ids[first: first + len(next_ids)]):
             if self.is_finish.get(rid):
                 continue
             t = int(next_ids[i])
             cache = self.token_cache.setdefault(rid, [])
             cache.append(t)
-            finished = (eos is not None and t == eos) or step_no + 1 >= task.max_tokens
+            budget = getattr(task, "request_max", None)
+            finished = (eos is not None and t == eos) or step_no + 1 >= (budget[first + i] if budget else task.max_tokens)
             if self.tokenizer is not None:
                 text = self.tokenizer.decode(cache, skip_special_tokens=True)
                 delta = self.get_printable_text(text, rid) if not finished else text[self.print_len.get(rid, 0):]
