@@ -596,6 +596,13 @@ class NativeDecoder:
                 torch.distributed.all_reduce(t, group=self.tp_group)
         return t
 
+    def _reduce_capturable(self):
+        """Whether the tensor-parallel sums of a decode step can sit inside a captured graph: the IPC kernels and RCCL's
+        collectives can, a host-staged backend (gloo) cannot -- such a group runs its decode steps eagerly."""
+        if self.tp_group is None or self.tp_fast_allreduce is not None:
+            return True
+        return torch.distributed.get_backend(self.tp_group) == "nccl"
+
     def _norm(self, x, w, b=None, residual=None, res_out=None):
         from ..ops import hip
         if self.cfg.norm == "layer":
@@ -1346,7 +1353,7 @@ class NativeDecoder:
         st = self._static.get((batch, q_len))
         if st is None:
             st = self._static[(batch, q_len)] = self._build_static(batch, q_len)
-        if not self.use_graph:
+        if not self.use_graph or not self._reduce_capturable():
             self._graphs[key] = None
             return None, st
         # warm up on a side stream (lazy module loads must happen outside capture), then capture.

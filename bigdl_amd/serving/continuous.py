@@ -68,11 +68,11 @@ class ContinuousBatcher:
         cache = engine.ensure_cache(max_num_seqs, max_seq_len, fp8=kv_fp8)
         cache.enable_slots()
         self.cache = cache
-        # a serving loop runs prompt passes all the time: keep fp16 copies of the weights for their GEMMs when that
-        # fits in a quarter of the HBM left after the KV cache (decode keeps streaming the low-bit tiles)
-        if dense_prefill_cache is None and hasattr(engine, "dense_copy_bytes") and torch.cuda.is_available() \
-                and os.environ.get("BIGDL_PREFILL_DENSE_CACHE") != "0":
-            dense_prefill_cache = engine.dense_copy_bytes() <= torch.cuda.mem_get_info()[0] // 4
+        # prompt passes run on the fused low-bit prompt GEMM like everything else.  Opt-in (argument, or
+        # BIGDL_PREFILL_DENSE_CACHE=1): keep fp16 copies of the weights and hand the prompt GEMMs to the library
+        # (+2 bytes per weight of HBM; decode keeps streaming the low-bit tiles either way)
+        if dense_prefill_cache is None:
+            dense_prefill_cache = os.environ.get("BIGDL_PREFILL_DENSE_CACHE") == "1"
         if dense_prefill_cache:
             from ..models.decoder import Lin
             Lin.cache_dense = True

@@ -165,12 +165,17 @@ class BatchedModelWorker(ModelWorker):
     Takes the place of the reference's vLLM-backed serving for families the native engine covers; other models fall
     back to the one-request-at-a-time loop of ``ModelWorker``."""
 
-    def __init__(self, *args, max_num_seqs: int = 16, max_seq_len: int = 4096, max_prefilled_seqs: int = 1, **kw):
+    def __init__(self, *args, max_num_seqs: int = 16, max_seq_len: int = 4096, max_prefilled_seqs: int = 1, batcher=None,
+                 **kw):
+        """``batcher``: a scheduler built by the caller instead of the one made here from the model's engine -- the
+        source rank of a tensor-parallel group passes its ``serving/tp.py::TensorParallelBatcher``."""
         super().__init__(*args, **kw)
         from ...models.hf_patch import get_native_engine, native_engine_supported
         from ...transformers.utils import engine_kv_mode
-        self.batcher = None
-        if self.device != "cpu" and native_engine_supported(self.model):
+        self.batcher = batcher
+        if batcher is not None:
+            batcher.on_token = self._on_token
+        elif self.device != "cpu" and native_engine_supported(self.model):
             from ..continuous import ContinuousBatcher
             self.batcher = ContinuousBatcher(get_native_engine(self.model), max_num_seqs=max_num_seqs,
                                              max_seq_len=max_seq_len, kv_fp8=engine_kv_mode(),
@@ -235,7 +240,16 @@ class BatchedModelWorker(ModelWorker):
             return await super().process_step()
         loop = asyncio.get_running_loop()
         if not self.batcher.has_work():
-            self._admit(await self.waiting_requests.get(), loop)        # idle: block until a request arrives
+            beat = getattr(self.batcher, "heartbeat_s", None)
+            if beat:
+                # a scheduler with followers (tensor-parallel ranks blocked in a host receive): an empty step every
+                # ``heartbeat_s`` keeps their receive from timing out while no request arrives
+                try:
+                    self._admit(await asyncio.wait_for(self.waiting_requests.get(), timeout=beat), loop)
+                except asyncio.TimeoutError:
+                    pass
+            else:
+                self._admit(await self.waiting_requests.get(), loop)    # idle: block until a request arrives
         while not self.waiting_requests.empty():
             self._admit(self.waiting_requests.get_nowait(), loop)
         await loop.run_in_executor(None, self._iterate)

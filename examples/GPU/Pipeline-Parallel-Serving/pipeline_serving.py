@@ -18,13 +18,32 @@ if __name__ == "__main__":
     ap.add_argument("--port", type=int, default=8000)
     ap.add_argument("--max-num-seqs", type=int, default=8)
     ap.add_argument("--max-prefilled-seqs", type=int, default=0)
+    ap.add_argument("--max-seq-len", type=int, default=4096)
+    ap.add_argument("--engine", action=argparse.BooleanOptionalAction, default=True,
+                    help="run the stages on the native engine (default); --no-engine: HuggingFace modules")
     a = ap.parse_args()
+    ap_engine = a.engine
     init_pipeline_parallel()
     rank, world = dist.get_rank(), dist.get_world_size()
     for r in range(world):                       # load one rank at a time: bounds the host memory used for conversion
         if r == rank:
-            worker = PPModelWorker(a.repo_id_or_model_path, rank, world, a.low_bit, a.max_num_seqs, a.max_prefilled_seqs,
-                                   torch_dtype=torch.float16)
+            if ap_engine:
+                # every stage step on the native engine: one graph replay per micro-batch step, packed prompt passes,
+                # partial prefill in pieces of --max-prefilled-seqs (bigdl_amd/parallel/pipeline.py::EnginePPWorker)
+                from bigdl_amd.models.hf_patch import get_native_engine, native_engine_supported
+                from bigdl_amd.parallel.pipeline import EnginePPWorker, split_engine
+                from ipex_llm.transformers import AutoModelForCausalLM
+                m = AutoModelForCausalLM.from_pretrained(a.repo_id_or_model_path, load_in_low_bit=a.low_bit,
+                                                         torch_dtype=torch.float16)
+                if not native_engine_supported(m):
+                    raise SystemExit("this model family has no native engine: run without --engine")
+                stage = split_engine(get_native_engine(m.half().to(f"cuda:{torch.cuda.current_device()}")), rank, world)
+                worker = EnginePPWorker(stage, rank, world, a.max_num_seqs, a.max_prefilled_seqs,
+                                        tokenizer=AutoTokenizer.from_pretrained(a.repo_id_or_model_path),
+                                        max_seq_len=a.max_seq_len)
+            else:
+                worker = PPModelWorker(a.repo_id_or_model_path, rank, world, a.low_bit, a.max_num_seqs, a.max_prefilled_seqs,
+                                       torch_dtype=torch.float16)
         dist.barrier()
     tok = AutoTokenizer.from_pretrained(a.repo_id_or_model_path, trust_remote_code=True)
     if rank == 0:

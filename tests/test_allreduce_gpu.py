@@ -188,3 +188,73 @@ def test_expert_parallel_engine_two_processes_one_gpu(tmp_path):
     for r in range(WORLD):
         ok, rel = torch.load(tmp_path / f"ep{r}.pt").tolist()
         assert ok == 1, f"rank {r}: rel diff {rel / 1e6}"
+
+
+@pytest.mark.parametrize("fast", ["1", "0"], ids=["ipc_allreduce_in_graph", "host_staged_eager"])
+def test_tensor_parallel_serving(tmp_path, fast):
+    """shard_engine + ContinuousBatcher on two ranks (one GPU), schedule broadcast as fixed-shape tensors: staggered
+    arrivals, admission limits (2 requests / 64 prompt tokens per step), one abort.  Every request gets the tokens the
+    unsharded engine generates for it alone; both ranks run the same steps."""
+    import json
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    port = _free_port()
+    out = str(tmp_path / "res")
+    procs = []
+    for r in range(WORLD):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE=str(WORLD), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), PYTHONPATH=os.path.dirname(here), HSA_ENABLE_IPC_MODE_LEGACY="0", TP_FAST=fast)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(here, "tp_serving_worker.py"), out], env=env))
+    codes = [p.wait(timeout=240) for p in procs]
+    assert codes == [0] * WORLD
+    res = [json.load(open(f"{out}.{r}")) for r in range(WORLD)]
+    head = res[0]
+    assert head["graph"] == (fast == "1")          # IPC all-reduce: captured decode graph; gloo sums: eager steps
+    budgets = [10, 7, 12, 6, 9]
+    agree = total = 0
+    for i, want in enumerate(head["alone"]):
+        got = head["served"][i]
+        assert len(got) == budgets[i] and head["reasons"][i] == "length"
+        assert got[0] == want[0]
+        agree += sum(a == b for a, b in zip(got, want))
+        total += len(want)
+    assert agree / total >= 0.9, (agree, total)
+    assert head["reasons"][5] == "abort" and 0 < len(head["served"][5]) < 30
+    for key in ("steps", "payload_steps", "batcher_steps", "generated", "left"):
+        assert res[0][key] == res[1][key], key
+    assert head["left"] == 0
+    # payloads travelled only on the steps that admitted or aborted something: 3 arrival steps (the second one needs two
+    # steps for its 3 requests at 2 admissions per step) + the abort
+    assert head["payload_steps"] == 5, head["payload_steps"]
+
+
+def test_rccl_all_reduce_inside_the_captured_decode_graph():
+    """The fallback when the IPC all-reduce is not available: the engine's tensor-parallel sums are RCCL all-reduces
+    captured into the decode hipGraph.  One process, a one-rank RCCL communicator (two ranks cannot share a device under
+    RCCL): the collective is really enqueued and captured, and generation equals the engine without a group."""
+    from bigdl_amd import qtypes as Q
+    from bigdl_amd.models.decoder import DecoderConfig, build_random_decoder
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        cfg = DecoderConfig(vocab_size=320, hidden_size=256, intermediate_size=512, num_layers=2, num_heads=4, num_kv_heads=2,
+                            head_dim=64, max_position=512)
+        ids = torch.randint(3, 320, (1, 20), generator=torch.Generator().manual_seed(0)).cuda()
+        plain = build_random_decoder(cfg, Q.SYM_INT4, device="cuda", seed=3)
+        want = plain.generate(ids, max_new_tokens=12)
+        eng = build_random_decoder(cfg, Q.SYM_INT4, device="cuda", seed=3)
+        eng.tp_group, eng.tp_world = dist.group.WORLD, 1
+        calls = []
+        real = dist.all_reduce
+        dist.all_reduce = lambda t, *a, **k: (calls.append(torch.cuda.is_current_stream_capturing()), real(t, *a, **k))[1]
+        try:
+            got = eng.generate(ids, max_new_tokens=12)
+        finally:
+            dist.all_reduce = real
+        assert eng._reduce_capturable() and any(g is not None for g in eng._graphs.values())
+        assert any(calls), "no all-reduce was issued while the decode graph was being captured"
+        assert torch.equal(got, want)
+    finally:
+        dist.destroy_process_group()
