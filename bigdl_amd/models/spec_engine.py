@@ -16,8 +16,11 @@ How it maps to this engine:
 * Verification is one graph replay over ``k + 1`` rows; the accepted prefix length is computed on the device and
   ``[m, target tokens]`` come back in ONE host read per round.
 * The draft length adapts between rounds from what was accepted (host side, no extra read): a fully accepted round
-  grows it, a rejection shrinks it.  ``th_stop_draft`` (stop drafting when the draft is unsure) would need a host
-  read per draft token; verifying a few doubtful tokens is cheaper here than asking.
+  grows it, a rejection shrinks it.  With ``th_stop_draft`` the draft's confidence decides instead: it is computed on
+  the device behind every draft step and read by the host one step late, from pinned memory, so drafting stops
+  without the device ever waiting for the host (reference :1046-1052; ``auto_th_stop_draft`` :1225-1236).
+* Sampling: draft distributions stay on the device, acceptance (min(1, q / p)), the first rejection and the
+  replacement sample from max(q - p, 0) are computed there too (reference :1162-1188).
 """
 from __future__ import annotations
 
@@ -59,10 +62,33 @@ class SelfSpeculativeEngine:
 
     @torch.no_grad()
     def generate(self, input_ids: torch.Tensor, max_new_tokens: int = 32, eos_token_id=None, kv_fp8=False, streamer=None,
-                 time_phases: bool = False, **unused):
-        """Greedy.  ``time_phases`` synchronises between the draft and verify phases of every round to fill
-        ``draft_time`` / ``verify_time`` (costs one extra host wait per round); otherwise only ``generate_time`` per
-        round is recorded."""
+                 time_phases: bool = False, do_sample: bool = False, temperature: float = 1.0, top_k: int = 0,
+                 top_p: float = 1.0, th_stop_draft: Optional[float] = None, auto_th_stop_draft: bool = False,
+                 auto_parameters=(1, 0.5, 0.9, 1e-2, 0.9), stop_lag: int = 1, oracle_accept: Optional[float] = None,
+                 **unused):
+        """Greedy or sampled speculative generation.
+
+        ``th_stop_draft``: stop drafting once the draft's confidence in a token it produced (the probability of the
+        token it picked) falls below the threshold and ``min_step_draft`` tokens exist.  The confidence of every draft
+        step is computed on the device right behind the step's graph and lands in pinned host memory by an
+        asynchronous copy; the host looks at step ``i - stop_lag``'s value before it queues step ``i + 1``.  With the
+        default lag of one step that value is already there (its step finished while the next one was running), so the
+        device never waits for the host and the loop stops at most one token late; ``stop_lag=0`` stops exactly where
+        the reference does and pays one host round trip per draft token.  ``auto_th_stop_draft`` moves the threshold
+        from the acceptance history with the reference's rule (``auto_parameters``).
+
+        ``do_sample``: the draft samples from its filtered distribution, the target accepts token i with probability
+        min(1, q_i / p_i) and replaces the first rejected token by a sample of normalize(max(q - p, 0)) (or, when all
+        were accepted, adds a sample of its own next distribution); everything up to that token is decided on the
+        device and one host read per round returns it.
+
+        ``oracle_accept`` (measurement only): ignore the comparison and accept each draft token with this probability
+        (1.0: every round accepts all k), so that speed can be tabulated against acceptance rate; the text produced
+        is meaningless.
+
+        ``time_phases`` synchronises between the draft and verify phases of every round to fill ``draft_time`` /
+        ``verify_time`` (costs one extra host wait per round); otherwise only ``generate_time`` per round is
+        recorded."""
         t, d, dev = self.target, self.draft, self.device
         input_ids = input_ids.to(dev)
         assert input_ids.shape[0] == 1, "speculative decoding serves one sequence"
@@ -72,12 +98,20 @@ class SelfSpeculativeEngine:
         cache = t.cache
         eos = set([eos_token_id] if isinstance(eos_token_id, int) else (eos_token_id or []))
         self.clear_benchmarks()
+        auto = list(auto_parameters)
+        matchness = 0.0
+        self.th_stop_draft = th = th_stop_draft
+        vocab = t.cfg.vocab_size
+
+        def dist_of(logits):
+            return _filtered_probs(logits.float(), temperature, top_k, top_p)
+
         torch.cuda.synchronize()
         tic = time.perf_counter()
         logits = t.prefill(input_ids)[:, -1, :]
         if d._rope_shift != t._rope_shift:                   # a compressed prompt: both count positions from its real length
             d._set_rope_shift(t._rope_shift)
-        last = logits.argmax(-1).view(1, 1)                  # device
+        last = (torch.multinomial(dist_of(logits), 1) if do_sample else logits.argmax(-1)).view(1, 1)      # device
         generated = [int(last)]
         self.first_token_time = self.first_cost = time.perf_counter() - tic
         if streamer is not None:
@@ -86,20 +120,47 @@ class SelfSpeculativeEngine:
         drafts = torch.zeros(kmax, dtype=torch.int64, device=dev)
         verify_in = torch.zeros(1, kmax + 1, dtype=torch.int64, device=dev)
         result = torch.zeros(kmax + 2, dtype=torch.int64, device=dev)      # [m, target tokens ...]
-        k = min(kmax, max(self.min_step_draft, 4))
+        watch = th is not None
+        if watch:
+            conf_dev = torch.zeros(kmax, dtype=torch.float32, device=dev)
+            conf_host = torch.zeros(kmax, dtype=torch.float32).pin_memory()
+            events = [torch.cuda.Event() for _ in range(kmax)]
+        if do_sample:
+            draft_probs = torch.zeros(kmax + 1, vocab, dtype=torch.float32, device=dev)   # row k stays zero (see below)
+        k = min(kmax, max(self.min_step_draft, 4)) if not watch else kmax
         done = generated[-1] in eos
         e2e = time.perf_counter()
+        rounds = 0
         while not done and len(generated) < max_new_tokens:
             t0 = time.perf_counter()
             base = cache.host_len
             k = max(1, min(k, max_new_tokens - len(generated) - 1)) if max_new_tokens - len(generated) > 1 else 0
-            # ---- draft: k chained replays of the low-bit engine on the shared cache
-            if k:
-                _, chained = d.decode(last, 1, chain=True)
-                drafts[0:1].copy_(chained)
-                for i in range(1, k):
-                    _, chained = d.decode(None, 1, chain=True)
-                    drafts[i:i + 1].copy_(chained)
+            # ---- draft: up to k chained replays of the low-bit engine on the shared cache
+            n = 0
+            while n < k:
+                if watch and n - 1 - stop_lag >= 0:
+                    j = n - 1 - stop_lag                      # newest step whose confidence the host may look at
+                    events[j].synchronize()
+                    if j + 1 >= self.min_step_draft and float(conf_host[j]) < th:
+                        break
+                if do_sample:
+                    lg, _ = d.decode(last if n == 0 else drafts[n - 1:n].view(1, 1), 1, chain=False)
+                    pr = dist_of(lg.view(1, -1))
+                    draft_probs[n].copy_(pr[0])
+                    drafts[n:n + 1].copy_(torch.multinomial(pr, 1).view(-1))
+                    if watch:
+                        conf_dev[n:n + 1].copy_(pr[0].gather(0, drafts[n:n + 1]))
+                else:
+                    lg, chained = d.decode(last if n == 0 else None, 1, chain=True)
+                    drafts[n:n + 1].copy_(chained)
+                    if watch:       # probability of the greedy token: 1 / sum(exp(logit - max))
+                        row = lg.view(-1)
+                        conf_dev[n:n + 1].copy_(torch.exp(row - row.max()).sum().reciprocal().view(1))
+                if watch:
+                    conf_host[n:n + 1].copy_(conf_dev[n:n + 1], non_blocking=True)
+                    events[n].record()
+                n += 1
+            k = n
             if time_phases:
                 torch.cuda.synchronize()
             t1 = time.perf_counter()
@@ -108,12 +169,33 @@ class SelfSpeculativeEngine:
             verify_in[0, 0:1].copy_(last.view(-1))
             if k:
                 verify_in[0, 1:k + 1].copy_(drafts[:k])
-            _, choice = t.decode(verify_in[:, :k + 1], k + 1, chain=False)            # choice: [k + 1]
-            if k:
+            vlogits, choice = t.decode(verify_in[:, :k + 1], k + 1, chain=False)     # choice: greedy tokens [k + 1]
+            if do_sample:
+                q_all = dist_of(vlogits.view(k + 1, -1))                             # target distributions, rows 0..k
+                if k:
+                    tok = drafts[:k]
+                    p = draft_probs[:k].gather(1, tok[:, None]).squeeze(1)
+                    q = q_all[:k].gather(1, tok[:, None]).squeeze(1)
+                    ok = (torch.rand(k, device=dev) <= q / p.clamp_min(1e-30)).to(torch.int64)
+                    m_dev = torch.cumprod(ok, 0).sum()
+                else:
+                    m_dev = torch.zeros((), dtype=torch.int64, device=dev)
+                # the token after the accepted prefix: from max(q_m - p_m, 0) at the first rejection; row k of the
+                # draft table is all zero, so "everything accepted" (m = k) samples the target's own next distribution
+                draft_probs[k].zero_()
+                resid = (q_all.index_select(0, m_dev.view(1)) - draft_probs[:k + 1].index_select(0, m_dev.view(1))).clamp_min(0)
+                resid = torch.where(resid.sum() > 0, resid, q_all.index_select(0, m_dev.view(1)))
+                bonus = torch.multinomial(resid / resid.sum(), 1).view(-1)
+                choice = torch.cat([drafts[:k], bonus])                               # [k + 1]; only [:m] + bonus are used
+                choice = torch.where(torch.arange(k + 1, device=dev) == m_dev, bonus.expand(k + 1), choice)
+            elif k:
                 ok = (choice[:k] == drafts[:k]).to(torch.int64)
                 m_dev = torch.cumprod(ok, 0).sum()
             else:
                 m_dev = torch.zeros((), dtype=torch.int64, device=dev)
+            if oracle_accept is not None and k:
+                ok = (torch.rand(k, device=dev) < oracle_accept).to(torch.int64)
+                m_dev = torch.cumprod(ok, 0).sum()
             result[0] = m_dev
             result[1:k + 2].copy_(choice)
             host = result[:k + 2].tolist()                                           # the round's one host read
@@ -129,15 +211,27 @@ class SelfSpeculativeEngine:
             self.accept_num.append(m + 1)
             self.n_drafted += k
             self.n_matched += m
+            rounds += 1
             if eos:
-                for i, tok in enumerate(accepted):
-                    if tok in eos:
+                for i, tok_h in enumerate(accepted):
+                    if tok_h in eos:
                         accepted, done = accepted[:i + 1], True
                         break
             generated.extend(accepted)
             if streamer is not None:
                 streamer.put(torch.tensor(accepted))
-            if self.adapt and k:
+            if watch:
+                if auto_th_stop_draft and k and rounds % max(1, int(auto[0])) == 0:
+                    # reference speculative.py:1225-1236: unsure drafts raise the threshold, confident ones lower it
+                    matchness = auto[1] * matchness + (1 - auto[1]) * (m / k)
+                    if matchness < auto[2]:
+                        new_th = th + auto[3]
+                    else:
+                        new_th = th if k == kmax else th - auto[3]
+                    th = auto[4] * th + (1 - auto[4]) * new_th
+                    self.th_stop_draft = th
+                k = kmax                                     # the threshold decides the length of the next draft
+            elif self.adapt and k:
                 k = min(kmax, k + 1) if m == k else max(self.min_step_draft, k - 1)
         if streamer is not None:
             streamer.end()
@@ -146,6 +240,22 @@ class SelfSpeculativeEngine:
         self.e2e_time_without_first = time.perf_counter() - e2e
         self.rest_cost_mean = self.e2e_time_without_first / max(1, len(generated) - 1)
         return torch.cat([input_ids, torch.tensor([generated], dtype=input_ids.dtype, device=dev)], 1)
+
+
+def _filtered_probs(logits, temperature, top_k, top_p):
+    """Sampling distribution [rows, V] after temperature / top-k / top-p (the same filters for draft and target, so the
+    acceptance ratio q / p compares like with like)."""
+    if temperature and temperature != 1.0:
+        logits = logits / temperature
+    if top_k and top_k > 0:
+        kth = torch.topk(logits, min(top_k, logits.shape[-1]), dim=-1).values[..., -1:]
+        logits = logits.masked_fill(logits < kth, float("-inf"))
+    if top_p is not None and top_p < 1.0:
+        srt, idx = torch.sort(logits, descending=True, dim=-1)
+        pr = torch.softmax(srt, -1)
+        srt = srt.masked_fill(pr.cumsum(-1) - pr > top_p, float("-inf"))
+        logits = torch.full_like(logits, float("-inf")).scatter(-1, idx, srt)
+    return torch.softmax(logits, -1)
 
 
 def quantized_draft_of(target, qtype, lm_head_qtype: Optional[int] = None):

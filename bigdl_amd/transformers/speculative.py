@@ -51,9 +51,9 @@ def _probs(logits, temperature, top_k, top_p):
 
 def _engine_pair(model, draft_model, do_sample, kwargs):
     """The engine-level loop for (model, draft_model), or None when this call has to take the generic stepper loop
-    (sampling, caller-provided steppers, a model without a native engine, CPU)."""
+    (caller-provided steppers, a model without a native engine, CPU)."""
     import os
-    if do_sample or "stepper" in kwargs or "draft_stepper" in kwargs or os.environ.get("BIGDL_SPEC_STEPPER_LOOP") == "1":
+    if "stepper" in kwargs or "draft_stepper" in kwargs or os.environ.get("BIGDL_SPEC_STEPPER_LOOP") == "1":
         return None
     try:
         dev = next(model.parameters()).device
@@ -94,13 +94,15 @@ def speculative_generate(self, inputs: Optional[torch.Tensor] = None, draft_mode
 
     fast = _engine_pair(self, draft_model, do_sample, sampling_kwargs)
     if fast is not None:
-        # both models run on the native engine: shared KV cache, device-chained draft loop, one host read per round
-        # (bigdl_amd/models/spec_engine.py).  th_stop_draft has no effect there: the draft length adapts from what was
-        # accepted instead of from the draft's confidence.
+        # both models run on the native engine: shared KV cache, device-chained draft loop, one host read per round,
+        # draft confidence read one step late from pinned memory (bigdl_amd/models/spec_engine.py)
         from .utils import engine_kv_mode
         fast.max_step_draft = max_step_draft
+        fast.min_step_draft = max(1, min_step_draft)
         out = fast.generate(input_ids, max_new_tokens=max_new_tokens, eos_token_id=eos, kv_fp8=engine_kv_mode(),
-                            streamer=streamer)
+                            streamer=streamer, do_sample=do_sample, temperature=temperature, top_k=top_k, top_p=top_p,
+                            th_stop_draft=th_stop_draft, auto_th_stop_draft=auto_th_stop_draft,
+                            auto_parameters=auto_parameters)
         for k in ("first_token_time", "generate_time", "draft_time", "verify_time", "draft_num", "accept_num", "n_drafted",
                   "n_matched", "n_token_generated", "e2e_time_without_first", "first_cost", "rest_cost_mean"):
             object.__setattr__(self, k, getattr(fast, k))
