@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--max-step-draft", type=int, default=6)
     ap.add_argument("--modes", default="fp16,int4,spec,lookup")
     ap.add_argument("--trials", type=int, default=3)
+    ap.add_argument("--oracle-rates", default="0.3,0.5,0.7,0.8,0.9,1.0", help="per-token acceptance rates of the oracle mode")
     ap.add_argument("--layers", type=int, default=0, help="override the layer count (quick runs)")
     a = ap.parse_args()
     from bigdl_amd import qtypes as Q
@@ -61,7 +62,7 @@ def main():
         emit("bigdl_fp16_gpu", target.first_cost, target.rest_cost_mean, peak_mem_gb=round(target.peak_memory, 2),
              weight_gb=round(target.weight_bytes() / 2 ** 30, 2), build_s=round(t_build, 1))
     draft = None
-    if "spec" in modes or "int4" in modes:
+    if "spec" in modes or "int4" in modes or "oracle" in modes:
         t0 = time.perf_counter()
         draft = quantized_draft_of(target, Q.ggml_tensor_qtype[a.draft])
         t_quant = time.perf_counter() - t0
@@ -90,6 +91,22 @@ def main():
             emit("speculative_gpu_if_all_accepted", spec.first_cost, full / (k + 1), k=k,
                  ms_per_round=round(full * 1e3, 3),
                  speedup_vs_fp16=None if base_rest is None else round(base_rest / (full / (k + 1)), 3))
+    if "oracle" in modes:
+        # controlled acceptance: every draft token is accepted with probability a, whatever the models say (the text is
+        # meaningless, the time per generated token is what a real pair with that per-token acceptance rate gets)
+        if draft is None:
+            draft = quantized_draft_of(target, Q.ggml_tensor_qtype[a.draft])
+        spec = SelfSpeculativeEngine(target, draft, max_step_draft=a.max_step_draft)
+        for acc in [float(x) for x in a.oracle_rates.split(",")]:
+            best = None
+            for _ in range(a.trials + 1):
+                spec.generate(ids, max_new_tokens=a.out_len, oracle_accept=acc)
+                cur = (spec.rest_cost_mean, spec.n_matched / max(1, spec.n_drafted),
+                       sum(spec.accept_num) / max(1, len(spec.accept_num)))
+                best = cur if best is None or cur[0] < best[0] else best
+            emit("speculative_gpu_controlled_acceptance", spec.first_cost, best[0], draft=a.draft, per_token_acceptance=acc,
+                 measured_accept_rate=round(best[1], 3), tokens_per_round=round(best[2], 2), k_max=a.max_step_draft,
+                 speedup_vs_fp16=None if base_rest is None else round(base_rest / best[0], 3))
     if "lookup" in modes:
         from bigdl_amd.transformers.lookup import lookup_generate
         from bigdl_amd.transformers.stepper import NativeStepper
