@@ -345,6 +345,34 @@ def convert_llama_like(cfg: dict, sd: StateDict):
     return dc, _llama_keys(cfg, sd, dc)
 
 
+def _cfg_decilm(cfg: dict) -> DecoderConfig:
+    per = [int(n) for n in cfg["num_key_value_heads_per_layer"]]
+    common = max(per)
+    if any(common % n for n in per):
+        raise NotImplementedError(f"kv head counts {sorted(set(per))} have no common multiple among them")
+    return _base_config(cfg, "deci", num_kv_heads=common)
+
+
+def convert_decilm(cfg: dict, sd: StateDict):
+    """DeciLM-7B (``model_type: deci``; reference models/decilm.py:48): llama layers whose number of key / value heads
+    differs from layer to layer (``num_key_value_heads_per_layer``).  The engine has one KV layout for all layers, so
+    every layer is brought to the largest count by repeating its k / v projection rows head by head: query head j of a
+    layer with n kv heads reads kv head j // (heads / n), and after each kv head is repeated r = max / n times in place
+    it reads head j // (heads / max) of the repeated set, which is the same original head.  Exact; the price is KV
+    cache memory for the repeated heads."""
+    dc = _cfg_decilm(cfg)
+    d, common = dc.head_dim, dc.num_kv_heads
+    wide = dict(sd)
+    for i, n in enumerate(cfg["num_key_value_heads_per_layer"]):
+        r = common // int(n)
+        if r > 1:
+            for name in ("k_proj", "v_proj"):
+                key = f"model.layers.{i}.self_attn.{name}.weight"
+                w = sd[key]
+                wide[key] = w.view(int(n), d, w.shape[1]).repeat_interleave(r, 0).reshape(common * d, w.shape[1])
+    return dc, _llama_keys(cfg, wide, dc)
+
+
 # ------------------------------------------------------------------------------------------------
 # LayerNorm families (HuggingFace has classes for them; the native engine is opt-in: ``native_engine=True`` or
 # BIGDL_NATIVE_ENGINE=1).  Reference forwards: models/gptneox.py, bloom.py, mpt.py, falcon.py, gpt2.py,
@@ -763,6 +791,7 @@ LN_CONFIGS = {"gpt_neox": _cfg_gpt_neox, "bloom": _cfg_bloom, "mpt": _cfg_mpt, "
 ARCH_CONVERTERS: Dict[str, Callable[[dict, StateDict], Tuple[DecoderConfig, StateDict]]] = {
     "chatglm": convert_chatglm, "baichuan": convert_baichuan, "qwen": convert_qwen, "internlm": convert_internlm,
     "internlm2": convert_internlm2, "minicpm": convert_minicpm, "minicpm3": convert_minicpm3, "deepseek_v2": convert_deepseek_v2, "deepseek_v3": convert_deepseek_v3, "aquila": convert_llama_like, "yi": convert_llama_like,
+    "deci": convert_decilm,
     **LN_CONVERTERS,
 }
 
@@ -1126,6 +1155,8 @@ def arch_config_only(cfg: dict, padded: bool = False) -> DecoderConfig:
         return LN_CONFIGS[mt](cfg)
     if mt == "baichuan":
         return _base_config(cfg, "baichuan", alibi="max_position_embeddings" not in cfg)
+    if mt == "deci":
+        return _cfg_decilm(cfg)
     if mt == "qwen":
         return _base_config(cfg, "qwen", intermediate_size=cfg["intermediate_size"] // 2,
                             head_dim=_get(cfg, "kv_channels", default=cfg["hidden_size"] // cfg["num_attention_heads"]))

@@ -125,6 +125,8 @@ def fold_norm_head(model):
 def optimize_pre(model, qtype=None):
     cfg = getattr(model, "config", None)
     mt = getattr(cfg, "model_type", None)
+    from .remote_code import pre_process_remote_code
+    pre_process_remote_code(model)            # e.g. partial-LoRA linears of InternLM-XComposer2 become plain linears
     fold_norm_head(model)
     if qtype is None or qtype in Q.T16_QTYPES:
         model.apply(pad_mlp_intermediate)
@@ -824,6 +826,8 @@ def optimize_post(model):
     if getattr(cfg, "model_type", None) in ("rwkv", "rwkv5"):
         from .rwkv import bind_rwkv
         bind_rwkv(model)
+    from .remote_code import bind_remote_code_forwards
+    bind_remote_code_forwards(model)          # families that ship as remote code, recognised by their module protocol
     base = getattr(model, "model", None)
     if isinstance(base, nn.Module) and hasattr(base, "layers") and not getattr(base, "_kv_hook_installed", False) \
             and any(hasattr(getattr(l, "self_attn", None), "_merged_sizes") for l in base.layers):

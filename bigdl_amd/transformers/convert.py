@@ -223,6 +223,8 @@ def _replace_with_low_bit_linear(model, qtype, modules_to_not_convert=None, conv
         full_module_name = prefix_name + "." + name if prefix_name else name
         if any(key in full_module_name for key in modules_to_not_convert):
             continue
+        if getattr(module, "_bigdl_keep_dense", False):
+            continue                          # e.g. the rank-r adapter matrices of a partial LoRA (models/remote_code.py)
         if is_linear and _parent_reads_weight_dtype(model, name):
             logger.info("%s stays dense: %s casts activations to its weight's dtype", full_module_name, type(model).__name__)
             continue

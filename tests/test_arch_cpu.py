@@ -227,7 +227,38 @@ def llama_named_forward(cfg, sd, ids):
     return h @ sd["lm_head.weight"].t()
 
 
+# ---------------------------------------------------------------- DeciLM: kv heads differ per layer
+def decilm_ckpt():
+    per = [4, 1][:L] if L == 2 else [4, 2, 1, 2][:L]
+    cfg = dict(model_type="deci", num_hidden_layers=L, hidden_size=H, intermediate_size=192, num_attention_heads=NH,
+               num_key_value_heads_per_layer=per, rms_norm_eps=1e-6, vocab_size=V, max_position_embeddings=256)
+    sd = {"model.embed_tokens.weight": _w(V, H, s=0.5), "model.norm.weight": 1 + _w(H), "lm_head.weight": _w(V, H)}
+    for i in range(L):
+        p = f"model.layers.{i}."
+        sd[p + "input_layernorm.weight"], sd[p + "post_attention_layernorm.weight"] = 1 + _w(H), 1 + _w(H)
+        sd[p + "self_attn.q_proj.weight"], sd[p + "self_attn.o_proj.weight"] = _w(H, H), _w(H, H)
+        sd[p + "self_attn.k_proj.weight"], sd[p + "self_attn.v_proj.weight"] = _w(per[i] * D, H), _w(per[i] * D, H)
+        sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"], sd[p + "mlp.down_proj.weight"] = _w(192, H), _w(192, H), _w(H, 192)
+    return cfg, sd
+
+
+def decilm_forward(cfg, sd, ids):
+    b, s = ids.shape
+    h = sd["model.embed_tokens.weight"][ids]
+    for i, nkv in enumerate(cfg["num_key_value_heads_per_layer"]):
+        p = f"model.layers.{i}."
+        x = _norm(h, sd[p + "input_layernorm.weight"], 1e-6)
+        q = (x @ sd[p + "self_attn.q_proj.weight"].t()).reshape(b, s, NH, D)
+        k = (x @ sd[p + "self_attn.k_proj.weight"].t()).reshape(b, s, nkv, D)
+        v = (x @ sd[p + "self_attn.v_proj.weight"].t()).reshape(b, s, nkv, D)
+        h = h + _attend(_rope_half(q), _rope_half(k), v) @ sd[p + "self_attn.o_proj.weight"].t()
+        x = _norm(h, sd[p + "post_attention_layernorm.weight"], 1e-6)
+        h = h + (F.silu(x @ sd[p + "mlp.gate_proj.weight"].t()) * (x @ sd[p + "mlp.up_proj.weight"].t())) @ sd[p + "mlp.down_proj.weight"].t()
+    return _norm(h, sd["model.norm.weight"], 1e-6) @ sd["lm_head.weight"].t()
+
+
 CASES = {
+    "decilm_variable_gqa": (decilm_ckpt, decilm_forward),
     "chatglm3": (lambda: chatglm_ckpt(True), chatglm_forward),
     "chatglm_no_mqa": (lambda: chatglm_ckpt(False), chatglm_forward),
     "internlm2": (internlm2_ckpt, internlm2_forward),
