@@ -126,7 +126,7 @@ class FusedLoraLowBit(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x2d, weight, out_len, a_w, b_w, scale, p, training):
         from .low_bit_linear import lowbit_matmul
-        y = lowbit_matmul(x2d, weight, out_len)
+        y = lowbit_matmul(x2d, weight, out_len, for_training=True)
         if p > 0.0 and training:
             xd, mask = torch.ops.aten.native_dropout(x2d, p, True)
         else:
