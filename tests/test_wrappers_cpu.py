@@ -73,6 +73,37 @@ def test_fastchat_worker_protocol(tiny):
     assert len(e["embedding"]) == 2 and e["token_num"] == 3
 
 
+def test_fastchat_batched_worker_protocol(tiny):
+    """The batching FastChat worker (the reference's vllm_worker.py role): NUL-terminated JSON chunks, stop strings
+    that abort the request, two requests in flight on one engine loop, the worker endpoints."""
+    import asyncio
+    from fastapi.testclient import TestClient
+    from ipex_llm.serving.fastchat.vllm_worker import VLLMWorker, create_app
+    w = VLLMWorker(model_path=tiny, load_in_low_bit="sym_int4")
+    want = _ref(tiny, "w1 w2", 6)
+
+    async def collect(params):
+        return [json.loads(c[:-1]) async for c in w.generate_stream(params)]
+
+    async def both():
+        a = collect({"prompt": "w1 w2", "max_new_tokens": 6, "temperature": 0.0, "echo": False})
+        b = collect({"prompt": "w1 w2", "max_new_tokens": 6, "temperature": 0.0, "echo": True, "stop": want.split()[3]})
+        res = await asyncio.gather(a, b)
+        w._driver.cancel()
+        return res
+    plain, stopped = asyncio.run(both())
+    assert plain[-1]["text"] == want and plain[-1]["finish_reason"] == "length" and plain[-1]["usage"]["completion_tokens"] == 6
+    assert all(c["finish_reason"] is None for c in plain[:-1])
+    assert stopped[-1]["finish_reason"] == "stop" and stopped[-1]["text"] == "w1 w2" + " ".join(want.split()[:3]) + " "
+    w._driver = None
+    with TestClient(create_app(w)) as client:
+        assert client.post("/count_token", json={"prompt": "w1 w2 w3"}).json()["count"] == 3
+        assert client.post("/model_details").json()["context_length"] == 256
+        assert client.post("/worker_get_status").json()["queue_length"] == 0
+        out = client.post("/worker_generate", json={"prompt": "w1 w2", "max_new_tokens": 6, "temperature": 0.0, "echo": False}).json()
+        assert out["text"] == want
+
+
 def test_vllm_hook_requires_vllm():
     from ipex_llm.vllm.model_convert import _ipex_llm_convert
     with pytest.raises(ImportError):
