@@ -19,6 +19,9 @@ import uuid
 from typing import List, Optional
 
 import torch
+from fastapi import BackgroundTasks, FastAPI
+from fastapi import Request as HttpRequest           # (module level: the endpoint annotations below are resolved here)
+from fastapi.responses import JSONResponse, StreamingResponse
 
 from .ipex_llm_worker import HAVE_FASTCHAT, BaseModelWorker, worker_id  # noqa: F401
 from ..fastapi.model_worker import BatchedModelWorker, Request
@@ -140,8 +143,6 @@ class VLLMWorker(BaseModelWorker):
 
 def create_app(worker: VLLMWorker):
     """FastChat's worker endpoints over ``worker`` (what fastchat/serve/vllm_worker.py registers on its module-level app)."""
-    from fastapi import BackgroundTasks, FastAPI, Request as HttpRequest
-    from fastapi.responses import JSONResponse, StreamingResponse
     app = FastAPI()
     sem = asyncio.Semaphore(worker.limit_worker_concurrency)
 
