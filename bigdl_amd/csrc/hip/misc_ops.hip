@@ -186,6 +186,71 @@ __global__ __launch_bounds__(256) void act_mul_kernel(void* gate, const void* up
   }
 }
 
+// backward of out = silu(gate) * up: dgate = g * up * s * (1 + gate * (1 - s)), dup = g * gate * s with s = sigmoid(gate)
+// (training path: transformers/fused_train_ops.py)
+template <int DT>
+__global__ __launch_bounds__(256) void silu_mul_bwd_kernel(const void* gate, const void* up, const void* grad, void* dgate,
+                                                           void* dup, int64_t rows, int H, int64_t ldg, int64_t ldu,
+                                                           int64_t ldgr) {
+  const int64_t nvec = rows * (H / 8);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / (H / 8);
+    const int c = (int)(i % (H / 8)) * 8;
+    float a[8], u[8], g[8], da[8], du[8];
+    load8<DT>(gate, r * ldg + c, a);
+    load8<DT>(up, r * ldu + c, u);
+    load8<DT>(grad, r * ldgr + c, g);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float sg = 1.0f / (1.0f + __expf(-a[j]));
+      da[j] = g[j] * u[j] * sg * (1.0f + a[j] * (1.0f - sg));
+      du[j] = g[j] * a[j] * sg;
+    }
+    store8<DT>(dgate, r * (int64_t)H + c, da);
+    store8<DT>(dup, r * (int64_t)H + c, du);
+  }
+}
+
+// backward of RMSNorm w.r.t. its input, one row per workgroup: with w' = w + offset, rs = rsqrt(mean(x^2) + eps),
+// dx = rs * (g w') - x * rs^3 * sum(g w' x) / H
+template <int DT, int VPT>
+__global__ __launch_bounds__(256) void rms_norm_bwd_kernel(const void* x, const void* w, const void* grad, void* dx, int H,
+                                                           int64_t ldx, int64_t ldg, float eps, float offset) {
+  __shared__ float sh[8];
+  const int64_t row = blockIdx.x;
+  float xv[VPT][8], gw[VPT][8];
+  float ss = 0.0f, dot = 0.0f;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int c = (threadIdx.x + i * 256) * 8;
+    if (c < H) {
+      float wv[8];
+      load8<DT>(x, row * ldx + c, xv[i]);
+      load8<DT>(grad, row * ldg + c, gw[i]);
+      load8<DT>(w, c, wv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        gw[i][j] *= wv[j] + offset;
+        ss += xv[i][j] * xv[i][j];
+        dot += gw[i][j] * xv[i][j];
+      }
+    }
+  }
+  ss = block_sum(ss, sh);
+  dot = block_sum(dot, sh);
+  const float rs = rsqrtf(ss / (float)H + eps);
+  const float k = rs * rs * rs * dot / (float)H;
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) {
+    const int c = (threadIdx.x + i * 256) * 8;
+    if (c < H) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) gw[i][j] = rs * gw[i][j] - xv[i][j] * k;
+      store8<DT>(dx, row * (int64_t)H + c, gw[i]);
+    }
+  }
+}
+
 // in-place softmax over the last dim, one row per workgroup
 template <int DT>
 __global__ __launch_bounds__(256) void softmax_kernel(void* x, int L, float scale) {
@@ -491,6 +556,29 @@ extern "C" int bigdl_act_mul(void* gate, const void* up, void* out, int64_t rows
   const int64_t nvec = rows * (H / 8);
   const int grid = (int)((nvec + 255) / 256 < 2048 ? (nvec + 255) / 256 : 2048);
   DISPATCH_DT(dtype, hipLaunchKernelGGL((act_mul_kernel<DT>), dim3(grid), dim3(256), 0, st, gate, up, out, rows, H, ldg, ldu, ldo, act))
+  return HIP_CHECK_LAUNCH();
+}
+
+extern "C" int bigdl_silu_mul_bwd(const void* gate, const void* up, const void* grad, void* dgate, void* dup, int64_t rows,
+                                  int H, int64_t ldg, int64_t ldu, int64_t ldgr, int dtype, hipStream_t st) {
+  if (rows <= 0 || H <= 0 || (H & 7) || (ldg & 7) || (ldu & 7) || (ldgr & 7)) return -1;
+  if (!aligned16(gate) || !aligned16(up) || !aligned16(grad) || !aligned16(dgate) || !aligned16(dup)) return -1;
+  const int64_t nvec = rows * (H / 8);
+  const int grid = (int)((nvec + 255) / 256 < 4096 ? (nvec + 255) / 256 : 4096);
+  DISPATCH_DT(dtype, hipLaunchKernelGGL((silu_mul_bwd_kernel<DT>), dim3(grid), dim3(256), 0, st, gate, up, grad, dgate, dup, rows, H, ldg, ldu, ldgr))
+  return HIP_CHECK_LAUNCH();
+}
+
+extern "C" int bigdl_rms_norm_bwd(const void* x, const void* w, const void* grad, void* dx, int64_t rows, int H, int64_t ldx,
+                                  int64_t ldg, float eps, float offset, int dtype, hipStream_t st) {
+  if (rows <= 0 || H <= 0 || (H & 7) || (ldx & 7) || (ldg & 7) || H > 8 * 256 * 8) return -1;
+  if (!aligned16(x) || !aligned16(w) || !aligned16(grad) || !aligned16(dx)) return -1;
+  const int vpt = (H / 8 + 255) / 256;
+  DISPATCH_DT(dtype,
+    if (vpt <= 1) hipLaunchKernelGGL((rms_norm_bwd_kernel<DT, 1>), dim3(rows), dim3(256), 0, st, x, w, grad, dx, H, ldx, ldg, eps, offset);
+    else if (vpt <= 2) hipLaunchKernelGGL((rms_norm_bwd_kernel<DT, 2>), dim3(rows), dim3(256), 0, st, x, w, grad, dx, H, ldx, ldg, eps, offset);
+    else if (vpt <= 4) hipLaunchKernelGGL((rms_norm_bwd_kernel<DT, 4>), dim3(rows), dim3(256), 0, st, x, w, grad, dx, H, ldx, ldg, eps, offset);
+    else hipLaunchKernelGGL((rms_norm_bwd_kernel<DT, 8>), dim3(rows), dim3(256), 0, st, x, w, grad, dx, H, ldx, ldg, eps, offset))
   return HIP_CHECK_LAUNCH();
 }
 

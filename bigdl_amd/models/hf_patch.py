@@ -170,6 +170,11 @@ def rms_norm_forward(self, hidden_states):
             and hidden_states.shape[-1] % 8 == 0 and not torch.is_grad_enabled():
         from ..ops import hip
         return hip.rms_norm(hidden_states.contiguous(), self.weight, eps, offset=offset)
+    if _is_cuda(hidden_states) and hidden_states.shape[-1] % 8 == 0 and hidden_states.shape[-1] <= 16384 \
+            and os.environ.get("BIGDL_FUSED_TRAIN_OPS", "1") != "0":
+        from ..transformers.fused_train_ops import RMSNormFn, usable
+        if usable(hidden_states) and (hidden_states.requires_grad or self.weight.requires_grad):
+            return RMSNormFn.apply(hidden_states.contiguous(), self.weight, float(eps), offset)
     x = hidden_states.float()
     x = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps)
     return (x * (self.weight.float() + offset)).to(hidden_states.dtype)
@@ -217,6 +222,12 @@ def mlp_forward(self, x):
                             bias=None if g.bias is None else g.bias.to(torch.float16),
                             bias2=None if u.bias is None else u.bias.to(torch.float16), act=act)
         return d(h.to(x.dtype).view(*x.shape[:-1], g.out_len))
+    if _is_cuda(x) and act in ("silu", "swish") and torch.is_grad_enabled() and os.environ.get("BIGDL_FUSED_TRAIN_OPS", "1") != "0":
+        from ..transformers.fused_train_ops import SiluMulFn, usable
+        gate, up = g(x), u(x)
+        if usable(gate, up) and gate.dtype == up.dtype and gate.shape[-1] % 8 == 0 and (gate.requires_grad or up.requires_grad):
+            return d(SiluMulFn.apply(gate.contiguous(), up.contiguous()))
+        return d(self.act_fn(gate) * up)
     return d(self.act_fn(g(x)) * u(x))
 
 
@@ -233,6 +244,11 @@ def apply_rotary(q, k, cos, sin):
         hip.rope_inplace(q, cos=cos, sin=sin, rot_dim=rot)
         hip.rope_inplace(k, cos=cos, sin=sin, rot_dim=rot)
         return q, k
+    if _is_cuda(q) and torch.is_grad_enabled() and (q.requires_grad or k.requires_grad) and cos.dim() == 3 \
+            and os.environ.get("BIGDL_FUSED_TRAIN_OPS", "1") != "0":
+        from ..transformers.fused_train_ops import RopeFn, usable
+        if usable(q, k) and cos.dtype == q.dtype:
+            return RopeFn.apply(q, cos, sin), RopeFn.apply(k, cos, sin)
     cos_, sin_ = cos.unsqueeze(1), sin.unsqueeze(1)
     if rot == q.shape[-1]:
         return q * cos_ + _rotate_half(q) * sin_, k * cos_ + _rotate_half(k) * sin_

@@ -52,6 +52,8 @@ def lib():
         L.bigdl_bf16_to_f16.argtypes = [vp, vp, i64, vp]
         L.bigdl_layer_norm.argtypes = [vp, vp, vp, vp, i64, ci, i64, cf, ci, vp]
         L.bigdl_act_mul.argtypes = [vp, vp, vp, i64, ci, i64, i64, i64, ci, ci, vp]
+        L.bigdl_silu_mul_bwd.argtypes = [vp, vp, vp, vp, vp, i64, ci, i64, i64, i64, ci, vp]
+        L.bigdl_rms_norm_bwd.argtypes = [vp, vp, vp, vp, i64, ci, i64, i64, cf, cf, ci, vp]
         L.bigdl_softmax_inplace.argtypes = [vp, i64, ci, cf, ci, vp]
         L.bigdl_rope_inplace.argtypes = [vp, i64, i64, i64, vp, vp, vp, vp, i64, i64, ci, ci, ci, ci, ci, ci, ci, cf, ci, vp]
         L.bigdl_to_e5m2.argtypes = [vp, vp, i64, ci, i64, i64, ci, vp]
@@ -694,6 +696,34 @@ def act_mul(gate, up, act="silu", out=None):
                              ACT[act], _out_type(gate.dtype), _stream())
     _check(rc, "act_mul")
     return gate if out is None else out
+
+
+def silu_mul_bwd(gate, up, grad):
+    """(dgate, dup) of ``silu(gate) * up`` for the upstream gradient ``grad`` (same shape; last dim contiguous)."""
+    _need_cuda(gate, up, grad)
+    h = gate.shape[-1]
+    g2, u2, r2 = (t.reshape(-1, h) if t.stride(-1) == 1 else t.contiguous().reshape(-1, h) for t in (gate, up, grad))
+    dg = torch.empty(gate.shape, dtype=gate.dtype, device=gate.device)
+    du = torch.empty(gate.shape, dtype=gate.dtype, device=gate.device)
+    rc = lib().bigdl_silu_mul_bwd(_ptr(g2), _ptr(u2), _ptr(r2), _ptr(dg), _ptr(du), g2.shape[0], h, g2.stride(0), u2.stride(0),
+                                  r2.stride(0), _out_type(gate.dtype), _stream())
+    _check(rc, "silu_mul_bwd")
+    return dg, du
+
+
+def rms_norm_bwd(x, weight, grad, eps, offset=0.0):
+    """Gradient of ``rms_norm(x, weight, eps, offset)`` with respect to x."""
+    _need_cuda(x, weight, grad)
+    h = x.shape[-1]
+    x2 = x.reshape(-1, h) if x.stride(-1) == 1 else x.contiguous().reshape(-1, h)
+    g2 = grad.reshape(-1, h) if grad.stride(-1) == 1 else grad.contiguous().reshape(-1, h)
+    if weight.dtype != x.dtype:
+        weight = weight.to(x.dtype)
+    dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    rc = lib().bigdl_rms_norm_bwd(_ptr(x2), _ptr(weight.contiguous()), _ptr(g2), _ptr(dx), x2.shape[0], h, x2.stride(0),
+                                  g2.stride(0), eps, offset, _out_type(x.dtype), _stream())
+    _check(rc, "rms_norm_bwd")
+    return dx
 
 
 def softmax_inplace(x, scale=1.0):

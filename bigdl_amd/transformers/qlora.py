@@ -412,6 +412,10 @@ def get_peft_model(model, peft_config: LoraConfig, adapter_name: str = "default"
     peft_model = PeftModelForCausalLM(model, peft_config, adapter_name)
     if peft_model.device.type == "cuda":
         cast_lora_weight(peft_model, torch.bfloat16)
+        if os.environ.get("BIGDL_FUSED_TRAIN_OPS", "1") != "0":
+            # norms, silu(g) * u and the rotary embedding as one kernel forward and one backward each
+            from .fused_train_ops import bind_fused_training_ops
+            bind_fused_training_ops(model)
     return peft_model
 
 
