@@ -32,6 +32,9 @@ TORCH_LINEAR_THRESHOLD = int(os.getenv("BIGDL_LLM_LINEAR_THRESHOLD", "512"))
 # up to 32 rows, inside the batched decode step the GEMM path is 20 % ahead at 32 rows), dequantize + hipBLASLt above
 GEMV_MAX_ROWS = int(os.getenv("BIGDL_GEMV_MAX_ROWS", "16"))
 GEMM_MAX_ROWS = 256
+# forward of frozen low-bit linears inside a training step on the fused prompt GEMM (fp16 copy of the activations)
+# instead of dequantize + dense product
+_TRAIN_FUSED_FORWARD = os.getenv("BIGDL_TRAIN_FUSED_FORWARD", "0") == "1"
 
 
 def get_block_size(qtype) -> int:
@@ -286,13 +289,18 @@ def lowbit_matmul(x_2d: torch.Tensor, weight: FP4Params, out_features: int, for_
             if m <= GEMV_MAX_ROWS:
                 return hip.gemv_lowbit(xh, weight.data, weight.qtype, n, k, out_dtype=x_2d.dtype)
             return hip.gemm_lowbit(xh, weight.data, weight.qtype, n, k, out_dtype=x_2d.dtype)
-        if weight.qlayout == "t16" and not for_training and getattr(weight, "_dense_cache", None) is None:
+        if weight.qlayout == "t16" and (not for_training or _TRAIN_FUSED_FORWARD) and getattr(weight, "_dense_cache", None) is None:
             # prompt-sized rows: the fused kernels take every row count (reference: one native op,
             # low_bit_linear.py:657-668); no fp16 copy of the weight is written and no library GEMM runs.  (Training keeps
             # the dense product below: its backward needs the expanded weight anyway, and its activations are bf16 --
             # measured 0.106 against 0.154 s per QLoRA step on Llama-2-7B.  Inside an autograd node's forward grad mode is
             # off, so the caller says so explicitly.)
-            xh = x_2d if x_2d.dtype == torch.float16 else x_2d.to(torch.float16)
+            if x_2d.dtype == torch.float16:
+                xh = x_2d
+            elif x_2d.dtype == torch.bfloat16:
+                xh = x_2d.clamp(-65504.0, 65504.0).to(torch.float16)      # (bf16 reaches further than fp16)
+            else:
+                xh = x_2d.to(torch.float16)
             if xh.stride(1) != 1 or xh.stride(0) % 8 or xh.data_ptr() % 16:
                 xh = xh.contiguous()
             return lowbit_rows(xh, weight.data, weight.qtype, n, k, out_dtype=x_2d.dtype)
