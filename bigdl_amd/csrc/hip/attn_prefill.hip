@@ -13,6 +13,11 @@
 //    registers, and every per-query quantity of the online softmax (running max, normaliser, rescale factor) is a
 //    per-lane scalar shared by the 4 lanes of a query via two xor-shuffles.
 //  * query blocks are scheduled heaviest first (causal: the last block sees the most keys).
+//  * what bounds it: LDS bandwidth.  Every wavefront reads the whole K and V^T tile for its 16 queries (32 KB per tile,
+//    128 KB per workgroup and tile against 1 KB of MFMA operand per 16 K flops), so a second group of wavefronts per
+//    query block that takes alternate key tiles (twice the wavefronts per SIMD, half the barriers per tile) was measured
+//    SLOWER: 51 against 41 us at 1024 tokens, 588 against 493 us at 4096 (Llama-2-7B heads).  Less LDS traffic per
+//    flop needs the 32x32x16 MFMA (32 queries per wavefront) or two query blocks per fragment read.
 #include "common.h"
 
 namespace bigdl {
