@@ -49,8 +49,14 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(PrefillArgs a) {
   static_assert(!KV8 || VT, "byte caches store V transposed");
   static_assert(DR <= D && DR % 8 == 0, "head_dim must be a multiple of 8 within the tile width");
   constexpr int BM = 64 * QB;
-  constexpr int KS = D + 8;          // halves per K row in LDS (16 B pad)
-  constexpr int VS = PF_BN + 8;      // halves per V^T row
+  // LDS images, read as 16-byte MFMA fragments without bank conflicts:
+  //  K   [64 keys][D]: rows of 2 D bytes, 16-byte chunk c of a key at chunk c ^ swz(key) (D = 96: 192-byte rows, padded
+  //      by 16 bytes instead -- an XOR needs a power-of-two chunk count)
+  //  V^T [D][64 keys]: rows of 128 bytes with the keys of a row reordered so that the 8 keys one lane feeds to an MFMA
+  //      (32 t + 4 g + j and 32 t + 16 + 4 g + j, j < 4) are one chunk, chunk 4 t + g; chunks XOR-swizzled like K's
+  constexpr bool KSWZ = D != 96;
+  constexpr int KS = KSWZ ? D : D + 8;   // halves per K row in LDS
+  constexpr int VS = PF_BN;              // halves per V^T row
   constexpr int DB = D / 16, STEPS = D / 32, CH = D / 8;
   // dynamic LDS: head_dim 256 needs 69 KiB (above the 64 KiB a kernel gets without asking)
   extern __shared__ __attribute__((aligned(16))) _Float16 pf_smem[];
@@ -59,6 +65,14 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(PrefillArgs a) {
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, g = lane >> 4;
+  // swizzle of a row: rows of 128 bytes alternate between the two halves of the 64 banks, so neighbours share a value
+  auto swz128 = [](int row) { return (row >> 1) & 7; };
+  auto kchunk = [&](int key, int c) {      // halves offset of chunk c of a key's row
+    if constexpr (!KSWZ) return key * KS + 8 * c;
+    else if constexpr (D == 64) return key * KS + 8 * (c ^ swz128(key));
+    else return key * KS + 8 * (c ^ (key & 15));
+  };
+  auto vchunk = [&](int d, int c) { return d * VS + 8 * (c ^ swz128(d)); };
   const int hq = blockIdx.y, b = blockIdx.z;
   // causal work grows with the query block index.  Workgroups are dispatched x-fastest; when more than one of them
   // shares a CU, the first half of the heads walks its query blocks heaviest-first and the second half
@@ -167,13 +181,18 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(PrefillArgs a) {
     for (int i = 0; i < NCH; ++i) {
       const int c = threadIdx.x + 256 * i;
       const int key = c / CH, dc = c % CH;
-      *(half8*)(Ks + key * KS + 8 * dc) = kreg[i];
+      *(half8*)(Ks + kchunk(key, dc)) = kreg[i];
       if constexpr (VT) {
+        // keys 8 kc .. 8 kc + 7 of row d: two groups of 4 that belong to neighbouring chunks (same half h of each)
         const int d = c / (PF_BN / 8), kc = c % (PF_BN / 8);
-        *(half8*)(Vt + d * VS + 8 * kc) = vreg[i];
+        const int ca = 4 * (kc >> 2) + 2 * (kc & 1), hh = (kc >> 1) & 1;
+        const half8 v8 = vreg[i];
+        *(half4*)(Vt + vchunk(d, ca) + 4 * hh) = half4{v8[0], v8[1], v8[2], v8[3]};
+        *(half4*)(Vt + vchunk(d, ca + 1) + 4 * hh) = half4{v8[4], v8[5], v8[6], v8[7]};
       } else {
+        const int ck = 4 * (key >> 5) + ((key >> 2) & 3), within = 4 * ((key >> 4) & 1) + (key & 3);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) Vt[(8 * dc + e) * VS + key] = vreg[i][e];
+        for (int e = 0; e < 8; ++e) Vt[vchunk(8 * dc + e, ck) + within] = vreg[i][e];
       }
     }
   };
@@ -198,7 +217,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(PrefillArgs a) {
     for (int st = 0; st < STEPS; ++st)
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb) {
-        const half8 kf = *(const half8*)(Ks + (16 * kb + r) * KS + 32 * st + 8 * g);
+        const half8 kf = *(const half8*)(Ks + kchunk(16 * kb + r, 4 * st + g));
 #pragma unroll
         for (int u = 0; u < QB; ++u) s[u][kb] = mfma16(kf, qf[u][st], s[u][kb]);
       }
@@ -277,9 +296,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(PrefillArgs a) {
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int db = 0; db < DB; ++db) {
-        const _Float16* vr = Vt + (16 * db + r) * VS + 32 * t + 4 * g;
-        const half4 v0 = *(const half4*)vr, v1 = *(const half4*)(vr + 16);
-        const half8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        const half8 vf = *(const half8*)(Vt + vchunk(16 * db + r, 4 * t + g));
 #pragma unroll
         for (int u = 0; u < QB; ++u) o[u][db] = mfma16(vf, pf[u][t], o[u][db]);
       }
@@ -530,7 +547,7 @@ extern "C" int bigdl_prefill_rope_append(void* qkv, void* kc, void* vc, void* vt
 template <int D, bool HAS_MASK, bool VT, int QB, int DR = D, bool KV8 = false>
 static int launch_pf_one(const PrefillArgs& a, hipStream_t st) {
   const dim3 grid((a.Sq + 64 * QB - 1) / (64 * QB), a.Hq, a.B), block(256);
-  constexpr size_t lds = ((size_t)PF_BN * (D + 8) + (size_t)D * (PF_BN + 8)) * 2;
+  constexpr size_t lds = ((size_t)PF_BN * (D != 96 ? D : D + 8) + (size_t)D * PF_BN) * 2;
   static bool attr = false;
   if (!attr && lds > 65536) {
     if (hipFuncSetAttribute((const void*)attn_prefill_kernel<D, HAS_MASK, VT, QB, DR, KV8>, hipFuncAttributeMaxDynamicSharedMemorySize,
