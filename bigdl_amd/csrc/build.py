@@ -26,6 +26,9 @@ HIP_SOURCES = sorted((CSRC / "hip").glob("*.hip"))
 HOST_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-fopenmp", "-march=x86-64-v3", "-Wall", "-Wno-unused-function"]
 HIP_FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall", "-Wno-unused-function",
              "-Wno-unused-variable", "-DNDEBUG"]
+# per-file additions.  attn_prefill: MFMA accumulators in ordinary VGPRs -- the online softmax rescales them with VALU
+# multiplies, and accumulators kept in AGPRs are copied out and back around every such pass (64 moves per key tile).
+HIP_FILE_FLAGS = {"attn_prefill.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _newer(src: Path, dst: Path, extra=()) -> bool:
@@ -43,7 +46,7 @@ def _run(cmd):
     return r
 
 
-def _compile_all(compiler, flags, sources, headers, tag, jobs):
+def _compile_all(compiler, flags, sources, headers, tag, jobs, file_flags=None):
     objs, todo = [], []
     for s in sources:
         o = OBJ / tag / (s.stem + ".o")
@@ -53,7 +56,8 @@ def _compile_all(compiler, flags, sources, headers, tag, jobs):
     if todo:
         (OBJ / tag).mkdir(parents=True, exist_ok=True)
         with ThreadPoolExecutor(max_workers=jobs) as ex:
-            list(ex.map(lambda so: _run([compiler, *flags, "-c", str(so[0]), "-o", str(so[1])]), todo))
+            list(ex.map(lambda so: _run([compiler, *flags, *(file_flags or {}).get(so[0].name, []), "-c", str(so[0]), "-o",
+                                         str(so[1])]), todo))
     return objs, bool(todo)
 
 
@@ -73,7 +77,7 @@ def build_hip(jobs=8, force=False) -> Path | None:
         return None
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     headers = list((CSRC / "hip").glob("*.h")) + list((CSRC / "hip").glob("*.hpp"))
-    objs, changed = _compile_all(hipcc, HIP_FLAGS, HIP_SOURCES, headers, "hip", jobs)
+    objs, changed = _compile_all(hipcc, HIP_FLAGS, HIP_SOURCES, headers, "hip", jobs, HIP_FILE_FLAGS)
     if changed or force or not out.exists():
         LIB.mkdir(exist_ok=True)
         _run([hipcc, "-shared", "--offload-arch=gfx950", "-o", str(out), *map(str, objs)])

@@ -36,6 +36,25 @@ struct PrefillArgs {
 
 constexpr int PF_BN = 64;
 
+// maximum over the 4 lanes that share a query (lanes r, r + 16, r + 32, r + 48): the two row swaps of gfx950 exchange
+// register halves between lanes without a trip through the LDS crossbar
+__device__ __forceinline__ float pf_max4(float x) {
+  uint2v t = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  x = fmaxf(__uint_as_float(t.x), __uint_as_float(t.y));
+  t = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(t.x), __uint_as_float(t.y));
+}
+__device__ __forceinline__ float pf_sum4(float x) {
+  uint2v t = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  x = __uint_as_float(t.x) + __uint_as_float(t.y);
+  t = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(t.x) + __uint_as_float(t.y);
+}
+// 2^x as the bare v_exp_f32 (exp2f adds a range fix-up for denormal results, which a softmax weight does not need)
+__device__ __forceinline__ float pf_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+// how far a tile's maximum may exceed the running one before the accumulators are rescaled: weights stay <= 2^8
+constexpr float PF_LAZY = 8.0f;
+
 // QB = 16-query blocks per wavefront: every K / V^T fragment read from LDS feeds QB MFMAs, which is what keeps the
 // kernel off the LDS-bandwidth limit (QB = 2: 128 queries per workgroup).
 // DR = the model's head_dim when it is not a multiple of 32 (72: SigLIP / MiniCPM-V vision towers, 80: phi-2): the
@@ -59,9 +78,11 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(PrefillArgs a) {
   constexpr int VS = PF_BN;              // halves per V^T row
   constexpr int DB = D / 16, STEPS = D / 32, CH = D / 8;
   // dynamic LDS: head_dim 256 needs 69 KiB (above the 64 KiB a kernel gets without asking)
+  // two tile buffers up to head_dim 128 (one barrier per tile: the next tile is stored while slower wavefronts still
+  // read the current one); head_dim 256 keeps one buffer of 64 KiB and two barriers
+  constexpr int NBUF = D <= 128 ? 2 : 1;
+  constexpr int TILE = PF_BN * KS + D * VS;  // halves per buffer: K [PF_BN][KS], then V^T [D][VS]
   extern __shared__ __attribute__((aligned(16))) _Float16 pf_smem[];
-  _Float16* Ks = pf_smem;                    // [PF_BN][KS]
-  _Float16* Vt = pf_smem + PF_BN * KS;       // [D][VS]
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, g = lane >> 4;
@@ -73,12 +94,24 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(PrefillArgs a) {
     else return key * KS + 8 * (c ^ (key & 15));
   };
   auto vchunk = [&](int d, int c) { return d * VS + 8 * (c ^ swz128(d)); };
-  const int hq = blockIdx.y, b = blockIdx.z;
-  // causal work grows with the query block index.  Workgroups are dispatched x-fastest; when more than one of them
-  // shares a CU, the first half of the heads walks its query blocks heaviest-first and the second half
-  // lightest-first, so that the workgroups landing on one CU add up to the same number of key tiles.
-  const bool flip = (int)(blockIdx.y + gridDim.y * blockIdx.z) * 2 >= (int)(gridDim.y * gridDim.z);
-  const int qb = flip ? (int)blockIdx.x : (int)gridDim.x - 1 - (int)blockIdx.x;
+  // Workgroups are dispatched x-fastest and dealt to the 8 XCDs in turn, each with an L2 of its own.  When the number
+  // of (batch, head) pairs divides by 8, XCD x takes a contiguous eighth of them (with grouped KV heads: whole groups),
+  // one head after the other, so the K / V of about one head at a time is what that L2 has to hold; otherwise the grid
+  // is used as it comes.  Within a head the causal work grows with the query block index: blocks are walked
+  // heaviest-first, and lightest-first in every other run of 32 workgroups (an XCD's CUs take one workgroup each
+  // before any takes a second) or every other head, so that workgroups sharing a CU add up to similar key counts.
+  const int nqb = gridDim.x, nbh = gridDim.y * gridDim.z;
+  const int lin = blockIdx.x + nqb * (blockIdx.y + gridDim.y * blockIdx.z);
+  int bh = lin / nqb, qslot = lin % nqb;
+  bool flip = 2 * bh >= nbh;
+  if ((nbh & 7) == 0) {
+    const int idx = lin >> 3;
+    bh = (lin & 7) * (nbh >> 3) + idx / nqb;
+    qslot = idx % nqb;
+    flip = (idx / max(32, nqb)) & 1;
+  }
+  const int hq = bh % (int)gridDim.y, b = bh / (int)gridDim.y;
+  const int qb = flip ? qslot : nqb - 1 - qslot;
   const int hkv = hq / (a.Hq / a.Hkv);
   const int q0 = qb * BM;
   const int offset = a.Lk - a.Sq;                    // causal alignment: query i sits at key position i + offset
@@ -122,7 +155,21 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(PrefillArgs a) {
   // global -> registers for one K/V tile (issued one tile ahead of its use)
   constexpr int NCH = PF_BN * CH / 256;
   half8 kreg[NCH], vreg[NCH];
+  const _Float16* kfast = kbase + (int64_t)(threadIdx.x / CH) * a.k_ss + 8 * (threadIdx.x % CH);
+  const _Float16* vfast = vbase + (int64_t)(threadIdx.x / (PF_BN / 8)) * a.v_ss + 8 * (threadIdx.x % (PF_BN / 8));
   auto load_tile = [&](int k0) {
+    if constexpr (DR == D && !KV8 && VT && 256 % CH == 0) {
+      if (k0 + PF_BN <= a.Lk) {          // whole tile inside the sequence (uniform): no per-lane bounds
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+          // chunk c = tid + 256 i: key / row advance by a whole number per i, so each address is one per-thread
+          // pointer plus a wavefront-uniform offset
+          kreg[i] = *(const half8*)(kfast + (int64_t)(k0 + (256 / CH) * i) * a.k_ss);
+          vreg[i] = *(const half8*)(vfast + (int64_t)(256 / (PF_BN / 8)) * i * a.v_ss + k0);
+        }
+        return;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int c = threadIdx.x + 256 * i;
@@ -176,7 +223,9 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(PrefillArgs a) {
       }
     }
   };
-  auto store_tile = [&]() {
+  auto store_tile = [&](int buf) {
+    _Float16* Ks = pf_smem + buf * TILE;
+    _Float16* Vt = Ks + PF_BN * KS;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int c = threadIdx.x + 256 * i;
@@ -197,110 +246,136 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(PrefillArgs a) {
     }
   };
 
-  if (kbeg < kend) load_tile(kbeg);
+  if (kbeg < kend) {
+    load_tile(kbeg);
+    store_tile(0);
+    if (kbeg + PF_BN < kend) load_tile(kbeg + PF_BN);
+  }
+  __syncthreads();
+  const float sc2 = a.scale * LOG2E;
+  const bool plain = !HAS_MASK && a.alibi == nullptr && a.softcap <= 0.0f && a.scale > 0.0f;
+  int cur = 0;
   for (int k0 = kbeg; k0 < kend; k0 += PF_BN) {
-    __syncthreads();                 // the previous tile has been consumed
-    store_tile();
-    __syncthreads();
-    if (k0 + PF_BN < kend) load_tile(k0 + PF_BN);
+    const _Float16* Ks = pf_smem + cur * TILE;
+    const _Float16* Vt = Ks + PF_BN * KS;
     // wavefronts whose queries all precede this tile have nothing to add (uniform per wavefront)
     const int wq_last = q0 + (wave * QB + QB) * 16 - 1 + offset;
-    if (a.causal && k0 > wq_last) continue;
-
-    // ---- S^T = K . Q^T : lane -> query r of block u, keys 16*kb + 4g + reg ----
-    float4v s[QB][4];
+    if (!(a.causal && k0 > wq_last)) {
+      // ---- S^T = K . Q^T : lane -> query r of block u, keys 16*kb + 4g + reg ----
+      float4v s[QB][4];
 #pragma unroll
-    for (int u = 0; u < QB; ++u)
+      for (int u = 0; u < QB; ++u)
 #pragma unroll
-      for (int kb = 0; kb < 4; ++kb) s[u][kb] = float4v{0, 0, 0, 0};
+        for (int kb = 0; kb < 4; ++kb) s[u][kb] = float4v{0, 0, 0, 0};
 #pragma unroll
-    for (int st = 0; st < STEPS; ++st)
+      for (int st = 0; st < STEPS; ++st)
 #pragma unroll
-      for (int kb = 0; kb < 4; ++kb) {
-        const half8 kf = *(const half8*)(Ks + kchunk(16 * kb + r, 4 * st + g));
+        for (int kb = 0; kb < 4; ++kb) {
+          const half8 kf = *(const half8*)(Ks + kchunk(16 * kb + r, 4 * st + g));
 #pragma unroll
-        for (int u = 0; u < QB; ++u) s[u][kb] = mfma16(kf, qf[u][st], s[u][kb]);
-      }
-
-    // ---- scale, soft-cap, mask, online softmax (all per-lane scalars per query block) ----
-    half8 pf[QB][2];
-#pragma unroll
-    for (int u = 0; u < QB; ++u) {
-      float mloc = -INFINITY;
-      const int wq0 = q0 + (wave * QB + u) * 16 + offset;
-      // interior tile: every key of the tile is visible to every query of this block (uniform branch)
-      const bool interior = !HAS_MASK && a.alibi == nullptr && a.softcap <= 0.0f && k0 + PF_BN <= a.Lk && (!a.causal || k0 + PF_BN - 1 <= wq0) &&
-                            (a.window <= 0 || k0 > wq0 + 15 - a.window);
-      if (interior) {
-        const float sc = a.scale * LOG2E;
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float v = s[u][kb][e] * sc;
-            s[u][kb][e] = v;
-            mloc = fmaxf(mloc, v);
-          }
-      } else {
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int key = k0 + 16 * kb + 4 * g + e;
-            float v = s[u][kb][e] * a.scale;
-            if (a.softcap > 0.0f) v = a.softcap * tanhf(v / a.softcap);
-            if constexpr (HAS_MASK) {
-              if (qi[u] < a.Sq && key < a.Lk) v += (float)a.mask[b * a.m_sb + hq * a.m_sh + (int64_t)qi[u] * a.m_sq + key];
-            }
-            v += slope * (float)(key - pos[u]);   // ALiBi: slope * (key - query position)
-            bool ok = key < a.Lk;
-            if (a.causal) ok = ok && key <= pos[u];
-            if (a.window > 0) ok = ok && key > pos[u] - a.window;
-            v = ok ? v * LOG2E : -INFINITY;
-            s[u][kb][e] = v;
-            mloc = fmaxf(mloc, v);
-          }
-      }
-      mloc = fmaxf(mloc, __shfl_xor(mloc, 16));
-      mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-      const float mnew = fmaxf(m[u], mloc);
-      const float msafe = mnew == -INFINITY ? 0.0f : mnew;
-      const float alpha = exp2f(m[u] - msafe);              // m = -inf -> 0
-      float lsum = 0.0f;
-#pragma unroll
-      for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float p = exp2f(s[u][kb][e] - msafe);
-          s[u][kb][e] = p;
-          lsum += p;
+          for (int u = 0; u < QB; ++u) s[u][kb] = mfma16(kf, qf[u][st], s[u][kb]);
         }
-      lsum += __shfl_xor(lsum, 16);
-      lsum += __shfl_xor(lsum, 32);
-      l[u] = l[u] * alpha + lsum;
-      m[u] = mnew;
+
+      // ---- scale, soft-cap, mask, online softmax (all per-lane scalars per query block) ----
+      half8 pf[QB][2];
 #pragma unroll
-      for (int i = 0; i < DB; ++i) o[u][i] *= alpha;
-      // P^T as B operand: k slot (g, j) = key 32t + 4g + j (j < 4) / 32t + 16 + 4g + j - 4
+      for (int u = 0; u < QB; ++u) {
+        float mloc = -INFINITY;
+        float mul;                     // weight = 2^(s * mul - running maximum)
+        const int wq0 = q0 + (wave * QB + u) * 16 + offset;
+        // interior tile: every key of the tile is visible to every query of this block (uniform branch)
+        const bool interior = plain && k0 + PF_BN <= a.Lk && (!a.causal || k0 + PF_BN - 1 <= wq0) &&
+                              (a.window <= 0 || k0 > wq0 + 15 - a.window);
+        if (interior) {
+          // the scale is folded into the exponent's multiply-add; the maximum is taken over the raw products
+#pragma unroll
+          for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mloc = fmaxf(mloc, s[u][kb][e]);
+          mloc *= sc2;
+          mul = sc2;
+        } else {
+#pragma unroll
+          for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int key = k0 + 16 * kb + 4 * g + e;
+              float v = s[u][kb][e] * a.scale;
+              if (a.softcap > 0.0f) v = a.softcap * tanhf(v / a.softcap);
+              if constexpr (HAS_MASK) {
+                if (qi[u] < a.Sq && key < a.Lk) v += (float)a.mask[b * a.m_sb + hq * a.m_sh + (int64_t)qi[u] * a.m_sq + key];
+              }
+              v += slope * (float)(key - pos[u]);   // ALiBi: slope * (key - query position)
+              bool ok = key < a.Lk;
+              if (a.causal) ok = ok && key <= pos[u];
+              if (a.window > 0) ok = ok && key > pos[u] - a.window;
+              v = ok ? v * LOG2E : -INFINITY;
+              s[u][kb][e] = v;
+              mloc = fmaxf(mloc, v);
+            }
+          mul = 1.0f;
+        }
+        mloc = pf_max4(mloc);
+        // The running maximum only follows a tile that exceeds it by more than 2^PF_LAZY: weights up to 2^8 are exact
+        // in fp16 / fp32 all the same, the result (o / l) does not depend on the reference point, and most tiles skip
+        // the pass over the accumulators.  The test is per wavefront so that the skip is a uniform branch.
+        const float mnew = fmaxf(m[u], mloc);
+        if (__builtin_amdgcn_ballot_w64(mnew > m[u] + PF_LAZY) != 0) {      // (-inf + 8 = -inf: any finite maximum)
+          const float alpha = pf_exp2(m[u] - (mnew == -INFINITY ? 0.0f : mnew));   // m = -inf -> 0
+          l[u] *= alpha;
+#pragma unroll
+          for (int i = 0; i < DB; ++i) o[u][i] *= alpha;
+          m[u] = mnew;
+        }
+        const float mref = m[u] == -INFINITY ? 0.0f : m[u];
+        float lsum = 0.0f;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float p = pf_exp2(__builtin_fmaf(s[u][kb][e], mul, -mref));
+            s[u][kb][e] = p;
+            lsum += p;
+          }
+        l[u] += lsum;                  // this lane's keys only: the 4 lanes of a query are added up after the loop
+        // P^T as B operand: k slot (g, j) = key 32t + 4g + j (j < 4) / 32t + 16 + 4g + j - 4
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            pf[u][t][e] = (_Float16)s[u][2 * t][e];
+            pf[u][t][4 + e] = (_Float16)s[u][2 * t + 1][e];
+          }
+      }
+
+      // ---- O^T += V^T . P^T ----
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          pf[u][t][e] = (_Float16)s[u][2 * t][e];
-          pf[u][t][4 + e] = (_Float16)s[u][2 * t + 1][e];
+        for (int d0 = 0; d0 < DB; d0 += 8) {         // fragments are fetched 8 at a time, then multiplied
+          constexpr int NV = DB < 8 ? DB : 8;
+          half8 vf[NV];
+#pragma unroll
+          for (int i = 0; i < NV; ++i)
+            if (d0 + i < DB) vf[i] = *(const half8*)(Vt + vchunk(16 * (d0 + i) + r, 4 * t + g));
+#pragma unroll
+          for (int i = 0; i < NV; ++i)
+            if (d0 + i < DB) {
+#pragma unroll
+              for (int u = 0; u < QB; ++u) o[u][d0 + i] = mfma16(vf[i], pf[u][t], o[u][d0 + i]);
+            }
         }
     }
-
-    // ---- O^T += V^T . P^T ----
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int db = 0; db < DB; ++db) {
-        const half8 vf = *(const half8*)(Vt + vchunk(16 * db + r, 4 * t + g));
-#pragma unroll
-        for (int u = 0; u < QB; ++u) o[u][db] = mfma16(vf, pf[u][t], o[u][db]);
-      }
+    if (k0 + PF_BN < kend) {
+      if constexpr (NBUF == 1) __syncthreads();      // every wavefront is done with the only buffer
+      store_tile(cur ^ (NBUF - 1));
+      if (k0 + 2 * PF_BN < kend) load_tile(k0 + 2 * PF_BN);
+    }
+    __syncthreads();
+    cur ^= NBUF - 1;
   }
+#pragma unroll
+  for (int u = 0; u < QB; ++u) l[u] = pf_sum4(l[u]);
 
 #pragma unroll
   for (int u = 0; u < QB; ++u)
@@ -547,7 +622,7 @@ extern "C" int bigdl_prefill_rope_append(void* qkv, void* kc, void* vc, void* vt
 template <int D, bool HAS_MASK, bool VT, int QB, int DR = D, bool KV8 = false>
 static int launch_pf_one(const PrefillArgs& a, hipStream_t st) {
   const dim3 grid((a.Sq + 64 * QB - 1) / (64 * QB), a.Hq, a.B), block(256);
-  constexpr size_t lds = ((size_t)PF_BN * (D != 96 ? D : D + 8) + (size_t)D * PF_BN) * 2;
+  constexpr size_t lds = ((size_t)PF_BN * (D != 96 ? D : D + 8) + (size_t)D * PF_BN) * 2 * (D <= 128 ? 2 : 1);
   static bool attr = false;
   if (!attr && lds > 65536) {
     if (hipFuncSetAttribute((const void*)attn_prefill_kernel<D, HAS_MASK, VT, QB, DR, KV8>, hipFuncAttributeMaxDynamicSharedMemorySize,
