@@ -11,13 +11,20 @@
 //  * scores are computed transposed, S^T = K . Q^T: the MFMA result then holds, per lane, one query (column) and
 //    16 keys, which is exactly the B-operand layout of the second product O^T += V^T . P^T.  P never leaves
 //    registers, and every per-query quantity of the online softmax (running max, normaliser, rescale factor) is a
-//    per-lane scalar shared by the 4 lanes of a query via two xor-shuffles.
-//  * query blocks are scheduled heaviest first (causal: the last block sees the most keys).
-//  * what bounds it: LDS bandwidth.  Every wavefront reads the whole K and V^T tile for its 16 queries (32 KB per tile,
-//    128 KB per workgroup and tile against 1 KB of MFMA operand per 16 K flops), so a second group of wavefronts per
-//    query block that takes alternate key tiles (twice the wavefronts per SIMD, half the barriers per tile) was measured
-//    SLOWER: 51 against 41 us at 1024 tokens, 588 against 493 us at 4096 (Llama-2-7B heads).  Less LDS traffic per
-//    flop needs the 32x32x16 MFMA (32 queries per wavefront) or two query blocks per fragment read.
+//    per-lane scalar shared by the 4 lanes of a query via two row swaps (v_permlane16_swap / v_permlane32_swap).
+//  * the softmax is kept off the VALU as far as it goes: bare v_exp_f32, the scale folded into the exponent's
+//    multiply-add, accumulators rescaled only when a tile's maximum exceeds the running one by more than 2^8, the
+//    normaliser summed per lane and reduced once at the end, MFMA accumulators in VGPRs (per-file build flag) so that
+//    the rare rescale needs no AGPR copies: 400 -> 140 VALU instructions per wavefront and key tile.
+//  * tiles are double-buffered in LDS (one barrier per tile); whole tiles load without per-lane bounds.
+//  * heads are placed per XCD (one L2 each); query blocks are scheduled heaviest first (causal: the last block sees the
+//    most keys), alternating direction so that workgroups sharing a CU add up to similar work.
+//  * measured on MI355X, Llama-2-7B heads, causal: 27 us at 1024 tokens, 276 us at 4096 (500 TFLOP/s; PyTorch SDPA:
+//    60 / 420 us).  Counters at 4096: the SIMDs issue 55 % of the time (MFMA 20 %, VALU about 33 %), the rest is
+//    waiting on LDS reads, dependent results and the per-tile barrier with two wavefronts per SIMD.  Variants measured
+//    and not adopted: two query blocks per wavefront (halves the LDS reads per MFMA; 256 VGPRs: 36 / 308 us), a second
+//    group of wavefronts taking alternate key tiles (51 / 588 us on the earlier kernel), tiles requested two phases
+//    ahead through a second register set (29 / 295 us), the normaliser as an extra MFMA row block (no change).
 #include "common.h"
 
 namespace bigdl {
