@@ -18,7 +18,13 @@ using namespace bigdl;
 #ifndef PROBE_NT
 #define PROBE_NT 2          // 16-column weight tiles per wavefront: column block = 64 * PROBE_NT
 #endif
-#define PROBE_BN (64 * PROBE_NT)
+#ifndef PROBE_NW
+#define PROBE_NW 4          // wavefronts per workgroup that multiply
+#endif
+#define PROBE_BN (16 * PROBE_NW * PROBE_NT)
+#ifndef PROBE_LW
+#define PROBE_LW 0          // 1: x tiles brought in by a loader wavefront (gemm_kernel.h, LW)
+#endif
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
@@ -110,7 +116,7 @@ int main(int argc, char** argv) {
       const int mblocks = (M + 63) / 64;
       int rc;
       (void)use_kg;
-      rc = gemm_launch_mt<Q_SYM_INT4, 4, PROBE_NT>(a, mblocks, st);
+      rc = gemm_launch_mt<Q_SYM_INT4, 4, PROBE_NT, false, PROBE_NW, (PROBE_LW != 0)>(a, mblocks, st);
       if (rc != 0) { printf("launch failed %d\n", rc); exit(1); }
       if (a.splitk > 1) hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)(((int64_t)M * sh.n + 255) / 256)), dim3(256), 0, st, a);
       return a;
@@ -148,6 +154,26 @@ int main(int argc, char** argv) {
         printf("\"%d\": [%.2f, %.2f, %.2f, %.2f], ", i, v.front(), v[v.size() / 2], v[v.size() * 9 / 10], v.back());
       }
       printf("\"waves\": %d}}\n", nwv);
+    }
+#endif
+#if GEMM_ABL & 32
+    {   // where the workgroups of one launch ran: distinct (XCC, SE, CU) and the largest number sharing a CU
+      GemmArgs aw = launch(3, kg);
+      CK(hipStreamSynchronize(st));
+      const int nwg = ((sh.n + PROBE_BN - 1) / PROBE_BN) * aw.splitk * ((M + 63) / 64);
+      std::vector<uint32_t> hw(2 * (size_t)nwg);
+      CK(hipMemcpy(hw.data(), ws, hw.size() * 4, hipMemcpyDeviceToHost));
+      std::vector<int> cnt(1 << 16, 0);
+      int distinct = 0, worst = 0;
+      for (int i = 0; i < nwg; ++i) {
+        const uint32_t h = hw[2 * i], x = hw[2 * i + 1] & 0xf;
+        const int cu = (h >> 8) & 0xf, sh_ = (h >> 12) & 0x1, se = (h >> 13) & 0x7;
+        const int key = (int)(x << 8 | se << 5 | sh_ << 4 | cu);
+        if (cnt[key]++ == 0) ++distinct;
+        worst = std::max(worst, cnt[key]);
+      }
+      printf("{\"tag\": \"%s\", \"shape\": \"%s\", \"workgroups\": %d, \"distinct_cus\": %d, \"max_per_cu\": %d, \"hw_id0\": \"%08x\", \"xcc0\": \"%08x\"}\n",
+             tag, sh.name, nwg, distinct, worst, hw[0], hw[1]);
     }
 #endif
     // timing

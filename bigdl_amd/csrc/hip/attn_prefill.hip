@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(PrefillArgs a) {
     const int idx = lin >> 3;
     bh = (lin & 7) * (nbh >> 3) + idx / nqb;
     qslot = idx % nqb;
-    flip = (idx / max(32, nqb)) & 1;
+    flip = ((idx - qslot) / max(32, nqb)) & 1;     // by the head's first workgroup: one direction per head
   }
   const int hq = bh % (int)gridDim.y, b = bh / (int)gridDim.y;
   const int qb = flip ? qslot : nqb - 1 - qslot;

@@ -23,7 +23,8 @@
 // GEMM_STAMP = 1: every wavefront writes 100 MHz wall-clock stamps to g_gemm_stamps ([workgroup][wavefront][32]:
 // 0 entry, 1 first x tile staged, 2 + i after k iteration i, 31 exit).
 // GEMM_ABL (results are wrong): 1 = no MFMA, 2 = no dequantization, 4 = no LDS fragment reads, 8 = no x loads in the
-// k loop, 16 = no weight loads in the k loop.
+// k loop, 16 = no weight loads in the k loop, 32 = no epilogue (one store per wavefront),
+// 64 = no weight loads before the loop, 128 = no x requests before the loop (loader form).
 #ifndef GEMM_STAMP
 #define GEMM_STAMP 0
 #endif
@@ -49,6 +50,10 @@ __device__ unsigned long long* g_gemm_stamps = nullptr;      // [2048 workgroups
 #endif
 
 namespace bigdl {
+
+// s_waitcnt immediate that waits for all but the n youngest vector-memory operations only (gfx9 encoding: vmcnt in bits
+// [3:0] and [15:14], expcnt [6:4] and lgkmcnt [11:8] left at their maxima)
+constexpr int gemm_waitcnt_vm(int n) { return (n & 0xF) | ((n >> 4) << 14) | (0x7 << 4) | (0xF << 8); }
 
 struct GemmArgs {
   const _Float16* x;      // [*, ldx]
@@ -85,13 +90,30 @@ struct GemmArgs {
 // MT = 16-row tiles of x per workgroup, NT = 16-column weight tiles per wavefront (4 wavefronts side by side)
 // NORM: x is multiplied by gamma while it is staged (compile-time, so that the gamma load is unconditional: a load
 // under a run-time condition costs the counted waits of the whole loop)
-template <int QT, int MT, int NT, bool NORM = false>
-__global__ __launch_bounds__(256, 2) void gemm_t16_kernel(GemmArgs a) {
+// NW = wavefronts per workgroup, side by side along N.  8 wavefronts of one weight tile each (NT = 1) cover the same 128
+// columns as 4 of two, in under 128 VGPRs: four wavefronts per SIMD instead of two hide the load -> dequantize -> MFMA ->
+// barrier chain of a k-tile behind each other, which is what the few-row shapes of batched decode lack.
+// LW: one more wavefront per workgroup does nothing but bring the x tiles in (global -> LDS directly, three stages), so
+// that the compute wavefronts request and wait for weight tiles only (a wavefront's vector loads retire in order: one
+// that requests both operands takes delivery of an x tile only after the older weight requests).  Measured on the
+// Llama-2-7B shapes at 64 rows: 117 -> 109 us for the four products of a layer.  Needs K % 128 == 0, no folded norm.
+// Where the time of these launches goes at 64 rows (qkv, 288 workgroups of 11 k-tiles, 22 us): 4.5 us for the kernel
+// with an empty loop and no loads, 4 - 8 us until the first four weight tiles of every wavefront have arrived (the
+// 128-byte scale requests cost more than the 1 KiB code requests next to them), 2.5 us for the eleven k-tiles, 6.5 us
+// for the fp32 partials (9.4 MB) -- then 4.8 us of reduce kernel.  Eight wavefronts of one tile each, deeper weight
+// look-ahead, more K splits, rotated k order and tile-major slabs were all measured within 5 % or slower.
+template <int QT, int MT, int NT, bool NORM = false, int NW = 4, bool LW = false>
+__global__ __launch_bounds__((NW + (LW ? 1 : 0)) * 64, 2) void gemm_t16_kernel(GemmArgs a) {
+  static_assert(!(LW && NORM), "the loader wavefront copies x as it is");
+  constexpr int NSTAGE = LW ? 3 : 2;
   constexpr int BM = MT * 16;
-  constexpr int BN = 4 * NT * 16;  // 4 wavefronts side by side along N
+  constexpr int BN = NW * NT * 16;
+  constexpr int RP = NW * 4;       // x rows staged per pass (16 threads per 256-byte row)
+  constexpr int NP = BM / RP;      // passes per x tile
+  static_assert(BM % RP == 0 && RP % 16 == 0, "whole passes; the swizzle of a row is that of its pass-0 row");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* As = smem;                                               // [2][BM][256 B]
-  _Float16* nf4_lut = (_Float16*)(smem + 2 * BM * 256);           // [64][16] (nf4 only)
+  char* As = smem;                                               // [NSTAGE][BM][256 B]
+  _Float16* nf4_lut = (_Float16*)(smem + NSTAGE * BM * 256);      // [64][16] (nf4 only)
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -119,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void gemm_t16_kernel(GemmArgs a) {
 
   const _Float16* lut = nullptr;
   if constexpr (QT == Q_NF4) {
-    fill_nf4_banked((uint32_t*)nf4_lut, threadIdx.x, 256);
+    fill_nf4_banked((uint32_t*)nf4_lut, threadIdx.x, (NW + (LW ? 1 : 0)) * 64);
     lut = (const _Float16*)((const uint32_t*)nf4_lut + (lane & 31));
   }
 
@@ -133,6 +155,55 @@ __global__ __launch_bounds__(256, 2) void gemm_t16_kernel(GemmArgs a) {
     tbase[n] = (wt + min(nt_idx[n], ntiles - 1)) * KT;
   }
 
+  const int klast = max(kt1 - 1, kt0);
+  auto kmap = [&](int k) { return min(k, klast); };     // tiles past the end: the last one again (never used)
+  if constexpr (LW) {
+    if (wave == NW) {
+      // ---- loader wavefront.  One instruction moves 4 rows of a tile (64 lanes x 16 bytes); lane i brings what belongs
+      // in slot i % 16 of row i / 16, i.e. k chunk (i % 16) ^ (row % 16) (the swizzle of the fragment reads, applied to
+      // the source address because the LDS side of the instruction is lane-linear).  Rows past the block re-read its last
+      // row (their products are never stored).  Tile i + 2 is requested into stage (i + 2) % 3 -- last read in iteration
+      // i - 1, which every wavefront has left -- then the wait leaves exactly those requests open: tile i + 1 is in LDS
+      // before the barrier that ends iteration i.
+      constexpr int NLD = BM / 4;
+      uint32_t xo[NLD];
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) {
+        const int row = min(4 * i + (lane >> 4), max(rows - 1, 0));
+        const int64_t xr = a.x_rows != nullptr ? a.x_rows[row0 + row] : row0 + row;
+        xo[i] = (uint32_t)(xr * a.ldx) + (uint32_t)((((lane & 15) ^ (4 * i + (lane >> 4))) & 15) << 3);
+      }
+      auto request = [&](int kt, int stage) {
+        const _Float16* src = a.x + (int64_t)kt * 128;
+        char* dst = As + stage * BM * 256;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i)
+          __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)(src + xo[i]),
+                                           (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+      };
+      // (bare s_barrier: __syncthreads() carries a fence that makes the compiler wait for EVERY outstanding LDS-bound
+      // load, the tile just requested included)
+      auto tile_ready_barrier = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(gemm_waitcnt_vm(NLD));
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      if constexpr (!(GEMM_ABL & 128)) {
+        request(kmap(kt0), 0);
+        request(kmap(kt0 + 1), 1);
+      }
+      tile_ready_barrier();
+      int st = 2;
+      for (int k = kt0; k < kt1; ++k) {
+        if constexpr (!(GEMM_ABL & 8)) request(kmap(k + 2), st);
+        st = st == 2 ? 0 : st + 1;
+        tile_ready_barrier();
+      }
+      return;
+    }
+  }
+
   // x staging: thread t moves 16 bytes of row (16 p + t / 16), slot t % 16, for p = 0 .. MT-1
   const int srow = threadIdx.x >> 4, sslot = threadIdx.x & 15;
   // element offsets into x (32 bits: the host checks rows * ldx < 2^31).  Rows past the block read the block's last
@@ -140,26 +211,26 @@ __global__ __launch_bounds__(256, 2) void gemm_t16_kernel(GemmArgs a) {
   // condition leaves the compiler without a static count of younger loads in flight, and it then waits for ALL of
   // them (s_waitcnt vmcnt(0)) before the LDS store of the x tile, including the weight tiles just requested four
   // k-tiles ahead, which put a full memory round trip into every k-tile.
-  uint32_t xsrc[MT];
-  bool xok[MT];
+  uint32_t xsrc[NP];
+  bool xok[NP];
 #pragma unroll
-  for (int p = 0; p < MT; ++p) {
-    const int row = min(16 * p + srow, max(rows - 1, 0));
-    xok[p] = 16 * p + srow < rows;
+  for (int p = 0; p < NP; ++p) {
+    const int row = min(RP * p + srow, max(rows - 1, 0));
+    xok[p] = RP * p + srow < rows;
     const int64_t xr = a.x_rows != nullptr ? a.x_rows[row0 + row] : row0 + row;
     xsrc[p] = (uint32_t)(xr * a.ldx);
   }
-  const int swz = ((sslot ^ srow) & 15) << 4;   // (16 p + srow) & 15 == srow
+  const int swz = ((sslot ^ srow) & 15) << 4;   // (RP p + srow) & 15 == srow & 15
   // x tiles travel global -> registers -> LDS two k-tiles ahead of their use: tile t sits in register set t & 1
   // from iteration t - 2 and is written to LDS stage t & 1 at the end of iteration t - 1
-  uint4v areg[2][MT];
+  uint4v areg[2][NP];
   uint4v greg[2];                              // NORM: gamma of the k slot of the tile in the same register set
-  auto gload_a = [&](uint4v (&dst)[MT], uint4v& gdst, int kt) {
+  auto gload_a = [&](uint4v (&dst)[NP], uint4v& gdst, int kt) {
     const int k = kt * 128 + sslot * 8;
     const int kc = min(k, a.K - 8);           // K % 32 == 0: the clamped address is a whole valid 16-byte slot
     const bool kin = k < a.K;
 #pragma unroll
-    for (int p = 0; p < MT; ++p) {
+    for (int p = 0; p < NP; ++p) {
       // zeroing by mask, not by a select the compiler could turn back into a branch around the load
       const uint32_t keep = 0u - (uint32_t)(kin & xok[p]);
       const uint4v v = *(const uint4v*)(a.x + xsrc[p] + kc);
@@ -169,15 +240,15 @@ __global__ __launch_bounds__(256, 2) void gemm_t16_kernel(GemmArgs a) {
     // would make this the point where the x loads are waited for)
     if constexpr (NORM) gdst = *(const uint4v*)(a.gamma + kc);
   };
-  auto store_a = [&](uint4v (&src)[MT], const uint4v& gsrc, int stage) {
+  auto store_a = [&](uint4v (&src)[NP], const uint4v& gsrc, int stage) {
     char* base = As + stage * BM * 256 + srow * 256 + swz;
     if constexpr (NORM) {
       const half8 g8 = __builtin_bit_cast(half8, gsrc) + (_Float16)a.gamma_offset;
 #pragma unroll
-      for (int p = 0; p < MT; ++p) *(half8*)(base + p * 16 * 256) = __builtin_bit_cast(half8, src[p]) * g8;
+      for (int p = 0; p < NP; ++p) *(half8*)(base + p * RP * 256) = __builtin_bit_cast(half8, src[p]) * g8;
     } else {
 #pragma unroll
-      for (int p = 0; p < MT; ++p) *(uint4v*)(base + p * 16 * 256) = src[p];
+      for (int p = 0; p < NP; ++p) *(uint4v*)(base + p * RP * 256) = src[p];
     }
   };
 
@@ -234,12 +305,32 @@ __global__ __launch_bounds__(256, 2) void gemm_t16_kernel(GemmArgs a) {
 
   // prologue.  Tile indices past the end are clamped to the last tile of the range (a redundant load of data that
   // is already on its way) so that the number of loads per iteration is fixed.
-  const int klast = max(kt1 - 1, kt0);
-  gload_a(areg[0], greg[0], kt0);
+  if constexpr (LW) {
+    // ---- compute wavefronts next to a loader: weights only; x tile k sits in stage (k - kt0) % 3
 #pragma unroll
-  for (int d = 0; d < DEPTH; ++d) fetch_b(tt[d], min(kt0 + d, klast));
+    for (int d = 0; d < DEPTH; ++d)
+      if constexpr (!(GEMM_ABL & 64)) fetch_b(tt[d], kmap(kt0 + d));
+    __syncthreads();
+    GEMM_STAMP_AT(1);
+    int st = 0;
+    for (int kt = kt0; kt < kt1; kt += DEPTH) {
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) {
+        const int k = kt + d;                 // block-uniform
+        if (k >= kt1) break;
+        compute(tt[d], st);
+        st = st == 2 ? 0 : st + 1;
+        if constexpr (!(GEMM_ABL & 16)) fetch_b(tt[d], kmap(k + DEPTH));
+        __syncthreads();
+        GEMM_STAMP_AT(2 + k - kt0);
+      }
+    }
+  } else {
+  gload_a(areg[0], greg[0], kmap(kt0));
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) fetch_b(tt[d], kmap(kt0 + d));
   store_a(areg[0], greg[0], 0);
-  gload_a(areg[1], greg[1], min(kt0 + 1, klast));
+  gload_a(areg[1], greg[1], kmap(kt0 + 1));
   __syncthreads();
   GEMM_STAMP_AT(1);
   for (int kt = kt0; kt < kt1; kt += DEPTH) {
@@ -247,16 +338,30 @@ __global__ __launch_bounds__(256, 2) void gemm_t16_kernel(GemmArgs a) {
     for (int d = 0; d < DEPTH; ++d) {
       const int k = kt + d;                 // block-uniform
       if (k >= kt1) break;
-      if constexpr (!(GEMM_ABL & 8)) gload_a(areg[d & 1], greg[d & 1], min(k + 2, klast));           // (k - kt0) & 1 == d & 1: DEPTH is even
+      if constexpr (!(GEMM_ABL & 8)) gload_a(areg[d & 1], greg[d & 1], kmap(k + 2));           // (k - kt0) & 1 == d & 1: DEPTH is even
       compute(tt[d], d & 1);
-      if constexpr (!(GEMM_ABL & 16)) fetch_b(tt[d], min(k + DEPTH, klast));
+      if constexpr (!(GEMM_ABL & 16)) fetch_b(tt[d], kmap(k + DEPTH));
       if constexpr (!(GEMM_ABL & 8)) store_a(areg[(d + 1) & 1], greg[(d + 1) & 1], (d + 1) & 1);
       __syncthreads();
       GEMM_STAMP_AT(2 + k - kt0);
     }
   }
+  }
 
   // epilogue
+  if constexpr (GEMM_ABL & 32) {               // measurement: one store per wavefront instead of the tile
+    float v = 0.0f;
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) v += acc[j][n][0] + acc[j][n][1] + acc[j][n][2] + acc[j][n][3];
+    // (where the workgroup ran: HW_ID and XCC_ID, for the probe's placement count)
+    if (lane == 0 && wave == 0) {
+      ((uint32_t*)a.partial)[(int64_t)blockIdx.x * 2] = __builtin_amdgcn_s_getreg((31 << 11) | 4) | (v == 12345.0f ? 1u << 31 : 0u);
+      ((uint32_t*)a.partial)[(int64_t)blockIdx.x * 2 + 1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    }
+    return;
+  }
   const int64_t mtot = a.M;
 #pragma unroll
   for (int n = 0; n < NT; ++n) {
@@ -297,20 +402,20 @@ __global__ __launch_bounds__(256, 2) void gemm_t16_kernel(GemmArgs a) {
   GEMM_STAMP_AT(31);
 }
 
-template <int QT, int MT, int NT, bool NORM = false>
+template <int QT, int MT, int NT, bool NORM = false, int NW = 4, bool LW = false>
 static int gemm_launch_mt(const GemmArgs& a, int mblocks, hipStream_t st) {
   constexpr int BM = MT * 16;
-  const size_t lds = 2 * BM * 256 + (QT == Q_NF4 ? 64 * 16 * 2 : 0);
+  const size_t lds = (LW ? 3 : 2) * BM * 256 + (QT == Q_NF4 ? 64 * 16 * 2 : 0);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm_t16_kernel<QT, MT, NT, NORM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)gemm_t16_kernel<QT, MT, NT, NORM, NW, LW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return -101;
     attr_set = true;
   }
-  const int bn = 64 * NT;
+  const int bn = NW * 16 * NT;
   const int nblocks = (a.N + bn - 1) / bn;
   const dim3 grid(nblocks * a.splitk, mblocks, a.w2 != nullptr ? 2 : 1);
-  hipLaunchKernelGGL((gemm_t16_kernel<QT, MT, NT, NORM>), grid, dim3(256), lds, st, a);
+  hipLaunchKernelGGL((gemm_t16_kernel<QT, MT, NT, NORM, NW, LW>), grid, dim3((NW + (LW ? 1 : 0)) * 64), lds, st, a);
   return HIP_CHECK_LAUNCH();
 }
 
@@ -325,6 +430,12 @@ static int gemm_launch_qt(const GemmArgs& a, int bm, int bn, int mblocks, hipStr
     if (bm == 64) return gemm_launch_mt<QT, 4, 2, true>(a, mblocks, st);
     if (bm == 128) return gemm_launch_mt<QT, 8, 2, true>(a, mblocks, st);
     return -4;
+  }
+  static const int lw = getenv("BIGDL_GEMM_LOADER") ? atoi(getenv("BIGDL_GEMM_LOADER")) : 1;
+  if (lw && (a.K & 127) == 0) {
+    if (bm == 16) return gemm_launch_mt<QT, 1, 2, false, 4, true>(a, mblocks, st);
+    if (bm == 32) return gemm_launch_mt<QT, 2, 2, false, 4, true>(a, mblocks, st);
+    if (bm == 64) return gemm_launch_mt<QT, 4, 2, false, 4, true>(a, mblocks, st);
   }
   if (bm == 16) return gemm_launch_mt<QT, 1, 2>(a, mblocks, st);
   if (bm == 32) return gemm_launch_mt<QT, 2, 2>(a, mblocks, st);

@@ -592,6 +592,13 @@ class NativeDecoder:
         if self.tp_group is not None:
             if self.tp_fast_allreduce is not None and self.tp_fast_allreduce.usable(t):
                 self.tp_fast_allreduce(t)          # one kernel launch over IPC-mapped peer buffers (graph-capturable)
+            elif t.is_cuda and torch.distributed.get_backend(self.tp_group) == "gloo":
+                # host-staged sum, staged here: gloo's own device-tensor path (private stream + worker thread) was seen
+                # to stall now and then with two ranks on one GPU; a blocking copy, a host all-reduce and a copy back
+                # have nothing to race with
+                h = t.cpu()
+                torch.distributed.all_reduce(h, group=self.tp_group)
+                t.copy_(h)
             else:
                 torch.distributed.all_reduce(t, group=self.tp_group)
         return t

@@ -10,6 +10,26 @@ import torch.distributed as dist
 
 
 def main():
+    # a rank that stops making progress says where (all thread stacks) and exits instead of holding the test
+    import faulthandler
+    import threading
+    deadline = int(os.environ.get("TP_WORKER_DEADLINE_S", "100"))
+    state = {}
+
+    def report():
+        tp = state.get("tp")
+        if tp is not None:
+            b = tp.batcher
+            sys.stderr.write(f"[rank {os.environ['RANK']}] stuck: tp.steps={tp.steps} batcher.steps={b.steps} running="
+                             f"{sorted((s, len(r.output_ids)) for s, r in b.running.items())} waiting={len(b.waiting)} "
+                             f"prefilling={b._prefilling is not None} header={tp._header.tolist()}\n")
+        faulthandler.dump_traceback(all_threads=True)
+        sys.stderr.flush()
+        os._exit(3)
+
+    timer = threading.Timer(deadline, report)
+    timer.daemon = True
+    timer.start()
     out_path = sys.argv[1]
     world = int(os.environ["WORLD_SIZE"])
     rank = int(os.environ["RANK"])
@@ -35,6 +55,7 @@ def main():
     fast = os.environ.get("TP_FAST", "1") == "1"
     eng = shard_engine(build_random_decoder(cfg, Q.SYM_INT4, device="cuda:0", seed=7), rank, world, fast_allreduce=fast)
     tp = TensorParallelBatcher(eng, max_num_seqs=4, max_seq_len=256, max_admit_per_step=2, max_batched_tokens=64)
+    state["tp"] = tp
     res["graph"] = bool(eng.use_graph and eng._reduce_capturable())
     if rank == 0:
         reqs = [SeqRequest(f"r{i}", p, max_new_tokens=b) for i, (p, b) in enumerate(zip(prompts, budgets))]
