@@ -7,7 +7,8 @@ is rebound (``model_convert._ipex_llm_convert``) so that every worker -- in this
 worker that imports the patched module -- converts its shard on the host and then moves it to its GPU.
 
 vLLM is imported lazily: the classes are created on first attribute access, so importing this module never needs vLLM
-(on ROCm: the ROCm build of vLLM)."""
+(on ROCm: the ROCm build of vLLM).  Without vLLM (or with ``IPEX_LLM_NOT_USE_VLLM=1``) ``IPEXLLMClass`` is
+``offline.LLM``: the same ``LLM(...).generate(prompts, SamplingParams)`` interface on this package's continuous batcher."""
 from __future__ import annotations
 
 from .model_convert import _ipex_llm_convert
@@ -78,7 +79,17 @@ def run_mp_engine(engine_args, usage_context, ipc_path, load_in_low_bit: str, en
     return _run(*args)
 
 
+def _have_vllm() -> bool:
+    import importlib.util
+    import os
+    return os.environ.get("IPEX_LLM_NOT_USE_VLLM", "") not in ("1", "true", "True") and importlib.util.find_spec("vllm") is not None
+
+
 def __getattr__(name):
+    if name == "IPEXLLMClass" and not _have_vllm():
+        # without vLLM the offline entry point runs on this package's own batching engine (same call interface)
+        from .offline import LLM
+        return LLM
     if name.startswith("IPEXLLM"):
         if not _CACHE:
             _CACHE.update(_build())

@@ -1,8 +1,12 @@
-"""vLLM (ROCm build) with low-bit weights (reference: python/llm/example/GPU/vLLM-Serving/offline_inference.py).
+"""Batched offline generation with low-bit weights: vLLM (ROCm build) when it is installed, otherwise this package's own
+batching engine behind the same interface (reference: python/llm/example/GPU/vLLM-Serving/offline_inference.py).
 Server: python -m ipex_llm.vllm.xpu.entrypoints.openai.api_server --model <path> --load-in-low-bit fp8 --tensor-parallel-size 8"""
 import argparse
 
-from vllm import SamplingParams
+try:
+    from vllm import SamplingParams
+except ImportError:                      # no vLLM: the same interface on this package's continuous batcher
+    from ipex_llm.vllm import SamplingParams
 
 from ipex_llm.vllm.xpu.engine import IPEXLLMClass as LLM
 
