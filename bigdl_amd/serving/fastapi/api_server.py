@@ -343,10 +343,18 @@ class FastApp:
 
 
 def serve(repo_id_or_model_path: str, low_bit: str = "sym_int4", port: int = 8000, host: str = "0.0.0.0",
-          served_model_name: Optional[str] = None, model_type: str = "normal"):
-    """Load a model and serve it (reference example: python/llm/example/GPU/Lightweight-Serving/lightweight_serving.py)."""
+          served_model_name: Optional[str] = None, model_type: str = "normal", max_num_seqs: int = 0,
+          max_seq_len: int = 4096, max_prefilled_seqs: int = 8):
+    """Load a model and serve it (reference example: python/llm/example/GPU/Lightweight-Serving/lightweight_serving.py).
+    ``max_num_seqs`` > 0: iteration-level batching over that many cache slots of the native engine
+    (``BatchedModelWorker``) instead of one request at a time."""
     import uvicorn
-    worker = ModelWorker(repo_id_or_model_path, low_bit, model_type)
+    if max_num_seqs > 0:
+        from .model_worker import BatchedModelWorker
+        worker = BatchedModelWorker(repo_id_or_model_path, low_bit, model_type, max_num_seqs=max_num_seqs,
+                                    max_seq_len=max_seq_len, max_prefilled_seqs=max_prefilled_seqs)
+    else:
+        worker = ModelWorker(repo_id_or_model_path, low_bit, model_type)
     fast = FastApp(worker=worker, served_model_name=served_model_name or repo_id_or_model_path)
     uvicorn.run(fast.app, host=host, port=port)
 
@@ -360,8 +368,12 @@ def main():
     ap.add_argument("--host", default="0.0.0.0")
     ap.add_argument("--served-model-name", default=None)
     ap.add_argument("--model-type", default="normal")
+    ap.add_argument("--max-num-seqs", type=int, default=0, help="> 0: continuous batching over this many cache slots")
+    ap.add_argument("--max-seq-len", type=int, default=4096)
+    ap.add_argument("--max-prefilled-seqs", type=int, default=8)
     a = ap.parse_args()
-    serve(a.repo_id_or_model_path, a.low_bit, a.port, a.host, a.served_model_name, a.model_type)
+    serve(a.repo_id_or_model_path, a.low_bit, a.port, a.host, a.served_model_name, a.model_type, a.max_num_seqs,
+          a.max_seq_len, a.max_prefilled_seqs)
 
 
 if __name__ == "__main__":

@@ -80,3 +80,20 @@ def test_langchain_wrapper_batches_all_prompts_into_one_generation():
     assert llm.invoke("abc") == texts[0]
     stop = texts[0][2:4]
     assert llm.invoke("abc", stop=[stop]) == texts[0][:texts[0].find(stop)]
+
+
+@pytest.mark.skipif(importlib.util.find_spec("vllm") is not None, reason="with vLLM installed vLLM's own server runs")
+def test_openai_server_entry_point_starts_the_builtin_batched_server(monkeypatch):
+    """vLLM's command line on the built-in server: the options it understands keep their meaning, the rest is reported."""
+    import bigdl_amd.serving.fastapi.api_server as builtin
+    from ipex_llm.vllm.cpu.entrypoints.openai.api_server import main as cpu_main
+    from ipex_llm.vllm.xpu.entrypoints.openai.api_server import main
+    seen = []
+    monkeypatch.setattr(builtin, "serve", lambda *a, **kw: seen.append((a, kw)))
+    main(["--model", "/m", "--served-model-name", "x", "--port", "8123", "--load-in-low-bit", "fp8", "--max-num-seqs", "12",
+          "--max-model-len", "2048", "--gpu-memory-utilization", "0.9", "--enforce-eager"])
+    cpu_main(["--model", "/m"])
+    assert seen[0] == (("/m", "fp8", 8123, "0.0.0.0", "x"), {"max_num_seqs": 12, "max_seq_len": 2048})
+    assert seen[1] == (("/m", "sym_int4", 8000, "0.0.0.0", None), {"max_num_seqs": 64, "max_seq_len": 4096})
+    with pytest.raises(SystemExit):
+        main(["--model", "/m", "--tensor-parallel-size", "2"])
