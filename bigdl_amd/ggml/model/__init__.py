@@ -232,6 +232,96 @@ class NativeModel:
 
     create_completion = __call__
 
+    # -- the rest of the llama-cpp-python surface the reference exposes (ggml/model/llama/llama.py:305-1420) -----------
+    def n_embd(self) -> int:
+        return int(self.model.config.hidden_size)
+
+    def token_nl(self) -> int:
+        ids = self.tokenizer("\n", add_special_tokens=False)["input_ids"]
+        return ids[-1] if ids else -1
+
+    def sample(self, tokens: List[int], top_k: int = 40, top_p: float = 0.95, temp: float = 0.8,
+               repeat_penalty: float = 1.1, **kwargs) -> int:
+        """The next token after ``tokens``: one forward pass, then the same processors ``generate`` applies."""
+        logits = self.eval(tokens)[-1]
+        if repeat_penalty and repeat_penalty != 1.0:
+            seen = torch.tensor(sorted(set(tokens)), dtype=torch.long)
+            v = logits[seen]
+            logits[seen] = torch.where(v > 0, v / repeat_penalty, v * repeat_penalty)
+        if temp is None or temp <= 0:
+            return int(logits.argmax())
+        logits = logits / temp
+        if top_k and top_k > 0:
+            kth = torch.topk(logits, min(top_k, logits.numel())).values[-1]
+            logits = logits.masked_fill(logits < kth, float("-inf"))
+        probs = torch.softmax(logits, -1)
+        if top_p is not None and top_p < 1.0:
+            sp, si = torch.sort(probs, descending=True)
+            keep = (torch.cumsum(sp, 0) - sp) < top_p
+            probs = torch.zeros_like(probs).scatter(0, si[keep], sp[keep])
+            probs = probs / probs.sum()
+        return int(torch.multinomial(probs, 1))
+
+    def reset(self):
+        """Forget the evaluated prefix (the engine keeps no state between calls: every call starts from its prompt)."""
+        self._state_tokens = []
+
+    def set_cache(self, cache):
+        """Accepted for llama-cpp-python scripts.  The engine's KV cache lives on the GPU and a prompt pass of a few
+        thousand tokens costs milliseconds, so completions are not looked up in a host-side prefix cache."""
+        self._prefix_cache = cache
+
+    def save_state(self) -> dict:
+        return {"tokens": list(getattr(self, "_state_tokens", [])), "n_ctx": self.n_ctx_}
+
+    def load_state(self, state: dict):
+        self._state_tokens = list(state.get("tokens", []))
+
+    @staticmethod
+    def logits_to_logprobs(logits: List[float]) -> List[float]:
+        return torch.log_softmax(torch.as_tensor(logits, dtype=torch.float32), -1).tolist()
+
+    @staticmethod
+    def longest_token_prefix(a, b) -> int:
+        n = 0
+        for x, y in zip(a, b):
+            if x != y:
+                break
+            n += 1
+        return n
+
+
+class LlamaCache:
+    """Host-side store keyed by token prefixes with llama-cpp-python's mapping interface (reference
+    ggml/model/llama/llama.py:63-107): ``cache[tokens] = state`` / ``cache[tokens]`` returns the state stored under the
+    longest prefix of ``tokens``.  Kept so that scripts which build one and pass it to ``set_cache`` run."""
+
+    def __init__(self, capacity_bytes: int = 2 << 30):
+        self.capacity_bytes = capacity_bytes
+        self._store = {}
+
+    def _longest(self, key):
+        best, best_n = None, 0
+        for k in self._store:
+            n = NativeModel.longest_token_prefix(k, key)
+            if n == len(k) and n > best_n:
+                best, best_n = k, n
+        return best
+
+    def __contains__(self, key) -> bool:
+        return self._longest(tuple(key)) is not None
+
+    def __getitem__(self, key):
+        k = self._longest(tuple(key))
+        if k is None:
+            raise KeyError("no stored prefix of these tokens")
+        return self._store[k]
+
+    def __setitem__(self, key, value):
+        self._store[tuple(key)] = value
+        while len(self._store) > 64:
+            self._store.pop(next(iter(self._store)))
+
 
 def _family(name: str, architectures, chat_format=None, chat_suffix=None):
     """A family class in the reference's naming: refuses files of another architecture instead of mis-loading them."""

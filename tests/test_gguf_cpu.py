@@ -238,9 +238,22 @@ def test_llm_convert_and_native_wrappers(tmp_path):
     assert [d["index"] for d in emb["data"]] == [0, 1] and len(emb["data"][1]["embedding"]) == 256
     toks = llm.tokenize("w1 w2")
     assert llm.eval(toks).shape == (len(toks), 320)
-    from bigdl_amd.ggml.model import Bloom
+    from bigdl_amd.ggml.model import Bloom, LlamaCache
     with pytest.raises(ValueError, match="bloom"):
         Bloom(out)
+    # the remaining llama-cpp-python accessors
+    assert llm.n_embd() == 256 and llm.n_vocab() == 320 and llm.n_ctx() == 512
+    assert llm.sample(toks, temp=0.0, repeat_penalty=1.0) == int(llm.eval(toks)[-1].argmax())
+    assert 0 <= llm.sample(toks, top_k=5, top_p=0.9, temp=0.7) < 320
+    lp = llm.logits_to_logprobs([0.0, 0.0])
+    assert abs(lp[0] + 0.6931) < 1e-3 and llm.longest_token_prefix([1, 2, 3], [1, 2, 4]) == 2
+    cache = LlamaCache()
+    cache[[1, 2]] = "a"
+    cache[[1, 2, 3]] = "b"
+    assert cache[[1, 2, 3, 4]] == "b" and [1, 2, 9] in cache and [2] not in cache
+    llm.set_cache(cache)
+    llm.load_state(llm.save_state())
+    llm.reset()
     # a completion cut short by a stop string leaves no generation running behind it: the worker is cancelled and
     # joined, so the next completion has the model (KV cache, decode graph) to itself and reproduces the first one
     import threading
