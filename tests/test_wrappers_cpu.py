@@ -108,3 +108,58 @@ def test_vllm_hook_requires_vllm():
     from ipex_llm.vllm.model_convert import _ipex_llm_convert
     with pytest.raises(ImportError):
         _ipex_llm_convert("sym_int4")
+
+
+def test_fastchat_model_adapters_and_patched_loaders(tiny, tmp_path, monkeypatch):
+    """The adapters FastChat is given (reference serving/fastchat/bigdl_llm_model.py): path patterns, loading through
+    this package, the low-bit directory adapter, and what ``patch_fastchat`` rebinds (against a stand-in of
+    ``fastchat.model.model_adapter``: FastChat is not installed here, parity with it unpinned beyond this protocol)."""
+    import shutil
+    import sys
+    import types
+    from ipex_llm.serving.fastchat import bigdl_llm_model as M
+    from bigdl_amd.transformers import AutoModelForCausalLM
+    from bigdl_amd.transformers.low_bit_linear import LowBitLinear
+    low, conv = M.BigDLLMLOWBITAdapter(), M.BigDLLLMAdapter()
+    assert conv.match("/models/bigdl-7b") and not conv.match("/models/llama")
+    assert low.match("/x/bigdl-lowbit-7b") and not low.match("/x/bigdl-7b")
+    d = str(tmp_path / "bigdl-tiny")
+    shutil.copytree(tiny, d)
+    model, tok = conv.load_model(d, {"revision": "main"})
+    assert isinstance(model.model.layers[0].mlp.down_proj, LowBitLinear) and tok("w1 w2").input_ids
+    ld = str(tmp_path / "bigdl-lowbit-tiny")
+    model.save_low_bit(ld)
+    tok.save_pretrained(ld)
+    again, _ = low.load_model(ld, {})
+    ids = torch.tensor([[5, 6, 7, 8]])
+    with torch.no_grad():
+        torch.testing.assert_close(again(ids).logits, model(ids).logits)
+    # the module-level loader picks the adapter by pattern and falls back to "any causal LM, converted on load"
+    for path in (d, ld, tiny):
+        m, _ = M.load_model(path, device="cpu")
+        assert isinstance(m.model.layers[0].mlp.down_proj, LowBitLinear)
+    # patch_fastchat against a stand-in of FastChat's adapter registry
+    fake = types.ModuleType("fastchat.model.model_adapter")
+
+    class ChatGLMAdapter(M.BaseModelAdapter):
+        def load_model(self, *a):
+            return "orig-glm"
+    fake.ChatGLMAdapter, fake.BaseModelAdapter = ChatGLMAdapter, M.BaseModelAdapter
+    fake.model_adapters = [M.BaseModelAdapter()]
+    fake.register_model_adapter = lambda cls: fake.model_adapters.append(cls())
+    fake.load_model = lambda *a, **k: "orig-load"
+    pkg, sub = types.ModuleType("fastchat"), types.ModuleType("fastchat.model")
+    pkg.model, sub.model_adapter = sub, fake
+    for name, mod in (("fastchat", pkg), ("fastchat.model", sub), ("fastchat.model.model_adapter", fake)):
+        monkeypatch.setitem(sys.modules, name, mod)
+    M.patch_fastchat()
+    try:
+        assert [type(a).__name__ for a in fake.model_adapters[:2]] == ["BigDLLMLOWBITAdapter", "BigDLLLMAdapter"]
+        assert fake.load_model is M.load_model and ChatGLMAdapter.load_model is M.load_model_chatglm
+        assert M.BaseModelAdapter.load_model is M.load_model_base
+        M.patch_fastchat()                                       # idempotent
+        assert len(fake.model_adapters) == 3
+    finally:
+        M.unpatch_fastchat()
+    assert fake.load_model() == "orig-load" and ChatGLMAdapter().load_model() == "orig-glm"
+    assert not M.is_fastchat_patched
