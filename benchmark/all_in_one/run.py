@@ -145,7 +145,22 @@ def _run_hf_generate(repo_id, hub, in_out_pairs, warm_up, num_trials, low_bit, b
     return rows
 
 
+# names the reference's config files use for the same measurement on other hosts (reference run.py:145-205): the
+# Windows variants differ only in how the process is set up there, the IPEX CPU modes are the CPU path of this package
+API_ALIASES = {"bigdl_ipex_bf16": ("transformer_autocast_bf16", None), "bigdl_ipex_int4": ("transformer_int4", "sym_int4"),
+               "bigdl_ipex_int8": ("transformer_int4", "sym_int8")}
+UNSUPPORTED_APIS = ("transformers_int4_npu_win", "transformers_int4_npu_pipeline_win", "transformers_int4_loadlowbit_npu_win",
+                    "transformers_openvino")
+
+
 def run_model(repo_id, test_api, in_out_pairs, local_model_hub, warm_up, num_trials, low_bit, batch_size, conf):
+    if test_api in UNSUPPORTED_APIS:
+        raise ValueError(f"test_api {test_api} measures another runtime (Intel NPU / OpenVINO); nothing to run here")
+    if test_api.endswith("_win"):
+        test_api = test_api[:-len("_win")]
+    if test_api in API_ALIASES:
+        test_api, lb = API_ALIASES[test_api]
+        low_bit = lb or low_bit
     gpu = dict(device="cuda")
     if test_api == "native_engine_gpu":
         return run_native_engine_gpu(repo_id, local_model_hub, in_out_pairs, warm_up, num_trials, low_bit, batch_size, conf)

@@ -203,7 +203,7 @@ def test_all_in_one_benchmark_harness(ckpt, tmp_path):
     import csv
     import yaml
     apis = ["transformer_int4_gpu", "transformer_int4_fp16_gpu", "optimize_model_gpu", "bigdl_fp16_gpu", "lookup_gpu",
-            "speculative_gpu", "ipex_fp16_gpu"]
+            "speculative_gpu", "ipex_fp16_gpu", "transformer_int4_fp16_gpu_win"]     # (_win: a reference config name)
     conf = dict(repo_id=[os.path.basename(str(ckpt))], local_model_hub=os.path.dirname(str(ckpt)), warm_up=1, num_trials=2,
                 num_beams=1, low_bit="sym_int4", batch_size=1, in_out_pairs=["32-8"], test_api=apis, cpu_embedding=False,
                 streaming=False, use_fp16_torch_dtype=True, quantize_kv_cache=False, task="continuation")
