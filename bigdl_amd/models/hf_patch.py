@@ -149,8 +149,10 @@ def optimize_pre(model, qtype=None):
         model.rwkv._rescale_layers()
     # multimodal wrappers: recurse into the language model with its own config (``model.language_model``, or
     # ``model.model.language_model`` where the wrapper keeps towers and decoder under one base module)
-    for holder in (model, getattr(model, "model", None)):
-        for attr in ("language_model", "llm"):
+    # (MiniCPM-o also carries a llama-style decoder inside its speech head: ``model.tts.model``, reference
+    # convert.py:1030-1041)
+    for holder in (model, getattr(model, "model", None), getattr(model, "tts", None)):
+        for attr in ("language_model", "llm") if holder is not getattr(model, "tts", None) or holder is None else ("model",):
             sub = getattr(holder, attr, None) if holder is not None else None
             if isinstance(sub, nn.Module) and getattr(getattr(sub, "config", None), "model_type", None) in MERGE_QKV_TYPES \
                     and sub is not model and mt not in MERGE_QKV_TYPES:

@@ -356,3 +356,44 @@ def test_minicpmv_generate_wrapper_and_penalty_processor():
     want = scores.clone()
     want[0, 1], want[0, 3] = 2.0 / 1.3, -2.0 * 1.3
     torch.testing.assert_close(proc(ids, scores.clone()), want)
+
+
+def test_wrapper_with_llm_and_speech_decoder_gets_both_optimized():
+    """MiniCPM-o / Megrez-o style wrappers keep their text decoder under ``.llm`` and (MiniCPM-o) a second llama-style
+    decoder under ``.tts.model`` (reference convert.py:1030-1047): both get the merged qkv projection and low-bit
+    linears, and the wrapper's logits stay those of the dense model."""
+    import copy
+    from transformers import LlamaConfig, LlamaForCausalLM, LlamaModel, PretrainedConfig
+    from bigdl_amd.optimize import optimize_model
+    from bigdl_amd.transformers.low_bit_linear import LowBitLinear
+    torch.manual_seed(0)
+    cfg = LlamaConfig(vocab_size=96, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+                      num_key_value_heads=2, max_position_embeddings=64)
+
+    class Speech(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.model = LlamaModel(cfg)
+
+    class Omni(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.config = PretrainedConfig()
+            self.config.model_type = "minicpmo"
+            self.llm = LlamaForCausalLM(cfg)
+            self.tts = Speech()
+
+        def forward(self, ids):
+            return self.llm(ids).logits, self.tts.model(ids).last_hidden_state
+
+    m = Omni().eval()
+    ids = torch.randint(3, 96, (1, 7))
+    with torch.no_grad():
+        want = m(ids)
+    q = optimize_model(copy.deepcopy(m), low_bit="sym_int8")
+    for attn in (q.llm.model.layers[0].self_attn, q.tts.model.layers[1].self_attn):
+        assert isinstance(attn.qkv_proj, LowBitLinear) and not hasattr(attn, "q_proj")
+    with torch.no_grad():
+        got = q(ids)
+    for a, b in zip(got, want):
+        assert ((a.float() - b).abs().mean() / b.abs().mean()).item() < 0.05
