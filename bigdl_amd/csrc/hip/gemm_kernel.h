@@ -101,7 +101,8 @@ struct GemmArgs {
 // with an empty loop and no loads, 4 - 8 us until the first four weight tiles of every wavefront have arrived (the
 // 128-byte scale requests cost more than the 1 KiB code requests next to them), 2.5 us for the eleven k-tiles, 6.5 us
 // for the fp32 partials (9.4 MB) -- then 4.8 us of reduce kernel.  Eight wavefronts of one tile each, deeper weight
-// look-ahead, more K splits, rotated k order and tile-major slabs were all measured within 5 % or slower.
+// look-ahead, more K splits, rotated k order, tile-major slabs and one 512-byte scale request per four k-tiles (with
+// ds_bpermute redistribution) were all measured within 5 % or slower.
 template <int QT, int MT, int NT, bool NORM = false, int NW = 4, bool LW = false>
 __global__ __launch_bounds__((NW + (LW ? 1 : 0)) * 64, 2) void gemm_t16_kernel(GemmArgs a) {
   static_assert(!(LW && NORM), "the loader wavefront copies x as it is");
