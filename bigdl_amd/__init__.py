@@ -21,8 +21,17 @@ if _os.environ.get("BIGDL_CHECK_DUPLICATE_IMPORT", "true").lower() in ("true", "
             raise ImportError(f"a different package is already imported as {_alias}: {_m.__file__}")
 
 
+# BIGDL_XPU_ALIAS=1: scripts written for the reference's "xpu" device run as they are (utils/xpu_alias.py)
+if _os.environ.get("BIGDL_XPU_ALIAS", "0").lower() in ("true", "1"):
+    from .utils.xpu_alias import enable_xpu_alias as _enable_xpu_alias
+    _enable_xpu_alias()
+
+
 def __getattr__(name):
     # lazy: importing the package must stay cheap (no torch/transformers import for the qtype table)
+    if name in ("enable_xpu_alias", "disable_xpu_alias"):
+        from .utils import xpu_alias
+        return getattr(xpu_alias, name)
     if name == "optimize_model":
         from .optimize import optimize_model
         return optimize_model

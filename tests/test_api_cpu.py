@@ -474,3 +474,25 @@ def test_load_override_is_recorded_for_the_next_save(tmp_path):
     again = AutoModelForCausalLM.load_low_bit(str(tmp_path / "new"))
     with torch.no_grad():
         assert torch.equal(again(ids).logits, out)
+
+
+def test_xpu_device_alias_runs_reference_style_scripts():
+    """``enable_xpu_alias``: "xpu" in ``.to(...)``, factory functions, ``torch.device`` objects and ``torch.xpu.*`` calls
+    resolves to the device of this build (here the CPU), and goes away again when disabled."""
+    import ipex_llm
+    target = ipex_llm.enable_xpu_alias("cpu")
+    try:
+        assert target == "cpu" and ipex_llm.enable_xpu_alias() == "cpu"          # second call: already on
+        x = torch.zeros(2, 3, device="xpu")
+        y = torch.tensor([1, 2], device=torch.device("xpu", 0)).to("xpu:0")
+        m = torch.nn.Linear(3, 2).to("xpu").to(device="xpu", dtype=torch.float32)
+        out = m(x.to("xpu"))
+        assert x.device.type == y.device.type == out.device.type == "cpu" and m.xpu() is m
+        assert torch.randn(2).xpu().device.type == "cpu" and torch.arange(3, device="xpu").sum().item() == 3
+        torch.xpu.synchronize()
+        torch.xpu.empty_cache()
+        assert torch.xpu.is_available() and torch.xpu.max_memory_allocated() == 0 and torch.xpu.device_count() == 1
+    finally:
+        ipex_llm.disable_xpu_alias()
+    with pytest.raises(Exception):
+        torch.zeros(1, device="xpu")

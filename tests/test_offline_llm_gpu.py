@@ -56,3 +56,24 @@ def test_offline_generate_runs_on_the_batcher_and_matches_single_prompt_generati
     s = llm.generate(prompt_token_ids=prompts[:2], sampling_params=SamplingParams(temperature=0.8, top_p=0.9, top_k=20, max_tokens=5,
                                                                                  ignore_eos=True, seed=1))
     assert all(len(o.outputs[0].token_ids) == 5 for o in s)
+
+
+def test_reference_style_script_with_the_xpu_device_name(tiny_dir):
+    """What the reference's GPU examples do verbatim -- ``.to('xpu')``, ``torch.xpu.synchronize()`` -- after
+    ``enable_xpu_alias()``: the model lands on the GPU of this build and generates the same tokens as with 'cuda'."""
+    import ipex_llm
+    from ipex_llm.transformers import AutoModelForCausalLM
+    ids = torch.randint(3, 320, (1, 12))
+    model = AutoModelForCausalLM.from_pretrained(tiny_dir, load_in_4bit=True).half().to("cuda")
+    want = model.generate(ids.to("cuda"), max_new_tokens=8, do_sample=False).cpu()
+    del model
+    assert ipex_llm.enable_xpu_alias() == "cuda"
+    try:
+        model = AutoModelForCausalLM.from_pretrained(tiny_dir, load_in_4bit=True).half().to("xpu")
+        assert next(model.parameters()).device.type == "cuda"
+        got = model.generate(ids.to("xpu"), max_new_tokens=8, do_sample=False)
+        torch.xpu.synchronize()
+        assert torch.xpu.max_memory_allocated() > 0 and torch.zeros(1, device="xpu:0").is_cuda
+        assert torch.equal(got.cpu(), want)
+    finally:
+        ipex_llm.disable_xpu_alias()
