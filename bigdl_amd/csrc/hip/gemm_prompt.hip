@@ -32,7 +32,7 @@ static int prompt_dispatch(const GemmArgs& a, int qtype, int cfg, hipStream_t st
 // Tile configurations (gemm_prompt_launch<QT> instantiates them in this order) and their relative MFMA efficiency
 // (measured: benchmark/gemm_big_bench.py --sweep).  One workgroup per CU for the 8-wavefront tiles.
 struct PromptCfg { int bm, bn; double eff; };
-static const PromptCfg kPromptCfgs[PROMPT_NCFG] = {{256, 256, 1.0}, {256, 192, 0.79}, {128, 128, 0.50}};
+static const PromptCfg kPromptCfgs[PROMPT_NCFG] = {{256, 256, 1.0}, {256, 192, 0.79}, {128, 128, 0.65}};
 
 struct PromptPlan { int cfg, splitk, kt_per_split; };
 static int g_force_cfg = -1, g_force_sk = 0;         // bigdl_gemm_prompt_force (tests / sweeps)

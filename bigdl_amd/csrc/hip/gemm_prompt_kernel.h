@@ -117,6 +117,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_prompt_kernel(GemmArgs a
     uint32_t* table = (uint32_t*)(smem + prompt_lds_tiles(BM, BN, NW, MTW, NTW));
     fill_nf4_banked(table, threadIdx.x, 64 * NW);
     lut = (const _Float16*)(table + (lane & 31));
+    __syncthreads();       // every wavefront fills a share of the table and the first expansion reads all of it
   }
 
   // ---- x tile: every wavefront stages rows of its own row half (the half it reads fragments from, so that the two
@@ -306,7 +307,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_prompt_kernel(GemmArgs a
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();
   } else {
-    // ---- software-pipelined form (4 wavefronts, one per SIMD: no partner to alternate with).  Tile t (LDS buffers t % 2)
+    // ---- software-pipelined form (4 wavefronts, one per SIMD: no partner to alternate with; none of the configurations
+    // in gemm_prompt_launch uses it since the 128 x 128 tile went to 8 wavefronts).  Tile t (LDS buffers t % 2)
     // runs as four phases of HM x NTW MFMAs: (k step 0, row half 0), (0, 1), (1, 0), (1, 1); fragments live in two named
     // register sets per operand (the set of the phase in flight and the set being filled for the next one; static
     // indices: a run-time set index would put them in scratch).  Phases 0 - 2 also expand tile t + 1 into the other weight
@@ -539,14 +541,17 @@ static int gemm_prompt_launch_cfg(const GemmArgs& a, hipStream_t st) {
   return HIP_CHECK_LAUNCH();
 }
 
-// configurations in the order of gemm_prompt.hip's table: 256 x 256, 256 x 192 (8 wavefronts), 128 x 128 (4 wavefronts)
+// configurations in the order of gemm_prompt.hip's table: 256 x 256, 256 x 192, 128 x 128 (8 wavefronts each)
 #define PROMPT_NCFG 3
 template <int QT>
 static int gemm_prompt_launch(const GemmArgs& a, int cfg, hipStream_t st) {
   switch (cfg) {
     case 0: return gemm_prompt_launch_cfg<QT, 2, 4, 8, 4, PROMPT_PH0>(a, st);
     case 1: return gemm_prompt_launch_cfg<QT, 2, 4, 8, 3, PROMPT_PH1>(a, st);
-    case 2: return gemm_prompt_launch_cfg<QT, 2, 2, 4, 4, 1>(a, st);
+    // 128 x 128 also runs on 8 wavefronts as a ping-pong pair of row halves (one phase per 64-deep tile): 43.8 us on
+    // the 1024 x 4096 x 4096 product against 54.4 us with 4 wavefronts of 64 x 64 each (and ahead on every other shape).
+    // 128 x 256 and 256 x 128 tiles on 8 wavefronts were measured too: within 4 % of the planned choice at best.
+    case 2: return gemm_prompt_launch_cfg<QT, 2, 4, 4, 2, 1>(a, st);
     default: return -4;
   }
 }
