@@ -14,7 +14,9 @@ SHAPES = [("qkv", 12288, 4096, False), ("o", 4096, 4096, False), ("gate_up", 110
 
 def main():
     copies = 16
-    for m in (1, 5):
+    # form 1: row-stream kernel for 1 - 4 rows (the default); form 0: the MFMA form for every row count
+    for m, form in ((1, 1), (1, 0), (4, 1), (4, 0), (5, 1)):
+        hip.gemv_f16_tune(rows_form=form)
         for name, n, k, gu in SHAPES:
             ws = [torch.randn(n, k, device="cuda", dtype=torch.float16) for _ in range(copies)]
             w2 = [torch.randn(n, k, device="cuda", dtype=torch.float16) for _ in range(copies)] if gu else None
@@ -40,7 +42,7 @@ def main():
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / (10 * copies)
             nbytes = n * k * 2 * (2 if gu else 1)
-            print(json.dumps({"shape": name, "M": m, "N": n, "K": k, "us": round(us, 2), "MiB": round(nbytes / 2 ** 20, 1),
+            print(json.dumps({"shape": name, "form": "rows" if form and m <= 4 else "mfma", "M": m, "N": n, "K": k, "us": round(us, 2), "MiB": round(nbytes / 2 ** 20, 1),
                               "TB_per_s": round(nbytes / us / 1e6, 2)}), flush=True)
             del ws, w2
 

@@ -218,6 +218,183 @@ __global__ __launch_bounds__(F16_NW * 64) void gemv_f16_kernel(GemvF16Args a) {
   }
 }
 
+// ---- row-stream form (M <= 4) ------------------------------------------------------------------------------------
+// With one to four rows of x the MFMA has nothing to amortise, and what the weight stream wants is requests whose 64
+// addresses are one contiguous KiB.  Here a wavefront owns ONE weight row (the gate and the up row of one column in the
+// pair form): lane l of request j loads the 16 bytes at k = 512 j + 8 l, all TC requests of the row are issued at the top
+// of the kernel with no branch around them (a branch around a load makes every later wait a full one), then x is staged
+// once per workgroup in LDS (already scaled by gamma, zeros from K on), and each request meets its 8 halves of x in four
+// v_dot2_f32_f16 per row of x.  A cross-lane sum ends the row.  Eight rows per workgroup, ceil(N / 8) workgroups: the
+// shape in which a plain streaming read is fastest on this chip (benchmark/hbm_stream_probe.hip: 512 threads, 8 requests
+// of 16 bytes per lane in flight).  Same prologue / epilogue fusions as the MFMA form above.
+constexpr int FR_NW = 8;
+
+__device__ __forceinline__ float dot8_f16(uint4v w, uint4v x, float acc) {
+  H8 a, b;
+  a.q = w;
+  b.q = x;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_fdot2(a.h2[i], b.h2[i], acc, false);
+  return acc;
+}
+
+// TC: 1 KiB requests per weight row (K <= 512 TC)
+template <int MR, int TC, bool GATE_UP, bool NORM>
+__global__ __launch_bounds__(FR_NW * 64) void gemv_f16_rows_kernel(GemvF16Args a) {
+  constexpr int NACC = GATE_UP ? 2 : 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  extern __shared__ _Float16 xs[];                         // [MR][XS]: x * gamma, zeros from K on
+  const int K512 = (a.K + 511) & ~511, XS = K512 + 8;
+  __shared__ float ssq_sh[FR_NW][MR];
+
+  const int nraw = blockIdx.x * FR_NW + wave;
+  const int n = min(nraw, a.N - 1);                        // (a wavefront past the last row repeats it and stores nothing)
+
+  // ---- requests, in the order in which their data is wanted (vector memory returns in order): x and gamma (out of L2),
+  // the bias, then the weight row.  All unconditional: absent operands point at x, indices past the end are clamped.
+  constexpr int XJ = (TC + 7) / 8;                         // 16-byte pieces of an x row per thread
+  const int per_row = a.K >> 3;
+  H8 xv[MR][XJ], gm[XJ];
+#pragma unroll
+  for (int j = 0; j < XJ; ++j) {
+    const int i = min(tid + j * (FR_NW * 64), per_row - 1);
+#pragma unroll
+    for (int m = 0; m < MR; ++m) xv[m][j].q = *(const uint4v*)(a.x + (int64_t)m * a.ldx + i * 8);
+    if constexpr (NORM) gm[j].q = *(const uint4v*)(a.gamma + i * 8);
+  }
+  const _Float16 b1h = *(a.bias ? a.bias + n : a.x);
+  const _Float16 b2h = *((GATE_UP && a.bias2) ? a.bias2 + n : a.x);
+  uint4v w[NACC][TC];
+  {
+    const int64_t base = (int64_t)n * a.K;
+#pragma unroll
+    for (int u = 0; u < TC; ++u) {
+      // past the end of a row (K % 512 != 0, or K <= 512 (TC - 1)) the address stays on the row's last 16 bytes and x
+      // reads as zero there
+      const int k = min(u * 512 + lane * 8, a.K - 8);
+      w[0][u] = __builtin_nontemporal_load((const uint4v*)(a.w + base + k));
+      if constexpr (GATE_UP) w[1][u] = __builtin_nontemporal_load((const uint4v*)(a.w2 + base + k));
+    }
+  }
+
+  // ---- x (times gamma) into LDS, sums of squares per row.  A piece index past the row was clamped for the load and is
+  // clamped for the store too (it rewrites the row's last piece with the same value): every loaded value is used
+  // unconditionally, so the compiler cannot sink a load into a branch and wait for the whole weight row there.
+#pragma unroll
+  for (int m = 0; m < MR; ++m) {
+    float s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < XJ; ++j) {
+      const int i = tid + j * (FR_NW * 64), ic = min(i, per_row - 1);
+      H8 v = xv[m][j];
+      if constexpr (NORM) {
+        s += i < per_row ? frag_sumsq_f16(v.v) : 0.0f;
+        half8 gmv = gm[j].v;
+        if (a.gamma_offset != 0.0f) gmv = gmv + (_Float16)a.gamma_offset;
+        v.v = v.v * gmv;
+      }
+      *(uint4v*)(xs + m * XS + ic * 8) = v.q;
+    }
+    for (int z = per_row + tid; z * 8 < XS; z += FR_NW * 64) *(uint4v*)(xs + m * XS + z * 8) = uint4v{0, 0, 0, 0};
+    if constexpr (NORM) {
+      s = wave_sum(s);
+      if (lane == 0) ssq_sh[wave][m] = s;
+    }
+  }
+  __syncthreads();
+
+  float acc[NACC][MR];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i)
+#pragma unroll
+    for (int m = 0; m < MR; ++m) acc[i][m] = 0.0f;
+#pragma unroll
+  for (int u = 0; u < TC; ++u) {
+    const int k = min(u * 512 + lane * 8, K512);           // zeros from K on
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+      const uint4v xa = *(const uint4v*)(xs + m * XS + k);
+#pragma unroll
+      for (int i = 0; i < NACC; ++i) acc[i][m] = dot8_f16(w[i][u], xa, acc[i][m]);
+    }
+  }
+
+  // ---- cross-lane sums, epilogue by lane m for row m of x
+  const float b1 = a.bias ? (float)b1h : 0.0f;
+  const float b2 = (GATE_UP && a.bias2) ? (float)b2h : 0.0f;
+#pragma unroll
+  for (int m = 0; m < MR; ++m) {
+    float rs = 1.0f;
+    if constexpr (NORM) {
+      float s = 0.0f;
+#pragma unroll
+      for (int ww = 0; ww < FR_NW; ++ww) s += ssq_sh[ww][m];
+      rs = rsqrtf(s / (float)a.K + a.eps);
+    }
+    float v = wave_sum(acc[0][m]) * rs + b1;
+    if constexpr (GATE_UP) v = act_apply(a.act, v) * (wave_sum(acc[1][m]) * rs + b2);
+    else v = act_apply(a.act, v);
+    if (lane == m && nraw < a.N) {
+      const int64_t o = (int64_t)m * a.ldo + n;
+      if (a.out_type == OUT_F16) {
+        if (a.residual) v += (float)((const _Float16*)a.residual)[o];
+        ((_Float16*)a.out)[o] = (_Float16)v;
+      } else if (a.out_type == OUT_BF16) {
+        if (a.residual) v += bf16_bits_to_f32(((const uint16_t*)a.residual)[o]);
+        ((uint16_t*)a.out)[o] = f32_to_bf16_bits(v);
+      } else {
+        if (a.residual) v += ((const float*)a.residual)[o];
+        ((float*)a.out)[o] = v;
+      }
+    }
+  }
+}
+
+static int g_rows_form = 1;        // bigdl_gemv_f16_tune: 0 = MFMA form for every row count
+
+static size_t f16_rows_lds(int M, int K) { return (size_t)M * (((K + 511) & ~511) + 8) * 2; }
+// the row-stream form takes M <= 4 with x inside 64 KB of LDS and rows of at most 32 requests (16 in the pair form)
+static bool f16_rows_ok(int M, int K, bool pair) {
+  return g_rows_form && M <= 4 && f16_rows_lds(M, K) <= 64 * 1024 && K <= 512 * (pair ? 16 : 32);
+}
+
+template <int MR, int TC, bool GATE_UP, bool NORM>
+static int launch_f16_rows(const GemvF16Args& a, hipStream_t stream) {
+  const int grid = (a.N + FR_NW - 1) / FR_NW;
+  const size_t xbytes = f16_rows_lds(MR, a.K);
+  auto k = gemv_f16_rows_kernel<MR, TC, GATE_UP, NORM>;
+  static bool raised = false;                   // one opt-in per instantiation: dynamic LDS above the default
+  if (!raised && xbytes > 32 * 1024) {
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess) return -5;
+    raised = true;
+  }
+  hipLaunchKernelGGL(k, dim3(grid), dim3(FR_NW * 64), xbytes, stream, a);
+  return HIP_CHECK_LAUNCH();
+}
+
+template <int MR, bool GATE_UP, bool NORM>
+static int launch_f16_rows_tc(const GemvF16Args& a, hipStream_t stream) {
+  const int t = (a.K + 511) / 512;
+  if (t <= 8) return launch_f16_rows<MR, 8, GATE_UP, NORM>(a, stream);
+  if (t <= 16) return launch_f16_rows<MR, 16, GATE_UP, NORM>(a, stream);
+  if constexpr (!GATE_UP) {
+    if (t <= 22) return launch_f16_rows<MR, 22, GATE_UP, NORM>(a, stream);
+    if (t <= 28) return launch_f16_rows<MR, 28, GATE_UP, NORM>(a, stream);
+    if (t <= 32) return launch_f16_rows<MR, 32, GATE_UP, NORM>(a, stream);
+  }
+  return -1;
+}
+
+template <bool GATE_UP, bool NORM>
+static int launch_f16_rows_m(const GemvF16Args& a, hipStream_t stream) {
+  switch (a.M) {
+    case 1: return launch_f16_rows_tc<1, GATE_UP, NORM>(a, stream);
+    case 2: return launch_f16_rows_tc<2, GATE_UP, NORM>(a, stream);
+    case 3: return launch_f16_rows_tc<3, GATE_UP, NORM>(a, stream);
+    default: return launch_f16_rows_tc<4, GATE_UP, NORM>(a, stream);
+  }
+}
+
 template <bool GATE_UP, bool NORM>
 static int launch_f16(const GemvF16Args& a, hipStream_t stream) {
   const dim3 grid(a.N / 16), block(F16_NW * 64);
@@ -254,6 +431,13 @@ extern "C" int bigdl_gemv_f16(const void* x, const void* w, const void* w2, void
   a.bias = (const _Float16*)bias; a.bias2 = (const _Float16*)bias2; a.residual = residual;
   a.gamma = (const _Float16*)gamma; a.eps = eps; a.gamma_offset = gamma_offset;
   a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldo = ldo; a.act = act; a.out_type = out_type;
+  if (f16_rows_ok(M, K, w2 != nullptr)) {
+    if (w2) return gamma ? launch_f16_rows_m<true, true>(a, stream) : launch_f16_rows_m<true, false>(a, stream);
+    return gamma ? launch_f16_rows_m<false, true>(a, stream) : launch_f16_rows_m<false, false>(a, stream);
+  }
   if (w2) return gamma ? launch_f16<true, true>(a, stream) : launch_f16<true, false>(a, stream);
   return gamma ? launch_f16<false, true>(a, stream) : launch_f16<false, false>(a, stream);
 }
+
+// Measurement hook (benchmark/gemv_f16_probe.py): rows_form 0 sends every row count to the MFMA form.
+extern "C" void bigdl_gemv_f16_tune(int rows_form) { g_rows_form = rows_form; }

@@ -40,6 +40,8 @@ def lib():
         vp, i64, ci, cf = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
         L.bigdl_gemv_lowbit.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, cf, cf, ci, ci, ci, ci, ci, ci, ci, ci, vp, ci, ci, ci, ci, ci, ci, vp]
         L.bigdl_gemv_f16.argtypes = [vp] * 8 + [cf, cf] + [ci] * 7 + [vp]
+        L.bigdl_gemv_f16_tune.argtypes = [ci]
+        L.bigdl_gemv_f16_tune.restype = None
         L.bigdl_gemv_lowbit_ln.argtypes = [vp] * 8 + [cf] + [ci] * 8 + [vp] * 5
         L.bigdl_attn_decode.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, ci, ci, ci, cf, cf] + [ci] * 14 + [vp, vp, vp]
         L.bigdl_kv_int4_append.argtypes = [vp, vp, vp, vp, vp] + [ci] * 7 + [i64, vp]
@@ -166,6 +168,11 @@ def gemv_lowbit(x, w, qtype, out_features, in_features, *, w2=None, bias=None, b
 def gemv_f16_ok(m, n, k):
     """shapes the fp16 skinny GEMM takes (csrc/hip/gemv_f16.hip)"""
     return 0 < m <= 16 and n % 16 == 0 and k % 64 == 0
+
+
+def gemv_f16_tune(rows_form=1):
+    """measurement hook: ``rows_form=0`` sends 1 - 4 rows to the MFMA form too (benchmark/gemv_f16_probe.py)"""
+    lib().bigdl_gemv_f16_tune(int(rows_form))
 
 
 def gemv_f16(x, w, *, w2=None, bias=None, bias2=None, residual=None, gamma=None, eps=1e-6, gamma_offset=0.0, act=None,

@@ -144,7 +144,10 @@ def test_attention_1100_keys_32_heads_with_deferred_combine(hip, fp8, batch):
 # ------------------------------------------------------------------------------------------------
 # fp16 weights, row-major as stored (csrc/hip/gemv_f16.hip): decode / speculative-verification rows
 @pytest.mark.parametrize("n,k,m", [(12288, 4096, 1), (4096, 4096, 5), (4096, 11008, 1), (4096, 11008, 9), (32000, 4096, 1),
-                                    (4544, 4544, 3), (256, 64, 16)])
+                                    (4544, 4544, 3), (256, 64, 16),
+                                    # row-stream form (1 - 4 rows): every request count per row, K % 512 != 0, x at the LDS cap
+                                    (4096, 4096, 4), (4096, 11008, 2), (4096, 14336, 2), (8192, 8192, 3), (1024, 16384, 1),
+                                    (4096, 11008, 4), (272, 4544, 2), (48, 64, 1)])
 def test_gemv_f16_against_fp32(n, k, m):
     from bigdl_amd.ops import hip
     g = torch.Generator(device="cuda").manual_seed(n + k + m)
@@ -163,12 +166,20 @@ def test_gemv_f16_against_fp32(n, k, m):
     got = hip.gemv_f16(x, w, out_dtype=torch.float32)
     want = xf @ w.float().T
     assert (got - want).abs().max().item() < 5e-3 * max(1.0, want.abs().max().item())
+    if m <= 4:
+        # both forms of the kernel on the same operands
+        hip.gemv_f16_tune(rows_form=0)
+        try:
+            other = hip.gemv_f16(x, w, out_dtype=torch.float32)
+        finally:
+            hip.gemv_f16_tune(rows_form=1)
+        assert (got - other).abs().max().item() < 2e-3 * max(1.0, want.abs().max().item())
 
 
-@pytest.mark.parametrize("m", [1, 4, 9])
-def test_gemv_f16_gate_up(m):
+@pytest.mark.parametrize("m,n,k", [(1, 11008, 4096), (4, 11008, 4096), (9, 11008, 4096), (2, 28672, 8192), (3, 1024, 5120),
+                                   (1, 512, 12288)])
+def test_gemv_f16_gate_up(m, n, k):
     from bigdl_amd.ops import hip
-    n, k = 11008, 4096
     g = torch.Generator(device="cuda").manual_seed(m)
     wg = (torch.randn(n, k, device="cuda", generator=g) / k ** 0.5).half()
     wu = (torch.randn(n, k, device="cuda", generator=g) / k ** 0.5).half()
