@@ -225,8 +225,11 @@ def main():
         for model in conf["repo_id"]:
             bs = conf["batch_size"] if isinstance(conf["batch_size"], list) else [conf["batch_size"]]
             for b in bs:
-                results += run_model(model, api, conf["in_out_pairs"], conf.get("local_model_hub", ""), conf["warm_up"],
-                                     conf["num_trials"], conf["low_bit"], b, conf)
+                rows = run_model(model, api, conf["in_out_pairs"], conf.get("local_model_hub", ""), conf["warm_up"],
+                                 conf["num_trials"], conf["low_bit"], b, conf)
+                for r in rows:
+                    r[-1] = api                  # the name the config asked for (an alias runs under its own name)
+                results += rows
         out = os.path.join(a.output_dir, f"{api}-results-{today}.csv")
         rank0 = int(os.environ.get("RANK", 0)) == 0
         if rank0:

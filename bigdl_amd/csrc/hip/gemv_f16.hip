@@ -218,8 +218,8 @@ __global__ __launch_bounds__(F16_NW * 64) void gemv_f16_kernel(GemvF16Args a) {
   }
 }
 
-// ---- row-stream form (M <= 4) ------------------------------------------------------------------------------------
-// With one to four rows of x the MFMA has nothing to amortise, and what the weight stream wants is requests whose 64
+// ---- row-stream form (M <= 2) ------------------------------------------------------------------------------------
+// With one or two rows of x the MFMA has nothing to amortise, and what the weight stream wants is requests whose 64
 // addresses are one contiguous KiB.  Here a wavefront owns ONE weight row (the gate and the up row of one column in the
 // pair form): lane l of request j loads the 16 bytes at k = 512 j + 8 l, all TC requests of the row are issued at the top
 // of the kernel with no branch around them (a branch around a load makes every later wait a full one), then x is staged
@@ -353,9 +353,12 @@ __global__ __launch_bounds__(FR_NW * 64) void gemv_f16_rows_kernel(GemvF16Args a
 static int g_rows_form = 1;        // bigdl_gemv_f16_tune: 0 = MFMA form for every row count
 
 static size_t f16_rows_lds(int M, int K) { return (size_t)M * (((K + 511) & ~511) + 8) * 2; }
-// the row-stream form takes M <= 4 with x inside 64 KB of LDS and rows of at most 32 requests (16 in the pair form)
+// The row-stream form takes one or two rows of x (measured at the Llama-2-7B shapes, us per launch, row-stream / MFMA form:
+// 1 row 16.9 / 22.9 qkv, 30.3 / 41.4 gate + up, 17.7 / 25.1 down; 2 rows 20.7 / 25.8, 39.3 / 43.1, 20.5 / 26.1; 3 rows
+// 22.9 / 29.1, 48.0 / 45.3, 35.4 / 35.5; 4 rows 34.5 / 31.1, 54.9 / 46.6, 36.0 / 36.2) with x inside 64 KB of LDS and
+// weight rows of at most 32 requests (16 in the pair form).
 static bool f16_rows_ok(int M, int K, bool pair) {
-  return g_rows_form && M <= 4 && f16_rows_lds(M, K) <= 64 * 1024 && K <= 512 * (pair ? 16 : 32);
+  return g_rows_form && M <= 2 && f16_rows_lds(M, K) <= 64 * 1024 && K <= 512 * (pair ? 16 : 32);
 }
 
 template <int MR, int TC, bool GATE_UP, bool NORM>
@@ -387,12 +390,8 @@ static int launch_f16_rows_tc(const GemvF16Args& a, hipStream_t stream) {
 
 template <bool GATE_UP, bool NORM>
 static int launch_f16_rows_m(const GemvF16Args& a, hipStream_t stream) {
-  switch (a.M) {
-    case 1: return launch_f16_rows_tc<1, GATE_UP, NORM>(a, stream);
-    case 2: return launch_f16_rows_tc<2, GATE_UP, NORM>(a, stream);
-    case 3: return launch_f16_rows_tc<3, GATE_UP, NORM>(a, stream);
-    default: return launch_f16_rows_tc<4, GATE_UP, NORM>(a, stream);
-  }
+  if (a.M == 1) return launch_f16_rows_tc<1, GATE_UP, NORM>(a, stream);
+  return launch_f16_rows_tc<2, GATE_UP, NORM>(a, stream);
 }
 
 template <bool GATE_UP, bool NORM>

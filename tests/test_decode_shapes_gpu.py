@@ -145,9 +145,9 @@ def test_attention_1100_keys_32_heads_with_deferred_combine(hip, fp8, batch):
 # fp16 weights, row-major as stored (csrc/hip/gemv_f16.hip): decode / speculative-verification rows
 @pytest.mark.parametrize("n,k,m", [(12288, 4096, 1), (4096, 4096, 5), (4096, 11008, 1), (4096, 11008, 9), (32000, 4096, 1),
                                     (4544, 4544, 3), (256, 64, 16),
-                                    # row-stream form (1 - 4 rows): every request count per row, K % 512 != 0, x at the LDS cap
-                                    (4096, 4096, 4), (4096, 11008, 2), (4096, 14336, 2), (8192, 8192, 3), (1024, 16384, 1),
-                                    (4096, 11008, 4), (272, 4544, 2), (48, 64, 1)])
+                                    # row-stream form (1 - 2 rows): every request count per row, K % 512 != 0, x at the LDS cap
+                                    (4096, 4096, 2), (4096, 11008, 2), (4096, 14336, 2), (8192, 8192, 2), (1024, 16384, 1),
+                                    (4096, 11008, 4), (272, 4544, 2), (48, 64, 1), (1024, 16384, 2)])
 def test_gemv_f16_against_fp32(n, k, m):
     from bigdl_amd.ops import hip
     g = torch.Generator(device="cuda").manual_seed(n + k + m)
@@ -166,7 +166,7 @@ def test_gemv_f16_against_fp32(n, k, m):
     got = hip.gemv_f16(x, w, out_dtype=torch.float32)
     want = xf @ w.float().T
     assert (got - want).abs().max().item() < 5e-3 * max(1.0, want.abs().max().item())
-    if m <= 4:
+    if m <= 2:
         # both forms of the kernel on the same operands
         hip.gemv_f16_tune(rows_form=0)
         try:
@@ -176,7 +176,7 @@ def test_gemv_f16_against_fp32(n, k, m):
         assert (got - other).abs().max().item() < 2e-3 * max(1.0, want.abs().max().item())
 
 
-@pytest.mark.parametrize("m,n,k", [(1, 11008, 4096), (4, 11008, 4096), (9, 11008, 4096), (2, 28672, 8192), (3, 1024, 5120),
+@pytest.mark.parametrize("m,n,k", [(1, 11008, 4096), (4, 11008, 4096), (9, 11008, 4096), (2, 28672, 8192), (2, 1024, 5120),
                                    (1, 512, 12288)])
 def test_gemv_f16_gate_up(m, n, k):
     from bigdl_amd.ops import hip
