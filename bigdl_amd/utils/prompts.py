@@ -55,6 +55,20 @@ def _chatml(default_system: str = "") -> Callable[..., str]:
     return build
 
 
+def _rwkv(sep: str) -> Callable[..., str]:
+    """RWKV world models: a greeting turn first, turns separated by ``sep`` (blank line for v4, newline for v5);
+    newlines inside an instruction are collapsed because a blank line ends a turn."""
+    greeting = ("Hi. I am your assistant and I will provide expert full response in full details. Please feel free to ask "
+                "any question and I will always answer it.")
+
+    def build(prompt: str, history: History = (), system: str = "") -> str:
+        clean = lambda t: t.strip().replace("\r\n", "\n").replace("\n\n", "\n")
+        turns = [("hi", greeting), *[(clean(u), a.strip()) for u, a in history]]
+        out = "".join(f"User: {u}{sep}Assistant: {a}{sep}" for u, a in turns)
+        return (system + sep if system else "") + out + f"User: {clean(prompt)}{sep}Assistant:"
+    return build
+
+
 _ALPACA = ("Below is an instruction that describes a task. Write a response that appropriately completes the request.\n\n"
            "### Instruction:\n{prompt}\n\n### Response:\n")
 
@@ -106,8 +120,8 @@ PROMPT_FORMATS: dict[str, Union[str, Callable[..., str]]] = {
     "qwen2.5": CHAT_TEMPLATE,
     "redpajama": "<human>: {prompt}\n<bot>:",
     "replit": "{prompt}",
-    "rwkv4": "Question: {prompt}\n\nAnswer:",
-    "rwkv5": "User: {prompt}\n\nAssistant:",
+    "rwkv4": _rwkv("\n\n"),
+    "rwkv5": _rwkv("\n"),
     "solar": "<s>### User:\n{prompt}\n### Assistant:\n",
     "stablelm": "<|user|>\n{prompt} <|endoftext|>\n<|assistant|>",
     "starcoder": "{prompt}",
