@@ -220,13 +220,20 @@ class MoEWeights:
         """h [m, H] fp16 (residual stream), updated in place: h += moe(rmsnorm(h))"""
         from ..ops import hip
         cfg = engine.cfg
-        x = hip.rms_norm(h, gamma, cfg.rms_eps, offset=cfg.norm_offset)
-        if self.ep_mode == "a2a" and self.ep_world > 1:
-            y = self.forward_gather_scatter(x)
-            sy, gl = self._shared_out(engine, x)
-            hip.moe_combine(y, 1, h, shared=sy, shared_gate=gl, residual=h)
-            return h
-        ids, w = self.route(x)
+        a2a = self.ep_mode == "a2a" and self.ep_world > 1
+        plain = not (self.n_group > 1 or self.score == "sigmoid")
+        if not a2a and plain and h.shape[0] <= 256 and hip.moe_norm_route_ok(h, gamma, self.router, self.num_experts):
+            # norm + router product + top-k in one launch (three otherwise, each mostly fixed cost at a few rows)
+            x, ids, w = hip.moe_norm_route(h, gamma, cfg.rms_eps, self.router, self.top_k, self.normalize,
+                                           expert_range=self.expert_range, offset=cfg.norm_offset)
+        else:
+            x = hip.rms_norm(h, gamma, cfg.rms_eps, offset=cfg.norm_offset)
+            if a2a:
+                y = self.forward_gather_scatter(x)
+                sy, gl = self._shared_out(engine, x)
+                hip.moe_combine(y, 1, h, shared=sy, shared_gate=gl, residual=h)
+                return h
+            ids, w = self.route(x)
         m, k = x.shape[0], self.top_k
         if self.fused:
             a = hip.gemv_lowbit_moe(x, self.gate, self.qtype, self.n_local, self.inter, self.hidden, ids.view(-1),

@@ -81,6 +81,7 @@ def lib():
         L.bigdl_moe_block_table.argtypes = [vp, ci, ci, ci, vp, vp, vp, vp]
         L.bigdl_moe_route.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, i64, ci, ci, vp]
         L.bigdl_moe_combine.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, i64, vp]
+        L.bigdl_moe_norm_route.argtypes = [vp] * 6 + [ci, ci, i64, cf, cf] + [ci] * 6 + [vp]
         L.bigdl_rwkv_time_shift.argtypes = [vp, vp, vp, vp, i64, ci, ci, ci, vp]
         L.bigdl_rwkv4_wkv.argtypes = [vp] * 8 + [ci] * 5 + [vp]
         L.bigdl_rwkv5_wkv.argtypes = [vp] * 7 + [ci] * 4 + [vp]
@@ -512,6 +513,35 @@ def moe_route(logits, top_k, normalize=True, expert_range=None, sigmoid_scores=F
                                logits.stride(0), int(logits.dtype == torch.float32), int(bool(sigmoid_scores)), _stream())
     _check(rc, "moe_route")
     return ids, weights
+
+
+def moe_norm_route_ok(h, gamma, router, n_experts) -> bool:
+    """whether :func:`moe_norm_route` takes these operands"""
+    return (h.is_cuda and h.dtype == torch.float16 and h.dim() == 2 and h.stride(1) == 1 and h.stride(0) % 8 == 0
+            and h.shape[1] % 8 == 0 and h.shape[1] <= 8192 and h.shape[0] <= 65535
+            and gamma.dtype == torch.float16 and gamma.is_contiguous()
+            and router.dtype == torch.float16 and router.is_contiguous() and tuple(router.shape) == (n_experts, h.shape[1])
+            and n_experts <= 1024)
+
+
+def moe_norm_route(h, gamma, eps, router, top_k, normalize=True, expert_range=None, offset=0.0, sigmoid_scores=False):
+    """One launch for the head of a routed layer's decode step: ``x = rmsnorm(h) * (gamma + offset)`` (fp16 [T, H]),
+    router logits ``x @ router.T`` (fp32 sums rounded to fp16, like the dense product) and the softmax / top-k of
+    :func:`moe_route` -> ``(x, ids int32 [T, top_k], weights fp32 [T, top_k])``."""
+    _need_cuda(h, gamma, router)
+    e = router.shape[0]
+    if not moe_norm_route_ok(h, gamma, router, e):
+        raise ValueError("moe_norm_route: fp16 rows of H % 8 == 0, H <= 8192 and a contiguous fp16 [E, H] router")
+    t, hd = h.shape
+    x = torch.empty((t, hd), dtype=torch.float16, device=h.device)
+    ids = torch.empty((t, top_k), dtype=torch.int32, device=h.device)
+    weights = torch.empty((t, top_k), dtype=torch.float32, device=h.device)
+    lo, hi = expert_range if expert_range is not None else (0, 0)
+    rc = lib().bigdl_moe_norm_route(_ptr(h), _ptr(gamma), _ptr(router), _ptr(x), _ptr(ids), _ptr(weights), t, hd,
+                                    h.stride(0), eps, offset, e, top_k, int(bool(normalize)), lo, hi,
+                                    int(bool(sigmoid_scores)), _stream())
+    _check(rc, "moe_norm_route")
+    return x, ids, weights
 
 
 def moe_combine(y, top_k, out, *, shared=None, shared_gate=None, residual=None):

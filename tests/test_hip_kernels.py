@@ -413,6 +413,43 @@ def test_moe_route_matches_softmax_topk(hip, cfg, dtype):
     torch.testing.assert_close(w2, rv, rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("cfg", [(1, 4096, 8, 2, True, 0.0), (5, 2048, 60, 4, False, 0.0), (3, 8192, 64, 6, True, 1.0),
+                                 (17, 256, 130, 8, True, 0.0)])
+def test_moe_norm_route_matches_separate_ops(hip, cfg):
+    """one launch (RMSNorm + router product + top-k) against a plain fp32 PyTorch statement of the three steps, and
+    bit-for-bit on x against the stand-alone norm kernel"""
+    t, h, e, k, norm, offset = cfg
+    torch.manual_seed(22)
+    hid = torch.randn(t + 1, h + 8).half().cuda()[1:, :h]            # strided rows
+    gamma = (1 + 0.1 * torch.randn(h)).half().cuda()
+    router = (torch.randn(e, h) * 0.05).half().cuda()
+    x, ids, w = hip.moe_norm_route(hid, gamma, 1e-5, router, k, normalize=norm, offset=offset)
+    assert torch.equal(x, hip.rms_norm(hid, gamma, 1e-5, offset=offset))
+    hf = hid.float()
+    xr = (hf * torch.rsqrt(hf.pow(2).mean(-1, keepdim=True) + 1e-5) * (gamma.float() + offset)).half()
+    torch.testing.assert_close(x, xr, rtol=2e-3, atol=2e-3)
+    logits = (x.float() @ router.float().t()).half().float()        # the dense product writes fp16 logits
+    p = torch.softmax(logits, -1)
+    rv, ri = torch.topk(p, k, dim=-1)
+    if norm:
+        rv = rv / rv.sum(-1, keepdim=True)
+    # a different summation order can move a logit by one fp16 step: compare the picked probability mass, and the ids
+    # wherever the reference's k-th and (k+1)-th candidates are not within such a step of each other
+    pk = p.gather(1, ids.long())
+    if norm:
+        pk = pk / pk.sum(-1, keepdim=True)
+    torch.testing.assert_close(w, pk, rtol=2e-3, atol=1e-5)
+    srt = p.sort(-1, descending=True).values
+    clear = (srt[:, k - 1] - srt[:, k]) > 4e-3 * srt[:, k - 1]      # the set of picked experts is unambiguous
+    assert clear.any()
+    assert torch.equal(ids.long().sort(-1).values[clear], ri.sort(-1).values[clear])
+    lo, hi = e // 2, e
+    _, ids2, w2 = hip.moe_norm_route(hid, gamma, 1e-5, router, k, normalize=norm, offset=offset, expert_range=(lo, hi))
+    il = ids.long()
+    assert torch.equal(ids2.long(), torch.where((il >= lo) & (il < hi), il - lo, torch.full_like(il, -1)))
+    assert torch.equal(w2, w)
+
+
 @pytest.mark.parametrize("name", ["sym_int4", "asym_int4", "sym_int8", "fp6"])
 def test_routed_expert_gemv(hip, name):
     torch.manual_seed(21)
