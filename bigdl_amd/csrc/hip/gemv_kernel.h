@@ -50,6 +50,9 @@ __device__ unsigned long long* g_gemv_stamps;
 #ifndef GEMV_FORCE_OCC
 #define GEMV_FORCE_OCC 0
 #endif
+#ifndef GEMV_SCLDS
+#define GEMV_SCLDS 0
+#endif
 #ifndef GEMV_NW_MAIN
 #define GEMV_NW_MAIN 8
 #endif
@@ -92,6 +95,11 @@ struct GemvArgs {
   const float* slot_scale;
   int n_total;
   int slot_xdiv, n_slots;
+  // slot_cat = top_k > 0 (kernel template parameter CAT): blockIdx.y = token; the token's top_k routed products are summed
+  // inside the launch by running them as ONE product over the concatenated reduction axis, k-tile kt belonging to
+  // expert slot_expert[token * top_k + kt / (KT / top_k)].  x is [tokens * top_k, K / top_k] contiguous (ldx = K), already
+  // scaled by the routing weights; rows of absent experts (negative id) must be zero.  K / top_k % 128 == 0.
+  int slot_cat;
   // CU-resident kernels (template parameter CU): output tiles whose K-split partials fit the LDS at once
   int cu_ntc;
 };
@@ -271,13 +279,14 @@ constexpr int XTAIL = 128;   // zero halves after each LDS x row: the k-tile "on
 // LEAN: every (chunk, row) item of x is one of the EX early items of its wavefront (M * ceil(ceil(K / 512) / NW) <= EX: one
 // row up to K = 8192, two up to K = 4096); the general staging loop is compiled out, which keeps the tile-per-workgroup kernel
 // within the 80 VGPRs that let three of its workgroups share a CU.
-template <int QT, int MT, bool GATE_UP, bool XLDS, int NW, bool ATT = false, bool CU = false, bool LEAN = false>
+template <int QT, int MT, bool GATE_UP, bool XLDS, int NW, bool ATT = false, bool CU = false, bool LEAN = false, bool CAT = false>
 #ifndef GEMV_GU_OCC
 #define GEMV_GU_OCC 5
 #endif
 __global__ __launch_bounds__(NW * 64, LEAN ? 6 : (NW + 3) / 4) void gemv_t16_kernel(GemvArgs a) {
   static_assert(!ATT || XLDS, "the attention combine lives in the LDS staging of x");
   static_assert(!CU || (MT == 1 && XLDS && NW == 16), "CU form: at most 16 rows, x in LDS, 16 wavefronts");
+  static_assert(!CAT || (MT == 1 && XLDS && !GATE_UP && !ATT && !CU && !LEAN && !GEMV_SCLDS), "summed routed products: one row, x in LDS");
   constexpr int GEMV_NW = NW;
   constexpr int NACC = GATE_UP ? 2 : 1;
   constexpr int NSTREAM = GATE_UP ? 2 : 1;
@@ -324,7 +333,18 @@ __global__ __launch_bounds__(NW * 64, LEAN ? 6 : (NW + 3) / 4) void gemv_t16_ker
   int orow = 0, n_planes = a.N;
   int64_t wt = 0;      // first weight tile row of the selected expert
   float oscale = 1.0f;
-  if (a.slot_expert != nullptr) {
+  int cat_e[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // CAT: first weight tile row of each of the token's experts
+  int cat_kt = 1;                              // CAT: k-tiles per expert
+  if constexpr (CAT) {
+    const int tok = blockIdx.y;
+    orow = tok;
+    n_planes = a.n_total;
+    a.x += (int64_t)tok * a.ldx;
+    cat_kt = (a.K >> 7) / a.slot_cat;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (j < a.slot_cat) cat_e[j] = max(__builtin_amdgcn_readfirstlane(a.slot_expert[tok * a.slot_cat + j]), 0) * (a.N >> 4);
+  } else if (a.slot_expert != nullptr) {
     const int slot = blockIdx.y;
     const int e = a.slot_expert[slot];
     orow = slot;
@@ -344,8 +364,10 @@ __global__ __launch_bounds__(NW * 64, LEAN ? 6 : (NW + 3) / 4) void gemv_t16_ker
     if (a.slot_scale != nullptr) oscale = a.slot_scale[slot];
   }
   T16Planes pl[NSTREAM];
-  pl[0] = t16_planes(a.w, QT, n_planes, a.K);
-  if constexpr (GATE_UP) pl[1] = t16_planes(a.w2, QT, n_planes, a.K);
+  // (CAT: a.K spans the token's top_k experts; the stacked matrices themselves are K / top_k wide)
+  const int k_planes = CAT ? a.K / a.slot_cat : a.K;
+  pl[0] = t16_planes(a.w, QT, n_planes, k_planes);
+  if constexpr (GATE_UP) pl[1] = t16_planes(a.w2, QT, n_planes, k_planes);
   const int64_t tile0 = (wt + nt) * KT;
   // CU form: this workgroup's tiles are nt + i * gridDim.x, i < cnt; a tile takes RPN rounds of U k-tiles per wavefront
   const int n_tiles = (a.N + 15) >> 4;
@@ -445,6 +467,18 @@ __global__ __launch_bounds__(NW * 64, LEAN ? 6 : (NW + 3) / 4) void gemv_t16_ker
   static_assert(NT_R == 2 || NT_R == 4, "one scale load per round covers at most four tiles");
   const int jl = g & (NT_R - 1), ul = jl / NSTREAM, sl = jl % NSTREAM;     // the slot whose scales this lane fetches
   int f_i = 0, f_rd = 0;      // CU: fetch cursor (tile of this workgroup, round within the tile)
+  // weight tile of k-tile kt (already clamped to the last one) of the tile row that starts at t0
+  auto tile_at = [&](int64_t t0, int kt) -> int64_t {
+    if constexpr (CAT) {
+      int j = 0, first = cat_e[0];
+#pragma unroll
+      for (int q = 1; q < 8; ++q)
+        if (kt >= q * cat_kt) { j = q; first = cat_e[q]; }
+      return ((int64_t)first + nt) * cat_kt + (kt - j * cat_kt);
+    } else {
+      return t0 + kt;
+    }
+  };
   auto fetch = [&](Tile<QT> (&tt)[NSTREAM][U], RoundScales& rs, int base) {
     int64_t t0 = tile0;
     if constexpr (CU) {
@@ -458,12 +492,12 @@ __global__ __launch_bounds__(NW * 64, LEAN ? 6 : (NW + 3) / 4) void gemv_t16_ker
 #pragma unroll
       for (int st = 0; st < NSTREAM; ++st)
       {
-        if constexpr (RSC || SCLDS) load_tile_codes<QT>(tt[st][u], pl[st], t0 + min(wave + GEMV_NW * (base + u), KT - 1), lane);
-        else load_tile<QT>(tt[st][u], pl[st], t0 + min(wave + GEMV_NW * (base + u), KT - 1), lane);
+        if constexpr (RSC || SCLDS) load_tile_codes<QT>(tt[st][u], pl[st], tile_at(t0, min(wave + GEMV_NW * (base + u), KT - 1)), lane);
+        else load_tile<QT>(tt[st][u], pl[st], tile_at(t0, min(wave + GEMV_NW * (base + u), KT - 1)), lane);
       }
     if constexpr (!RSC) return;
 #ifndef GEMV_ABL_NOSC
-    const int64_t tl = t0 + min(wave + GEMV_NW * (base + ul), KT - 1);
+    const int64_t tl = tile_at(t0, min(wave + GEMV_NW * (base + ul), KT - 1));
     const _Float16* scp = pl[0].sc;
     const _Float16* mnp = pl[0].mn;
     if constexpr (NSTREAM == 2) {
@@ -956,6 +990,21 @@ static int launch_x(const GemvArgs& a_in, hipStream_t st) {
     return (size_t)nw * NACC * MT * 256 * 4 + misc(nw, xlds) +
            (GEMV_SCLDS ? (size_t)(has_min_of(QT) ? 2 : 1) * NACC * (Kp / 128) * 128 : 0);
   };
+  if (a.slot_expert != nullptr && a.slot_cat > 0) {
+    // summed routed products (n_slots = tokens): the general 8-wavefront kernel with x in LDS
+    if constexpr (MT == 1 && !GATE_UP && !GEMV_SCLDS) {
+#ifndef GEMV_CAT_NW
+#define GEMV_CAT_NW 16
+#endif
+      auto k = gemv_t16_kernel<QT, 1, false, true, GEMV_CAT_NW, false, false, false, true>;
+      const size_t lds = fixed(GEMV_CAT_NW) + xbytes;
+      if (a.M != 1 || a.slot_cat > 8 || (a.K & 127) || (a.K >> 7) % a.slot_cat || !gemv_allow_lds((const void*)k, lds)) return -7;
+      hipLaunchKernelGGL(k, grid, dim3(GEMV_CAT_NW * 64), lds, st, a);
+      return HIP_CHECK_LAUNCH();
+    } else {
+      return -7;
+    }
+  }
   if constexpr (MT == 1) {
     // CU-resident form: one workgroup per CU streams all its output tiles (see the kernel's comment).  Needs x and
     // at least one tile's partial sums in LDS.

@@ -71,7 +71,7 @@ static int gemv_lowbit_impl(const void* x, const void* w, const void* w2, void* 
   a.att_ws = att_ws; a.att_splits = att_splits; a.att_D = att_D; a.att_G = att_G; a.att_Hkv = att_Hkv;
   a.att_qlen = att_qlen; a.att_rows_alloc = att_rows_alloc;
   a.ln_c1 = ln_c1; a.ln_c2 = ln_c2; a.ln2_c1 = ln2_c1; a.ln2_c2 = ln2_c2;
-  a.slot_expert = nullptr; a.slot_scale = nullptr; a.n_total = 0; a.slot_xdiv = 1; a.n_slots = 0;
+  a.slot_expert = nullptr; a.slot_scale = nullptr; a.n_total = 0; a.slot_xdiv = 1; a.n_slots = 0; a.slot_cat = 0;
   return dispatch(a, qtype, stream);
 }
 
@@ -121,6 +121,32 @@ extern "C" int bigdl_gemv_lowbit_moe(const void* x, const void* w, const void* w
   a.att_ws = nullptr; a.att_splits = 0; a.att_D = 0; a.att_G = 0; a.att_Hkv = 0; a.att_qlen = 1; a.att_rows_alloc = 0;
   a.ln_c1 = nullptr; a.ln_c2 = nullptr; a.ln2_c1 = nullptr; a.ln2_c2 = nullptr;
   a.slot_expert = slot_expert; a.slot_scale = slot_scale; a.n_total = n_experts * N; a.slot_xdiv = slot_xdiv;
-  a.n_slots = n_slots;
+  a.n_slots = n_slots; a.slot_cat = 0;
+  return dispatch(a, qtype, stream);
+}
+
+// The second routed product of a decode step with the sum over a token's experts and the residual add inside the launch:
+//   out[t, :] = residual[t, :] + sum_j x[t * top_k + j, :] . dequant(W[slot_expert[t * top_k + j]])^T
+// x [tokens * top_k, K] fp16 contiguous rows (already scaled by the routing weights; zero rows for negative ids), w the
+// experts' [N, K] matrices stacked by rows as above.  K % 128 == 0, top_k <= 8, one workgroup per 16 output columns and
+// token walks the top_k weight tile rows back to back (a product over the concatenated reduction axis).  out may alias
+// residual.
+extern "C" int bigdl_gemv_lowbit_moe_sum(const void* x, const void* w, void* out, const void* residual, const int* slot_expert,
+                                         int tokens, int top_k, int n_experts, int N, int K, int ldo, int qtype, int out_type,
+                                         hipStream_t stream) {
+  qtype = t16_kernel_qtype(qtype);
+  if (tokens <= 0 || tokens > 65535 || top_k <= 0 || top_k > 8 || N <= 0 || K <= 0 || (K & 127) || (N & 15) ||
+      ((uintptr_t)x & 15) || ((uintptr_t)w & 15) || n_experts <= 0 || slot_expert == nullptr)
+    return -1;
+  if (out_type < 0 || out_type > 2) return -3;
+  if ((size_t)(top_k * K + XTAIL + XPAD) * 2 > GEMV_XLDS_LIMIT_FEW_ROWS) return -7;
+  GemvArgs a;
+  a.x = (const _Float16*)x; a.w = w; a.w2 = nullptr; a.out = out; a.bias = nullptr; a.bias2 = nullptr;
+  a.residual = residual; a.gamma = nullptr; a.eps = 0.0f; a.gamma_offset = 0.0f;
+  a.M = 1; a.N = N; a.K = top_k * K; a.ldx = top_k * K; a.ldo = ldo; a.act = 0; a.out_type = out_type;
+  a.att_ws = nullptr; a.att_splits = 0; a.att_D = 0; a.att_G = 0; a.att_Hkv = 0; a.att_qlen = 1; a.att_rows_alloc = 0;
+  a.ln_c1 = nullptr; a.ln_c2 = nullptr; a.ln2_c1 = nullptr; a.ln2_c2 = nullptr;
+  a.slot_expert = slot_expert; a.slot_scale = nullptr; a.n_total = n_experts * N; a.slot_xdiv = 1;
+  a.n_slots = tokens; a.slot_cat = top_k;
   return dispatch(a, qtype, stream);
 }

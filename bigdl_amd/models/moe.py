@@ -63,6 +63,9 @@ def grouped_moe_ffn(x, ids, weights, gate, up, down, qtype, n_experts, inter, hi
     return out
 
 
+_MOE_SUM = os.environ.get("BIGDL_MOE_SUM", "0") == "1"
+
+
 class MoEWeights:
     def __init__(self, router, gate, up, down, qtype, num_experts, top_k, hidden, inter, act="silu", normalize=True,
                  shared=None, shared_router=None, expert_range=None, group=None):
@@ -236,6 +239,17 @@ class MoEWeights:
             ids, w = self.route(x)
         m, k = x.shape[0], self.top_k
         if self.fused:
+            if _MOE_SUM and self.shared is None and self.expert_range is None and m <= 16 and h.dtype == torch.float16 \
+                    and hip.gemv_lowbit_moe_sum_ok(k, self.inter) and self.hidden % 16 == 0:
+                # routing weights applied to act(g) * u, then the k down products of a token as one product over the
+                # concatenated reduction axis with the residual add in its epilogue: two launches, no combine.
+                # BIGDL_MOE_SUM=1 only: on Mixtral-8x7B (one MI355X, batch 1) 2.60 ms per token against 2.51 with the
+                # separate combine launch: 256 workgroups that walk two experts each stream slower than 512 that walk
+                # one, by more than the 4.6 us launch they save.
+                a = hip.gemv_lowbit_moe(x, self.gate, self.qtype, self.n_local, self.inter, self.hidden, ids.view(-1),
+                                        w2=self.up, slot_xdiv=k, act=self.act, slot_scale=w.view(-1))
+                return hip.gemv_lowbit_moe_sum(a, self.down, self.qtype, self.n_local, self.hidden, self.inter,
+                                               ids.view(-1), k, residual=h, out=h)
             a = hip.gemv_lowbit_moe(x, self.gate, self.qtype, self.n_local, self.inter, self.hidden, ids.view(-1),
                                     w2=self.up, slot_xdiv=k, act=self.act)
             y = hip.gemv_lowbit_moe(a, self.down, self.qtype, self.n_local, self.hidden, self.inter, ids.view(-1),

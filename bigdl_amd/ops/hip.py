@@ -65,6 +65,7 @@ def lib():
         L.bigdl_dequant_t16.argtypes = [vp, vp, ci, ci, i64, ci, ci, ci, ci, vp]
         L.bigdl_dequant_rows.argtypes = [vp, vp, vp, i64, i64, ci, ci, i64, ci, vp]
         L.bigdl_gemv_lowbit_moe.argtypes = [vp, vp, vp, vp, vp, vp, vp, cf, cf, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp]
+        L.bigdl_gemv_lowbit_moe_sum.argtypes = [vp] * 5 + [ci] * 8 + [vp]
         L.bigdl_gemm_lowbit.argtypes = [vp, vp, vp, vp, vp, vp, i64, ci, ci, ci, ci, ci, ci, ci, ci, vp]
         L.bigdl_gemm_lowbit_splitk.argtypes = [ci, ci, ci]
         L.bigdl_gemm_prompt.argtypes = [vp, vp, vp, vp, vp, vp, i64, ci, ci, ci, ci, ci, ci, ci, ci, vp]
@@ -248,6 +249,41 @@ def gemv_lowbit_moe(x, w, qtype, n_experts, out_features, in_features, slot_expe
                                      in_features, x.stride(0), out.stride(0), qtype, ACT[act], _out_type(out.dtype),
                                      _stream())
     _check(rc, "gemv_lowbit_moe")
+    return out
+
+
+def gemv_lowbit_moe_sum_ok(top_k, in_features) -> bool:
+    """whether :func:`gemv_lowbit_moe_sum` takes a product of this shape (x of one token has to fit the LDS staging)"""
+    return top_k <= 8 and in_features % 128 == 0 and (top_k * in_features + 136) * 2 <= 100 * 1024
+
+
+def gemv_lowbit_moe_sum(x, w, qtype, n_experts, out_features, in_features, slot_expert, top_k, *, residual=None, out=None):
+    """Routed products summed per token inside the launch: ``out[t] = residual[t] + sum_j x[t * top_k + j] @
+    dequant(W[slot_expert[t * top_k + j]])^T``.  x [tokens * top_k, in_features] fp16 contiguous, already scaled by the
+    routing weights (zero rows for negative expert ids); ``out`` may be ``residual`` itself."""
+    _need_cuda(x, w, slot_expert, residual, out)
+    if x.dim() != 2 or x.dtype != torch.float16 or not x.is_contiguous() or x.shape[1] != in_features:
+        raise ValueError("x must be a contiguous fp16 tensor [tokens * top_k, in_features]")
+    if qtype not in Q.T16_QTYPES:
+        raise ValueError(f"qtype {qtype} has no fused GEMV kernel")
+    if out_features % 16 or not gemv_lowbit_moe_sum_ok(top_k, in_features):
+        raise ValueError("gemv_lowbit_moe_sum: out_features % 16, in_features % 128, top_k <= 8, top_k * in_features <= 51064")
+    from .host import device_nbytes
+    if w.numel() * w.element_size() != device_nbytes(qtype, out_features * n_experts, in_features):
+        raise ValueError("expert weight buffer size does not match n_experts x [out_features, in_features]")
+    if slot_expert.dtype != torch.int32 or not slot_expert.is_contiguous() or slot_expert.numel() != x.shape[0] \
+            or x.shape[0] % top_k:
+        raise ValueError("slot_expert must be contiguous int32 [tokens * top_k]")
+    t = x.shape[0] // top_k
+    if out is None:
+        out = torch.empty((t, out_features), dtype=torch.float16 if residual is None else residual.dtype, device=x.device)
+    if out.shape != (t, out_features) or out.stride(1) != 1:
+        raise ValueError("bad out tensor")
+    if residual is not None and (residual.shape != out.shape or residual.dtype != out.dtype or residual.stride() != out.stride()):
+        raise ValueError("residual must match out")
+    rc = lib().bigdl_gemv_lowbit_moe_sum(_ptr(x), _ptr(w), _ptr(out), _ptr(residual), _ptr(slot_expert), t, top_k, n_experts,
+                                         out_features, in_features, out.stride(0), qtype, _out_type(out.dtype), _stream())
+    _check(rc, "gemv_lowbit_moe_sum")
     return out
 
 

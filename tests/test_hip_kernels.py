@@ -450,6 +450,36 @@ def test_moe_norm_route_matches_separate_ops(hip, cfg):
     assert torch.equal(w2, w)
 
 
+@pytest.mark.parametrize("name", ["sym_int4", "asym_int4", "nf4", "sym_int8", "fp6", "fp8_e5m2"])
+@pytest.mark.parametrize("shape", [(6, 256, 96, 3, 2), (8, 384, 160, 1, 3), (10, 128, 64, 4, 8), (8, 14336, 64, 1, 2)])
+def test_routed_expert_sum(hip, name, shape):
+    """a token's routed down products summed inside one launch (with the residual) against fp32 products over the
+    dequantized expert matrices"""
+    torch.manual_seed(23)
+    qt = Q.ggml_tensor_qtype[name]
+    e, i, h, t, k = shape
+    down = torch.randn(e * h, i) * 0.05
+    dd, dr = _quant_dev(down, qt)
+    a = (torch.randn(t * k, i) * 0.5).half()
+    ids = torch.stack([torch.randperm(e)[:k] for _ in range(t)]).int()
+    if t > 1:
+        ids[1, 0] = -1                      # expert of another rank: its row of x is zero by contract
+        a[k] = 0
+    res = torch.randn(t, h).half()
+    ref = res.float().clone()
+    for s_ in range(t * k):
+        ex = int(ids.view(-1)[s_])
+        if ex >= 0:
+            ref[s_ // k] += dr[ex * h:(ex + 1) * h] @ a[s_].float()
+    out = hip.gemv_lowbit_moe_sum(a.cuda(), dd, qt, e, h, i, ids.view(-1).cuda(), k, residual=res.cuda())
+    torch.testing.assert_close(out.float().cpu(), ref, rtol=5e-3, atol=2e-2 if i > 1000 else 5e-3)
+    inplace = res.cuda()
+    assert hip.gemv_lowbit_moe_sum(a.cuda(), dd, qt, e, h, i, ids.view(-1).cuda(), k, residual=inplace, out=inplace) is inplace
+    assert torch.equal(inplace, out)
+    plain = hip.gemv_lowbit_moe_sum(a.cuda(), dd, qt, e, h, i, ids.view(-1).cuda(), k)
+    torch.testing.assert_close(plain.float().cpu(), ref - res.float(), rtol=5e-3, atol=2e-2 if i > 1000 else 5e-3)
+
+
 @pytest.mark.parametrize("name", ["sym_int4", "asym_int4", "sym_int8", "fp6"])
 def test_routed_expert_gemv(hip, name):
     torch.manual_seed(21)
