@@ -8,8 +8,9 @@
 //    launch per decode step: one workgroup per token keeps the normed row in LDS, every wavefront takes experts
 //    wave, wave + 4, ... (all 16-byte requests of a router row issued before the first product), wavefront 0 picks.
 //    Replaces three launches (norm, library GEMM for 8 .. 64 logits, top-k) whose fixed cost is most of their time.
-// They replace the reference's xe_addons moe_softmax_topk / moe_group_topk routing + the python-side
-// index_add loops (python/llm/src/ipex_llm/transformers/models/common.py:339-354, mixtral.py:60-130).
+// They replace the reference's python-side routing (softmax + torch.topk), its host-side bucketing
+// (xe_linear.get_moe_indexes) and index_add loops: python/llm/src/ipex_llm/transformers/models/qwen2_moe.py:376-452,
+// models/phixtral.py:44-104.
 #include "common.h"
 
 namespace bigdl {
@@ -69,9 +70,115 @@ __device__ __forceinline__ void route_pick(float (&v)[ROUTE_MAX_PER_LANE], float
   }
 }
 
+// Group-limited / biased selection (DeepSeek-V2 and V3 routers) by one wavefront: p = softmax or sigmoid of the logits,
+// choice = p + bias; with n_group > 1 the groups are ranked by their best (or the sum of their two best) choice values,
+// experts outside the topk_group best groups get choice 0 (not -inf: that is what those routers do), the top_k best
+// choices are picked and weighted by their p (renormalized with the routers' 1e-20 guard when asked).  ``ch`` is LDS
+// scratch of E + n_group floats; lane l holds experts i * 64 + l.
+__device__ __forceinline__ void route_pick_grouped(float (&v)[ROUTE_MAX_PER_LANE], float mx, int t, int E, int top_k,
+                                                   int normalize, int lo, int hi, int sigmoid_scores, const float* bias,
+                                                   int n_group, int topk_group, int group_top2, float* ch, int* ids,
+                                                   float* weights) {
+  const int lane = threadIdx.x & 63;
+  const float NEG = -3.0e38f;
+  float pr[ROUTE_MAX_PER_LANE];
+  mx = wave_max(mx);
+  float sum = 0.0f;
+#pragma unroll
+  for (int i = 0; i < ROUTE_MAX_PER_LANE; ++i) {
+    const int e = i * 64 + lane;
+    pr[i] = 0.0f;
+    if (e < E) {
+      pr[i] = sigmoid_scores ? 1.0f / (1.0f + __expf(-v[i])) : __expf(v[i] - mx);
+      sum += pr[i];
+    }
+  }
+  sum = wave_sum(sum);
+  const float inv = sigmoid_scores ? 1.0f : 1.0f / sum;
+#pragma unroll
+  for (int i = 0; i < ROUTE_MAX_PER_LANE; ++i) {
+    const int e = i * 64 + lane;
+    pr[i] *= inv;
+    v[i] = e < E ? pr[i] + (bias != nullptr ? bias[e] : 0.0f) : NEG;
+  }
+  if (n_group > 1) {
+    const int gs = E / n_group;
+#pragma unroll
+    for (int i = 0; i < ROUTE_MAX_PER_LANE; ++i) {
+      const int e = i * 64 + lane;
+      if (e < E) ch[e] = v[i];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float score = NEG;                       // lane g < n_group: score of group g
+    if (lane < n_group) {
+      float b1 = NEG, b2 = NEG;
+      for (int j = 0; j < gs; ++j) {
+        const float x = ch[lane * gs + j];
+        if (x > b1) { b2 = b1; b1 = x; } else if (x > b2) { b2 = x; }
+      }
+      score = group_top2 ? b1 + (gs > 1 ? b2 : 0.0f) : b1;
+    }
+    bool keep = false;
+    for (int k = 0; k < topk_group; ++k) {
+      float best = score;
+      int best_g = lane < n_group ? lane : 0x7fffffff;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const float ob = __shfl_xor(best, off);
+        const int og = __shfl_xor(best_g, off);
+        if (ob > best || (ob == best && og < best_g)) { best = ob; best_g = og; }
+      }
+      if (lane == best_g) { keep = true; score = NEG; }
+    }
+    if (lane < n_group) ch[E + lane] = keep ? 1.0f : 0.0f;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int i = 0; i < ROUTE_MAX_PER_LANE; ++i) {
+      const int e = i * 64 + lane;
+      if (e < E && ch[E + e / gs] == 0.0f) v[i] = 0.0f;
+    }
+  }
+  float picked = 0.0f, my_w = 0.0f;
+  int my_id = -1;
+  for (int k = 0; k < top_k; ++k) {
+    float best = NEG, best_p = 0.0f;
+    int best_e = 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < ROUTE_MAX_PER_LANE; ++i) {
+      const int e = i * 64 + lane;
+      if (e < E && v[i] > best) { best = v[i]; best_e = e; best_p = pr[i]; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ob = __shfl_xor(best, off), op = __shfl_xor(best_p, off);
+      const int oe = __shfl_xor(best_e, off);
+      if (ob > best || (ob == best && oe < best_e)) { best = ob; best_e = oe; best_p = op; }
+    }
+#pragma unroll
+    for (int i = 0; i < ROUTE_MAX_PER_LANE; ++i)
+      if (i * 64 + lane == best_e) v[i] = NEG;   // taken
+    picked += best_p;
+    if (lane == k) { my_w = best_p; my_id = best_e; }
+  }
+  if (lane < top_k) {
+    float w = my_w;
+    if (normalize) w /= picked + 1e-20f;
+    int id = my_id;
+    if (hi > lo) id = (id >= lo && id < hi) ? id - lo : -1;
+    ids[t * top_k + lane] = id;
+    weights[t * top_k + lane] = w;
+  }
+}
+
 template <bool F32>
 __global__ __launch_bounds__(256) void moe_route_kernel(const void* logits, int* ids, float* weights, int T, int E, int top_k,
-                                                        int normalize, int lo, int hi, int64_t ld, int sigmoid_scores) {
+                                                        int normalize, int lo, int hi, int64_t ld, int sigmoid_scores,
+                                                        const float* bias, int n_group, int topk_group, int group_top2) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];      // grouped selection: [4][E + n_group] floats
   const int lane = threadIdx.x & 63;
   const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (t >= T) return;
@@ -85,74 +192,87 @@ __global__ __launch_bounds__(256) void moe_route_kernel(const void* logits, int*
     v[i] = x;
     mx = fmaxf(mx, x);
   }
-  route_pick(v, mx, t, E, top_k, normalize, lo, hi, sigmoid_scores, ids, weights);
+  if (bias != nullptr || n_group > 1)
+    route_pick_grouped(v, mx, t, E, top_k, normalize, lo, hi, sigmoid_scores, bias, n_group, topk_group, group_top2,
+                       (float*)smem + (threadIdx.x >> 6) * (E + n_group), ids, weights);
+  else
+    route_pick(v, mx, t, E, top_k, normalize, lo, hi, sigmoid_scores, ids, weights);
 }
 
 // h [T, ldh] fp16 -> x = rmsnorm(h) * (gamma + offset) [T, H] fp16, router logits of x (rounded to fp16 like the dense
-// product they replace) -> ids / weights.  H % 8 == 0, H <= 8192; E <= 64 * ROUTE_MAX_PER_LANE.
-__global__ __launch_bounds__(256) void moe_norm_route_kernel(const _Float16* h, const _Float16* gamma, const _Float16* router,
-                                                             _Float16* x_out, int* ids, float* weights, int H, int64_t ldh,
-                                                             float eps, float offset, int E, int top_k, int normalize, int lo,
-                                                             int hi, int sigmoid_scores) {
+// product they replace) -> ids / weights.  One workgroup of 16 wavefronts per token; H % 8 == 0, H <= 8192 (one 16-byte
+// chunk per thread); E <= 64 * ROUTE_MAX_PER_LANE.  LPE = 16-byte requests per lane and router row (H <= 512 * LPE): a
+// wavefront takes 16 / LPE experts at a time with all their requests in flight together, so a 64-expert, 2048-wide
+// router (DeepSeek-V2-Lite, Qwen-MoE) and an 8-expert, 4096-wide one (Mixtral) are both one memory round trip.
+template <int LPE>
+__global__ __launch_bounds__(1024) void moe_norm_route_kernel(const _Float16* h, const _Float16* gamma, const _Float16* router,
+                                                              _Float16* x_out, int* ids, float* weights, int H, int64_t ldh,
+                                                              float eps, float offset, int E, int top_k, int normalize, int lo,
+                                                              int hi, int sigmoid_scores, const float* bias, int n_group,
+                                                              int topk_group, int group_top2) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   _Float16* xs = (_Float16*)smem;                       // [H]
   float* lg = (float*)(xs + H);                         // [E]
-  float* sh = lg + ((E + 3) & ~3);                      // [4]
+  float* sh = lg + ((E + 3) & ~3);                      // [16]
+  float* ch = sh + 16;                                  // [E + n_group] (grouped selection only)
+  constexpr int EB = 16 / LPE;
   const int t = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float v[4][8];
-  half8 gm[4];
+  const int nch = H >> 3;
+  // the first batch of router rows is requested before anything else: it does not depend on the norm
+  half8 w[EB][LPE];
+  auto request = [&](int e0) {
+#pragma unroll
+    for (int b = 0; b < EB; ++b)
+#pragma unroll
+      for (int u = 0; u < LPE; ++u) {
+        const int e = min(e0 + b, E - 1), chk = min(u * 64 + lane, nch - 1);     // clamped: unconditional loads
+        w[b][u] = *(const half8*)(router + (int64_t)e * H + chk * 8);
+      }
+  };
+  request(wave * EB);
+  float v[8];
+  half8 gm;
   float ss = 0.0f;
+  const int c = threadIdx.x * 8;
+  if (c < H) {
+    const half8 hv = *(const half8*)(h + (int64_t)t * ldh + c);
+    gm = *(const half8*)(gamma + c);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = (threadIdx.x + i * 256) * 8;
-    if (c < H) {
-      const half8 hv = *(const half8*)(h + (int64_t)t * ldh + c);
-      gm[i] = *(const half8*)(gamma + c);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { v[i][j] = (float)hv[j]; ss += v[i][j] * v[i][j]; }
-    }
+    for (int j = 0; j < 8; ++j) { v[j] = (float)hv[j]; ss += v[j] * v[j]; }
   }
   ss = wave_sum(ss);
   if (lane == 0) sh[wave] = ss;
   __syncthreads();
-  const float rs = rsqrtf((sh[0] + sh[1] + sh[2] + sh[3]) / (float)H + eps);
+  float tot = 0.0f;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = (threadIdx.x + i * 256) * 8;
-    if (c < H) {
-      half8 o;
+  for (int q = 0; q < 16; ++q) tot += sh[q];
+  const float rs = rsqrtf(tot / (float)H + eps);
+  if (c < H) {
+    half8 o;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = (_Float16)(v[i][j] * rs * ((float)gm[i][j] + offset));
-      *(half8*)(xs + c) = o;
-      *(half8*)(x_out + (int64_t)t * H + c) = o;
-    }
+    for (int j = 0; j < 8; ++j) o[j] = (_Float16)(v[j] * rs * ((float)gm[j] + offset));
+    *(half8*)(xs + c) = o;
+    *(half8*)(x_out + (int64_t)t * H + c) = o;
   }
   __syncthreads();
-  // router rows: lane l of the owning wavefront takes the 16-byte chunks l, l + 64, ... of the row
-  const int nch = H >> 3;
-  for (int e = wave; e < E; e += 4) {
-    const _Float16* row = router + (int64_t)e * H;
-    float acc = 0.0f;
-    for (int c0 = 0; c0 < nch; c0 += 64 * 8) {
-      half8 w[8];
+  for (int e0 = wave * EB; e0 < E; e0 += 16 * EB) {
+    if (e0 != wave * EB) request(e0);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int ch = c0 + u * 64 + lane;
-        if (ch < nch) w[u] = *(const half8*)(row + ch * 8);
-      }
+    for (int b = 0; b < EB; ++b) {
+      float acc = 0.0f;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int ch = c0 + u * 64 + lane;
-        if (ch < nch) {
-          const half8 xv = *(const half8*)(xs + ch * 8);
+      for (int u = 0; u < LPE; ++u) {
+        const int chk = u * 64 + lane;
+        if (chk < nch) {
+          const half8 xv = *(const half8*)(xs + chk * 8);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) acc += (float)w[u][j] * (float)xv[j];
+          for (int j = 0; j < 8; ++j) acc += (float)w[b][u][j] * (float)xv[j];
         }
       }
+      acc = wave_sum(acc);
+      if (lane == 0 && e0 + b < E) lg[e0 + b] = (float)(_Float16)acc;
     }
-    acc = wave_sum(acc);
-    if (lane == 0) lg[e] = (float)(_Float16)acc;
   }
   __syncthreads();
   if (wave != 0) return;
@@ -164,7 +284,11 @@ __global__ __launch_bounds__(256) void moe_norm_route_kernel(const _Float16* h, 
     lv[i] = e < E ? lg[e] : -3.0e38f;
     mx = fmaxf(mx, lv[i]);
   }
-  route_pick(lv, mx, t, E, top_k, normalize, lo, hi, sigmoid_scores, ids, weights);
+  if (bias != nullptr || n_group > 1)
+    route_pick_grouped(lv, mx, t, E, top_k, normalize, lo, hi, sigmoid_scores, bias, n_group, topk_group, group_top2, ch, ids,
+                       weights);
+  else
+    route_pick(lv, mx, t, E, top_k, normalize, lo, hi, sigmoid_scores, ids, weights);
 }
 
 __global__ __launch_bounds__(256) void moe_combine_kernel(const _Float16* y, const _Float16* shared, const _Float16* shared_gate,
@@ -202,13 +326,29 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(const _Float16* y, con
 using namespace bigdl;
 
 // logits [T, E] (fp16 or fp32, row stride ld) -> ids int32 [T, top_k], weights fp32 [T, top_k]
+static int moe_route_launch(const void* logits, int* ids, float* weights, int T, int E, int top_k, int normalize, int lo,
+                            int hi, int64_t ld, int is_f32, int sigmoid_scores, const float* bias, int n_group,
+                            int topk_group, int group_top2, hipStream_t st) {
+  if (T <= 0 || E <= 0 || E > 64 * ROUTE_MAX_PER_LANE || top_k <= 0 || top_k > 64 || top_k > E) return -1;
+  if (n_group < 1 || n_group > 64 || E % n_group || topk_group < 1 || topk_group > n_group) return -1;
+  const dim3 grid((T + 3) / 4), block(256);
+  const size_t lds = (bias != nullptr || n_group > 1) ? (size_t)4 * (E + n_group) * 4 : 0;
+  if (is_f32) hipLaunchKernelGGL((moe_route_kernel<true>), grid, block, lds, st, logits, ids, weights, T, E, top_k, normalize, lo, hi, ld, sigmoid_scores, bias, n_group, topk_group, group_top2);
+  else hipLaunchKernelGGL((moe_route_kernel<false>), grid, block, lds, st, logits, ids, weights, T, E, top_k, normalize, lo, hi, ld, sigmoid_scores, bias, n_group, topk_group, group_top2);
+  return HIP_CHECK_LAUNCH();
+}
+
 extern "C" int bigdl_moe_route(const void* logits, int* ids, float* weights, int T, int E, int top_k, int normalize, int lo,
                                int hi, int64_t ld, int is_f32, int sigmoid_scores, hipStream_t st) {
-  if (T <= 0 || E <= 0 || E > 64 * ROUTE_MAX_PER_LANE || top_k <= 0 || top_k > 64 || top_k > E) return -1;
-  const dim3 grid((T + 3) / 4), block(256);
-  if (is_f32) hipLaunchKernelGGL((moe_route_kernel<true>), grid, block, 0, st, logits, ids, weights, T, E, top_k, normalize, lo, hi, ld, sigmoid_scores);
-  else hipLaunchKernelGGL((moe_route_kernel<false>), grid, block, 0, st, logits, ids, weights, T, E, top_k, normalize, lo, hi, ld, sigmoid_scores);
-  return HIP_CHECK_LAUNCH();
+  return moe_route_launch(logits, ids, weights, T, E, top_k, normalize, lo, hi, ld, is_f32, sigmoid_scores, nullptr, 1, 1, 0, st);
+}
+
+// ... with the group-limited / biased selection of route_pick_grouped (bias fp32 [E] or null)
+extern "C" int bigdl_moe_route_grouped(const void* logits, int* ids, float* weights, int T, int E, int top_k, int normalize,
+                                       int lo, int hi, int64_t ld, int is_f32, int sigmoid_scores, const float* bias,
+                                       int n_group, int topk_group, int group_top2, hipStream_t st) {
+  return moe_route_launch(logits, ids, weights, T, E, top_k, normalize, lo, hi, ld, is_f32, sigmoid_scores, bias, n_group,
+                          topk_group, group_top2, st);
 }
 
 // all fp16, contiguous rows of H (H % 8 == 0); shared / shared_gate / residual may be null; out may alias residual
@@ -221,16 +361,26 @@ extern "C" int bigdl_moe_combine(const void* y, const void* shared, const void* 
   return HIP_CHECK_LAUNCH();
 }
 
-// h [T, ldh] fp16, gamma [H] fp16, router [E, H] fp16 (contiguous rows) -> x [T, H] fp16, ids int32 / weights fp32 [T, top_k]
+// h [T, ldh] fp16, gamma [H] fp16, router [E, H] fp16 (contiguous rows) -> x [T, H] fp16, ids int32 / weights fp32 [T, top_k].
+// bias (fp32 [E], may be null), n_group / topk_group / group_top2: the group-limited selection of route_pick_grouped.
 extern "C" int bigdl_moe_norm_route(const void* h, const void* gamma, const void* router, void* x, int* ids, float* weights,
                                     int T, int H, int64_t ldh, float eps, float offset, int E, int top_k, int normalize,
-                                    int lo, int hi, int sigmoid_scores, hipStream_t st) {
+                                    int lo, int hi, int sigmoid_scores, const float* bias, int n_group, int topk_group,
+                                    int group_top2, hipStream_t st) {
   if (T <= 0 || T > 65535 || H <= 0 || (H & 7) || H > 8192 || ldh < H || (ldh & 7) || E <= 0 || E > 64 * ROUTE_MAX_PER_LANE ||
       top_k <= 0 || top_k > 64 || top_k > E)
     return -1;
-  const size_t lds = (size_t)H * 2 + (size_t)((E + 3) & ~3) * 4 + 16;
-  hipLaunchKernelGGL(moe_norm_route_kernel, dim3(T), dim3(256), lds, st, (const _Float16*)h, (const _Float16*)gamma,
-                     (const _Float16*)router, (_Float16*)x, ids, weights, H, ldh, eps, offset, E, top_k, normalize, lo, hi,
-                     sigmoid_scores);
+  if (n_group < 1 || n_group > 64 || E % n_group || topk_group < 1 || topk_group > n_group) return -1;
+  const size_t lds = (size_t)H * 2 + (size_t)((E + 3) & ~3) * 4 + 64 + (size_t)(E + n_group) * 4;
+#define BIGDL_NR_LAUNCH(LPE)                                                                                                 \
+  hipLaunchKernelGGL((moe_norm_route_kernel<LPE>), dim3(T), dim3(1024), lds, st, (const _Float16*)h, (const _Float16*)gamma, \
+                     (const _Float16*)router, (_Float16*)x, ids, weights, H, ldh, eps, offset, E, top_k, normalize, lo, hi,  \
+                     sigmoid_scores, bias, n_group, topk_group, group_top2)
+  if (H <= 512) BIGDL_NR_LAUNCH(1);
+  else if (H <= 1024) BIGDL_NR_LAUNCH(2);
+  else if (H <= 2048) BIGDL_NR_LAUNCH(4);
+  else if (H <= 4096) BIGDL_NR_LAUNCH(8);
+  else BIGDL_NR_LAUNCH(16);
+#undef BIGDL_NR_LAUNCH
   return HIP_CHECK_LAUNCH();
 }

@@ -280,7 +280,8 @@ def _probe_deepseek_v2(cfg):
 
 
 def convert_deepseek_v2(cfg: dict, sd: StateDict):
-    """DeepSeek-V2 / V2-Lite (reference models/deepseek.py ``deepseek_attention_forward`` / ``deepseek_moe_forward``):
+    """DeepSeek-V2 / V2-Lite (the reference converts the linears only and runs the model's own remote-code forward,
+    example/GPU/HuggingFace/LLM/deepseek):
     latent attention with interleaved rotary pairs, dense MLP in the first ``first_k_dense_replace`` layers, then
     routed experts (softmax scores, plain or group-limited top-k without renormalization, ``routed_scaling_factor`` folded into the experts'
     down projections) plus always-on shared experts.  Expert weights are taken stacked (``experts.gate_up_proj``) or
@@ -326,8 +327,7 @@ def _probe_deepseek_v3(cfg):
 
 
 def convert_deepseek_v3(cfg: dict, sd: StateDict):
-    """DeepSeek-V3 / R1 (the reference runs it through its DeepSeek-V2 forwards plus ``moe_group_topk``, models/deepseek.py;
-    example GPU/CPU-GPU-Hybrid-DeepSeek-R1-Inference): the V2 layout with sigmoid router scores, a learned selection bias
+    """DeepSeek-V3 / R1 (reference: example/GPU/CPU-GPU-Hybrid-DeepSeek-R1-Inference): the V2 layout with sigmoid router scores, a learned selection bias
     (``e_score_correction_bias``), groups ranked by the sum of their two best experts, renormalized weights."""
     dc, out = convert_deepseek_v2(cfg, sd)
     v3 = _probe_deepseek_v3(cfg)

@@ -18,8 +18,9 @@ Expert parallelism: ``expert_range=(lo, hi)`` keeps a contiguous slice of the ex
   fixed-shape form of the same exchange (all-gather of the step's [batch, hidden] rows, local experts over all of them,
   reduce-scatter back), because a hipGraph cannot hold data-dependent split sizes.
 
-Reference behaviour: python/llm/src/ipex_llm/transformers/models/mixtral.py:60-130 (``mixtral_moeblock_forward``),
-models/qwen2_moe.py:104-149, models/common.py:339-354 (``moe_group_topk`` / ``moe_softmax_topk``).
+Reference behaviour: python/llm/src/ipex_llm/transformers/models/qwen2_moe.py:376-452 (``qwen2moe_moeblock_forward``:
+per-expert loops, ``xe_linear.get_moe_indexes`` on the host), models/phixtral.py:44-104; Mixtral and DeepSeek have no
+forward of their own there (stock HuggingFace expert loops over ``LowBitLinear`` modules).
 """
 from __future__ import annotations
 
@@ -64,6 +65,7 @@ def grouped_moe_ffn(x, ids, weights, gate, up, down, qtype, n_experts, inter, hi
 
 
 _MOE_SUM = os.environ.get("BIGDL_MOE_SUM", "0") == "1"
+_FUSED_ROUTE = os.environ.get("BIGDL_MOE_FUSED_ROUTE", "1") != "0"     # 0: norm, router product and top-k as separate launches
 
 
 class MoEWeights:
@@ -147,9 +149,18 @@ class MoEWeights:
         and local ones are rebased to this rank's slice."""
         logits = F.linear(x, self.router.to(x.dtype))
         rng = self.expert_range if local_only else None
+        if x.device.type == "cuda" and self.n_group <= 64 and self.num_experts % self.n_group == 0 \
+                and self.num_experts <= 1024 and (self.n_group > 1 or self.score == "sigmoid"):
+            from ..ops import hip
+            bias = self.route_bias
+            if bias is not None and (bias.dtype != torch.float32 or not bias.is_contiguous()):
+                bias = self.route_bias = bias.float().contiguous()
+            return hip.moe_route(logits, self.top_k, self.normalize, expert_range=rng, sigmoid_scores=self.score == "sigmoid",
+                                 route_bias=bias, n_group=self.n_group, topk_group=self.topk_group,
+                                 group_top2=self.group_score == "top2sum")
         if self.n_group > 1 or self.score == "sigmoid":
             # scores over all experts, experts outside the topk_group best groups drop out, weights are the scores of the
-            # chosen experts (reference models/deepseek.py ``moe_group_topk``); plain tensor ops, replayable inside the
+            # chosen experts (the DeepSeek-V2 / V3 models' own ``MoEGate``); plain tensor ops, replayable inside the
             # decode graph
             p = torch.sigmoid(logits.float()) if self.score == "sigmoid" else torch.softmax(logits.float(), -1)
             choice = p if self.route_bias is None else p + self.route_bias.float()
@@ -224,11 +235,17 @@ class MoEWeights:
         from ..ops import hip
         cfg = engine.cfg
         a2a = self.ep_mode == "a2a" and self.ep_world > 1
-        plain = not (self.n_group > 1 or self.score == "sigmoid")
-        if not a2a and plain and h.shape[0] <= 256 and hip.moe_norm_route_ok(h, gamma, self.router, self.num_experts):
-            # norm + router product + top-k in one launch (three otherwise, each mostly fixed cost at a few rows)
+        groups_ok = self.n_group <= 64 and self.num_experts % self.n_group == 0
+        if _FUSED_ROUTE and not a2a and groups_ok and h.shape[0] <= 256 and hip.moe_norm_route_ok(h, gamma, self.router, self.num_experts):
+            # norm + router product + (group-limited) top-k in one launch: three launches otherwise, a dozen with the
+            # DeepSeek routers' selection written as tensor ops, each mostly fixed cost at a few rows
+            bias = self.route_bias
+            if bias is not None and (bias.dtype != torch.float32 or not bias.is_contiguous()):
+                bias = self.route_bias = bias.float().contiguous()
             x, ids, w = hip.moe_norm_route(h, gamma, cfg.rms_eps, self.router, self.top_k, self.normalize,
-                                           expert_range=self.expert_range, offset=cfg.norm_offset)
+                                           expert_range=self.expert_range, offset=cfg.norm_offset,
+                                           sigmoid_scores=self.score == "sigmoid", route_bias=bias, n_group=self.n_group,
+                                           topk_group=self.topk_group, group_top2=self.group_score == "top2sum")
         else:
             x = hip.rms_norm(h, gamma, cfg.rms_eps, offset=cfg.norm_offset)
             if a2a:

@@ -81,8 +81,9 @@ def lib():
         L.bigdl_gemm_lowbit_grouped.argtypes = [vp] * 8 + [ci] * 12 + [vp]
         L.bigdl_moe_block_table.argtypes = [vp, ci, ci, ci, vp, vp, vp, vp]
         L.bigdl_moe_route.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, i64, ci, ci, vp]
+        L.bigdl_moe_route_grouped.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, i64, ci, ci, vp, ci, ci, ci, vp]
         L.bigdl_moe_combine.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, i64, vp]
-        L.bigdl_moe_norm_route.argtypes = [vp] * 6 + [ci, ci, i64, cf, cf] + [ci] * 6 + [vp]
+        L.bigdl_moe_norm_route.argtypes = [vp] * 6 + [ci, ci, i64, cf, cf] + [ci] * 6 + [vp, ci, ci, ci, vp]
         L.bigdl_rwkv_time_shift.argtypes = [vp, vp, vp, vp, i64, ci, ci, ci, vp]
         L.bigdl_rwkv4_wkv.argtypes = [vp] * 8 + [ci] * 5 + [vp]
         L.bigdl_rwkv5_wkv.argtypes = [vp] * 7 + [ci] * 4 + [vp]
@@ -530,10 +531,13 @@ def gemm_lowbit_grouped(x, w, qtype, n_experts, out_features, in_features, table
     return out
 
 
-def moe_route(logits, top_k, normalize=True, expert_range=None, sigmoid_scores=False, ids=None, weights=None):
+def moe_route(logits, top_k, normalize=True, expert_range=None, sigmoid_scores=False, ids=None, weights=None,
+              route_bias=None, n_group=1, topk_group=1, group_top2=False):
     """Router logits [T, E] -> (expert ids int32 [T, top_k], weights fp32 [T, top_k]): softmax, top-k, optional
-    renormalisation.  ``expert_range=(lo, hi)`` keeps local experts only (others -1, kept ids rebased to lo)."""
-    _need_cuda(logits, ids, weights)
+    renormalisation.  ``expert_range=(lo, hi)`` keeps local experts only (others -1, kept ids rebased to lo).
+    ``route_bias`` / ``n_group`` / ``topk_group`` / ``group_top2``: the group-limited selection described at
+    :func:`moe_norm_route`."""
+    _need_cuda(logits, ids, weights, route_bias)
     if logits.dim() != 2 or logits.stride(1) != 1 or logits.dtype not in (torch.float16, torch.float32):
         raise ValueError("logits must be 2-D fp16/fp32 with contiguous rows")
     t, e = logits.shape
@@ -545,6 +549,17 @@ def moe_route(logits, top_k, normalize=True, expert_range=None, sigmoid_scores=F
             or weights.dtype != torch.float32 or not ids.is_contiguous() or not weights.is_contiguous():
         raise ValueError("bad ids / weights buffers")
     lo, hi = expert_range if expert_range is not None else (0, 0)
+    if route_bias is not None or n_group > 1:
+        if route_bias is not None and (route_bias.dtype != torch.float32 or route_bias.numel() != e
+                                       or not route_bias.is_contiguous()):
+            raise ValueError("route_bias must be contiguous fp32 [E]")
+        if n_group < 1 or n_group > 64 or e % n_group or not 1 <= topk_group <= n_group:
+            raise ValueError("bad expert groups")
+        rc = lib().bigdl_moe_route_grouped(_ptr(logits), _ptr(ids), _ptr(weights), t, e, top_k, int(bool(normalize)), lo, hi,
+                                           logits.stride(0), int(logits.dtype == torch.float32), int(bool(sigmoid_scores)),
+                                           _ptr(route_bias), n_group, topk_group, int(bool(group_top2)), _stream())
+        _check(rc, "moe_route_grouped")
+        return ids, weights
     rc = lib().bigdl_moe_route(_ptr(logits), _ptr(ids), _ptr(weights), t, e, top_k, int(bool(normalize)), lo, hi,
                                logits.stride(0), int(logits.dtype == torch.float32), int(bool(sigmoid_scores)), _stream())
     _check(rc, "moe_route")
@@ -557,17 +572,28 @@ def moe_norm_route_ok(h, gamma, router, n_experts) -> bool:
             and h.shape[1] % 8 == 0 and h.shape[1] <= 8192 and h.shape[0] <= 65535
             and gamma.dtype == torch.float16 and gamma.is_contiguous()
             and router.dtype == torch.float16 and router.is_contiguous() and tuple(router.shape) == (n_experts, h.shape[1])
-            and n_experts <= 1024)
+            and n_experts <= 1024 and n_experts * h.shape[1] <= 256 * 1024)     # one workgroup reads the whole router
 
 
-def moe_norm_route(h, gamma, eps, router, top_k, normalize=True, expert_range=None, offset=0.0, sigmoid_scores=False):
+def moe_norm_route(h, gamma, eps, router, top_k, normalize=True, expert_range=None, offset=0.0, sigmoid_scores=False,
+                   route_bias=None, n_group=1, topk_group=1, group_top2=False):
     """One launch for the head of a routed layer's decode step: ``x = rmsnorm(h) * (gamma + offset)`` (fp16 [T, H]),
     router logits ``x @ router.T`` (fp32 sums rounded to fp16, like the dense product) and the softmax / top-k of
-    :func:`moe_route` -> ``(x, ids int32 [T, top_k], weights fp32 [T, top_k])``."""
-    _need_cuda(h, gamma, router)
+    :func:`moe_route` -> ``(x, ids int32 [T, top_k], weights fp32 [T, top_k])``.
+
+    ``route_bias`` (fp32 [E]) / ``n_group`` / ``topk_group`` / ``group_top2`` select the way the DeepSeek-V2 / V3 routers
+    do: candidates are ``p + bias``, groups of ``E / n_group`` experts are ranked by their best candidate (or the sum of
+    their two best), candidates outside the ``topk_group`` best groups become 0, the weights are the picked experts'
+    ``p`` (divided by their sum + 1e-20 with ``normalize``)."""
+    _need_cuda(h, gamma, router, route_bias)
     e = router.shape[0]
+    if route_bias is not None and (route_bias.dtype != torch.float32 or route_bias.numel() != e or not route_bias.is_contiguous()):
+        raise ValueError("route_bias must be contiguous fp32 [E]")
+    if n_group < 1 or n_group > 64 or e % n_group or not 1 <= topk_group <= n_group:
+        raise ValueError("bad expert groups")
     if not moe_norm_route_ok(h, gamma, router, e):
-        raise ValueError("moe_norm_route: fp16 rows of H % 8 == 0, H <= 8192 and a contiguous fp16 [E, H] router")
+        raise ValueError("moe_norm_route: fp16 rows of H % 8 == 0, H <= 8192 and a contiguous fp16 [E, H] router of at most "
+                         "256 Ki elements")
     t, hd = h.shape
     x = torch.empty((t, hd), dtype=torch.float16, device=h.device)
     ids = torch.empty((t, top_k), dtype=torch.int32, device=h.device)
@@ -575,7 +601,8 @@ def moe_norm_route(h, gamma, eps, router, top_k, normalize=True, expert_range=No
     lo, hi = expert_range if expert_range is not None else (0, 0)
     rc = lib().bigdl_moe_norm_route(_ptr(h), _ptr(gamma), _ptr(router), _ptr(x), _ptr(ids), _ptr(weights), t, hd,
                                     h.stride(0), eps, offset, e, top_k, int(bool(normalize)), lo, hi,
-                                    int(bool(sigmoid_scores)), _stream())
+                                    int(bool(sigmoid_scores)), _ptr(route_bias), n_group, topk_group, int(bool(group_top2)),
+                                    _stream())
     _check(rc, "moe_norm_route")
     return x, ids, weights
 

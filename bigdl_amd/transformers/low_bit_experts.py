@@ -6,8 +6,9 @@ quantized matrices (gate [E*I, H], up [E*I, H], down [E*H, I]): each is an ordin
 quantization, ``.to(device)`` re-tiling and ``save_low_bit`` / ``load_low_bit`` work unchanged, and on the device expert
 ``e`` is tile rows ``e*N/16 ...`` of one buffer, which the routed GEMV indexes from the router's output without a
 host round trip.  Reference behaviour: per-expert ``LowBitLinear`` modules and the python loops over them in
-python/llm/src/ipex_llm/transformers/models/mixtral.py:60-130 and models/common.py:339-354 (``moe_group_topk`` /
-``moe_softmax_topk`` + ``xe_linear.moe_forward_vec``).
+python/llm/src/ipex_llm/transformers/models/qwen2_moe.py:376-452 (``qwen2moe_moeblock_forward``: top-k loop at one
+token, host-side ``xe_linear.get_moe_indexes`` bucketing below 256 tokens, one-hot mask loop above) and
+models/phixtral.py:44-104; Mixtral itself runs through the stock HuggingFace expert loop there.
 """
 from __future__ import annotations
 

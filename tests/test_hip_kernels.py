@@ -413,7 +413,7 @@ def test_moe_route_matches_softmax_topk(hip, cfg, dtype):
     torch.testing.assert_close(w2, rv, rtol=1e-4, atol=1e-6)
 
 
-@pytest.mark.parametrize("cfg", [(1, 4096, 8, 2, True, 0.0), (5, 2048, 60, 4, False, 0.0), (3, 8192, 64, 6, True, 1.0),
+@pytest.mark.parametrize("cfg", [(1, 4096, 8, 2, True, 0.0), (5, 2048, 60, 4, False, 0.0), (3, 8192, 32, 6, True, 1.0),
                                  (17, 256, 130, 8, True, 0.0)])
 def test_moe_norm_route_matches_separate_ops(hip, cfg):
     """one launch (RMSNorm + router product + top-k) against a plain fp32 PyTorch statement of the three steps, and
@@ -448,6 +448,62 @@ def test_moe_norm_route_matches_separate_ops(hip, cfg):
     il = ids.long()
     assert torch.equal(ids2.long(), torch.where((il >= lo) & (il < hi), il - lo, torch.full_like(il, -1)))
     assert torch.equal(w2, w)
+
+
+@pytest.mark.parametrize("cfg", [(4, 512, 64, 6, 8, 3, False, False, False, False),      # DeepSeek-V2 style: softmax, max
+                                 (3, 1024, 160, 6, 8, 3, False, False, False, False),
+                                 (5, 1024, 256, 8, 8, 4, True, True, True, True),         # V3 style: sigmoid + bias, top-2 sums
+                                 (2, 512, 64, 6, 1, 1, True, True, False, True),          # bias only, one group
+                                 (2, 512, 96, 4, 4, 2, True, False, True, False)])
+def test_moe_norm_route_group_limited(hip, cfg):
+    """the group-limited / biased selection inside the fused launch against the same steps as tensor ops"""
+    t, h, e, k, n_group, topk_group, sigmoid, with_bias, top2, norm = cfg
+    torch.manual_seed(24)
+    hid = torch.randn(t, h).half().cuda()
+    gamma = (1 + 0.1 * torch.randn(h)).half().cuda()
+    router = (torch.randn(e, h) * 0.08).half().cuda()
+    bias = (torch.randn(e) * 0.2).float().cuda() if with_bias else None
+    x, ids, w = hip.moe_norm_route(hid, gamma, 1e-6, router, k, normalize=norm, sigmoid_scores=sigmoid, route_bias=bias,
+                                   n_group=n_group, topk_group=topk_group, group_top2=top2)
+    logits = (x.float() @ router.float().t()).half().float()
+    p = torch.sigmoid(logits) if sigmoid else torch.softmax(logits, -1)
+    choice = p if bias is None else p + bias
+    if n_group > 1:
+        grouped = choice.view(t, n_group, -1)
+        gsc = grouped.topk(2, dim=-1).values.sum(-1) if top2 else grouped.amax(-1)
+        keep = torch.zeros_like(gsc).scatter_(1, gsc.topk(topk_group, dim=-1).indices, 1.0)
+        choice = choice.masked_fill(keep.repeat_interleave(e // n_group, 1) == 0, 0.0)
+    rv, ri = torch.topk(choice, k, dim=-1)
+    # rows whose selection does not hang on a rounding-sized gap (k-th against (k+1)-th candidate, and the group cut)
+    srt = choice.sort(-1, descending=True).values
+    clear = (srt[:, k - 1] - srt[:, k]) > 2e-3 * srt[:, k - 1].abs().clamp_min(1e-3)
+    if n_group > 1:
+        gsrt = gsc.sort(-1, descending=True).values
+        clear &= (gsrt[:, topk_group - 1] - gsrt[:, topk_group]) > 2e-3 * gsrt[:, topk_group - 1].abs().clamp_min(1e-3)
+    assert clear.any()
+    assert torch.equal(ids.long().sort(-1).values[clear], ri.sort(-1).values[clear])
+    wr = p.gather(1, ids.long())
+    if norm:
+        wr = wr / (wr.sum(-1, keepdim=True) + 1e-20)
+    torch.testing.assert_close(w, wr, rtol=2e-3, atol=1e-6)
+    # picks are ordered best first, like torch.topk
+    cg = choice.gather(1, ids.long())
+    assert bool((cg[clear][:, :-1] >= cg[clear][:, 1:] - 1e-6).all())
+    # the same selection from given logits (the form the prompt pass and large routers use): same inputs as the
+    # reference, so ids and order match exactly on the clear rows
+    for lg in (logits.half(), logits):
+        ids2, w2 = hip.moe_route(lg, k, normalize=norm, sigmoid_scores=sigmoid, route_bias=bias, n_group=n_group,
+                                 topk_group=topk_group, group_top2=top2)
+        assert torch.equal(ids2.long()[clear], ri[clear])
+        wr2 = p.gather(1, ids2.long())
+        if norm:
+            wr2 = wr2 / (wr2.sum(-1, keepdim=True) + 1e-20)
+        torch.testing.assert_close(w2, wr2, rtol=1e-4, atol=1e-6)
+    lo, hi = e // 2, e
+    ids3, _ = hip.moe_route(logits, k, normalize=norm, sigmoid_scores=sigmoid, route_bias=bias, n_group=n_group,
+                            topk_group=topk_group, group_top2=top2, expert_range=(lo, hi))
+    il = ids2.long()
+    assert torch.equal(ids3.long(), torch.where((il >= lo) & (il < hi), il - lo, torch.full_like(il, -1)))
 
 
 @pytest.mark.parametrize("name", ["sym_int4", "asym_int4", "nf4", "sym_int8", "fp6", "fp8_e5m2"])
