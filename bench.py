@@ -285,7 +285,8 @@ def cpu_module_path(args, rank, local_rank, world, dist):
 def qlora(args, rank, world, dist):
     """QLoRA training steps (data parallel): delegates to benchmark/qlora_bench.py in this process group"""
     sys.argv = [sys.argv[0], "--steps", str(args.steps), "--warmup", str(args.warmup),
-                "--model", "llama2-7b" if args.model == "llama2-7b" else "tiny", "--full-targets"]
+                "--model", "llama2-7b" if args.model == "llama2-7b" else "tiny", "--full-targets"] + \
+               ([] if args.no_graph else ["--graph"])
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "benchmark"))
     import qlora_bench
     qlora_bench.main(process_group_ready=dist is not None)

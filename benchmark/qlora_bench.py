@@ -71,6 +71,9 @@ def main(process_group_ready: bool = False):
     ap.add_argument("--full-targets", action="store_true",
                     help="LoRA on all seven projections (q, k, v, o, gate, up, down) as in the reference's alpaca-qlora "
                          "recipe (alpaca_qlora_finetuning.py:80-88) instead of q/k/v only")
+    ap.add_argument("--graph", action="store_true",
+                    help="forward + backward (+ the optimizer step on one GPU) replayed as one hipGraph "
+                         "(bigdl_amd/transformers/graph_train.py)")
     args = ap.parse_args()
     rank, local, world = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("LOCAL_RANK", 0), ("WORLD_SIZE", 1)))
     torch.cuda.set_device(local)
@@ -96,16 +99,26 @@ def main(process_group_ready: bool = False):
     model = get_peft_model(model, LoraConfig(r=8, lora_alpha=32, target_modules=targets,
                                              lora_dropout=0.05, bias="none", task_type="CAUSAL_LM", training_mode="qlora"))
     params = [p for p in model.parameters() if p.requires_grad]
-    opt = torch.optim.AdamW(params, lr=2e-5)
-    dp = DataParallelAdapter(model, opt)
     g = torch.Generator().manual_seed(rank)
+    if args.graph:
+        from bigdl_amd.parallel.data_parallel import broadcast_trainable
+        from bigdl_amd.transformers.graph_train import GraphedTrainStep, capturable_adamw
+        opt = capturable_adamw(params, lr=2e-5)
+        broadcast_trainable(model, 0)
+        graphed = GraphedTrainStep(model, opt, torch.randint(3, cfg.vocab_size, (args.batch, args.seq_len), generator=g).to(dev))
 
-    def step():
-        ids = torch.randint(3, cfg.vocab_size, (args.batch, args.seq_len), generator=g).to(dev)
-        with torch.autocast("cuda", dtype=torch.bfloat16):
-            out = model(input_ids=ids, labels=ids)
-        dp.step(out.loss)
-        return out.loss
+        def step():
+            return graphed(torch.randint(3, cfg.vocab_size, (args.batch, args.seq_len), generator=g).to(dev))
+    else:
+        opt = torch.optim.AdamW(params, lr=2e-5)
+        dp = DataParallelAdapter(model, opt)
+
+        def step():
+            ids = torch.randint(3, cfg.vocab_size, (args.batch, args.seq_len), generator=g).to(dev)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out = model(input_ids=ids, labels=ids)
+            dp.step(out.loss)
+            return out.loss
 
     def sync():
         if world > 1:
@@ -130,7 +143,7 @@ def main(process_group_ready: bool = False):
                           "dtype": "bf16 compute, %s base weights" % args.low_bit, "data": "synthetic",
                           "config": {"model": args.model + " (random-init)", "global_batch": world * args.batch,
                                      "seq_len": args.seq_len, "parallelism": f"dp{world}" if world > 1 else "single",
-                                     "lora_targets": targets, "lora_r": 8},
+                                     "lora_targets": targets, "lora_r": 8, "hip_graph": bool(args.graph)},
                           "bench": "qlora_train_step", "model": args.model, "low_bit": args.low_bit, "n_gpus": world,
                           "per_device_batch": args.batch, "seq_len": args.seq_len, "s_per_it": round(dt, 4),
                           "samples_per_s": round(world * args.batch / dt, 2),
