@@ -80,6 +80,8 @@ def lib():
         L.bigdl_gemm_lowbit_bm.argtypes = [ci]
         L.bigdl_gemm_lowbit_grouped.argtypes = [vp] * 8 + [ci] * 12 + [vp]
         L.bigdl_moe_block_table.argtypes = [vp, ci, ci, ci, vp, vp, vp, vp]
+        L.bigdl_lora_down.argtypes = [vp, vp, vp, ci, ci, ci, i64, i64, ci, cf, ci, vp]
+        L.bigdl_lora_up.argtypes = [vp, vp, vp, vp, ci, ci, ci, i64, i64, i64, ci, cf, ci, ci, vp]
         L.bigdl_moe_route.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, i64, ci, ci, vp]
         L.bigdl_moe_route_grouped.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, i64, ci, ci, vp, ci, ci, ci, vp]
         L.bigdl_moe_combine.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, i64, vp]
@@ -528,6 +530,63 @@ def gemm_lowbit_grouped(x, w, qtype, n_experts, out_features, in_features, table
                                          in_features, x.stride(0), out.stride(0), qtype, ACT[act], _out_type(out.dtype),
                                          x.shape[0], _stream())
     _check(rc, "gemm_lowbit_grouped")
+    return out
+
+
+def lora_ops_ok(x, rank) -> bool:
+    """whether :func:`lora_down` / :func:`lora_up` take activations like ``x`` ([M, K] rows) with adapters of this rank"""
+    return (x.is_cuda and x.dim() == 2 and x.dtype in (torch.float16, torch.bfloat16) and rank in (8, 16)
+            and x.shape[1] % 8 == 0 and x.stride(1) == 1 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0
+            and 0 < x.shape[0] <= 65535 * 4)
+
+
+def _lora_small(w, rank, wide):
+    """(wt flag, row stride) of an adapter matrix given as [rank, wide] or [wide, rank]"""
+    if not w.is_contiguous() or w.data_ptr() % 16:
+        raise ValueError("adapter matrices must be contiguous")
+    if tuple(w.shape) == (rank, wide) and (rank != wide):
+        return 0, wide
+    if tuple(w.shape) == (wide, rank):
+        return 1, rank
+    if tuple(w.shape) == (rank, wide):
+        return 0, wide
+    raise ValueError(f"adapter matrix {tuple(w.shape)} is neither [{rank}, {wide}] nor [{wide}, {rank}]")
+
+
+def lora_down(x, w, rank, alpha=1.0):
+    """``alpha * x @ W^T`` -> [M, rank] in x's dtype: x [M, K]; w the [rank, K] matrix (an adapter's A) or, as stored,
+    its transpose [K, rank] (an adapter's B, for ``gy @ B``).  One pass over x, the small operand in registers."""
+    _need_cuda(x, w)
+    if not lora_ops_ok(x, rank) or w.dtype != x.dtype:
+        raise ValueError("lora_down: fp16 / bf16 rows with K % 8 == 0, rank 8 or 16, adapter in the same dtype")
+    m, k = x.shape
+    wt, ldw = _lora_small(w, rank, k)
+    t = torch.empty((m, rank), dtype=x.dtype, device=x.device)
+    rc = lib().bigdl_lora_down(_ptr(x), _ptr(w), _ptr(t), m, k, rank, x.stride(0), ldw, wt, float(alpha), _out_type(x.dtype),
+                               _stream())
+    _check(rc, "lora_down")
+    return t
+
+
+def lora_up(t, w, out, alpha=1.0, accumulate=True, mask=None):
+    """``out = (out if accumulate else 0) + alpha * mask * (t @ W)``: t [M, rank]; w [rank, C] (an adapter's A) or, as
+    stored, [C, rank] (an adapter's B, for ``t @ B^T``); out [M, C]; mask a bool / uint8 [M, C] (False = dropped) or None."""
+    _need_cuda(t, w, out, mask)
+    rank = t.shape[1]
+    if not lora_ops_ok(out, rank) or w.dtype != out.dtype or t.dtype != out.dtype or not t.is_contiguous() \
+            or t.shape[0] != out.shape[0]:
+        raise ValueError("lora_up: fp16 / bf16 rows with C % 8 == 0, rank 8 or 16, operands in one dtype")
+    m, c = out.shape
+    wt, ldw = _lora_small(w, rank, c)
+    ldm = 0
+    if mask is not None:
+        if mask.dtype not in (torch.bool, torch.uint8) or mask.shape != out.shape or mask.stride(1) != 1 \
+                or mask.stride(0) % 8 or mask.data_ptr() % 8:
+            raise ValueError("mask must be bool / uint8 [M, C] with 8-byte aligned rows")
+        ldm = mask.stride(0)
+    rc = lib().bigdl_lora_up(_ptr(t), _ptr(w), _ptr(out), _ptr(mask), m, c, rank, out.stride(0), ldw, ldm, wt, float(alpha),
+                             int(bool(accumulate)), _out_type(out.dtype), _stream())
+    _check(rc, "lora_up")
     return out
 
 

@@ -132,8 +132,16 @@ class FusedLoraLowBit(torch.autograd.Function):
         else:
             xd, mask = x2d, None
         a16, b16 = a_w.to(x2d.dtype), b_w.to(x2d.dtype)
-        t = xd @ a16.t()                                   # [M, r]
-        y.addmm_(t, b16.t(), alpha=scale)
+        r = a16.shape[0]
+        # rank-8 / rank-16 products on the one-pass kernels of csrc/hip/lora_ops.hip (BIGDL_LORA_KERNELS=0: library GEMMs)
+        ctx.native = _LORA_KERNELS and _hip_lora_ok(xd, y, r)
+        if ctx.native:
+            from ..ops import hip
+            t = hip.lora_down(xd, a16, r)                      # [M, r]
+            hip.lora_up(t, b16, y, alpha=scale)                # y += scale * t @ B^T
+        else:
+            t = xd @ a16.t()                                   # [M, r]
+            y.addmm_(t, b16.t(), alpha=scale)
         ctx.save_for_backward(xd, t, mask, a16, b16)
         ctx.weight, ctx.scale, ctx.p = weight, scale, p
         return y
@@ -143,17 +151,36 @@ class FusedLoraLowBit(torch.autograd.Function):
         from .low_bit_linear import dequant_weight
         xd, t, mask, a16, b16 = ctx.saved_tensors
         gy = gy.contiguous()
-        gt = (gy @ b16) * ctx.scale                        # [M, r]
+        native = ctx.native and gy.dtype == xd.dtype
+        if native:
+            from ..ops import hip
+            gt = hip.lora_down(gy, b16, a16.shape[0], alpha=ctx.scale)                   # [M, r] = scale * gy @ B
+        else:
+            gt = (gy @ b16) * ctx.scale                        # [M, r]
         g_b = (gy.t() @ t).float() * ctx.scale if ctx.needs_input_grad[4] else None      # [N, r]
         g_a = (gt.t() @ xd).float() if ctx.needs_input_grad[3] else None                # [r, K]
         gx = None
         if ctx.needs_input_grad[0]:
             gx = gy @ dequant_weight(ctx.weight, gy.dtype)
-            if mask is None:
+            if native:
+                # gx += (gt @ A) * mask / (1 - p): one pass over gx, the mask read as the bytes it is stored in
+                hip.lora_up(gt, a16, gx, alpha=1.0 if mask is None else 1.0 / (1.0 - ctx.p), mask=mask)
+            elif mask is None:
                 gx.addmm_(gt, a16)
             else:
                 gx.addcmul_(gt @ a16, mask.to(gy.dtype), value=1.0 / (1.0 - ctx.p))
         return gx, None, None, g_a, g_b, None, None, None
+
+
+_LORA_KERNELS = os.environ.get("BIGDL_LORA_KERNELS", "1") != "0"
+
+
+def _hip_lora_ok(x, y, rank) -> bool:
+    try:
+        from ..ops import hip
+    except Exception:
+        return False
+    return hip.lora_ops_ok(x, rank) and hip.lora_ops_ok(y, rank) and x.dtype == y.dtype
 
 
 class LoraLowBitLinear(nn.Module, LoraLayer):

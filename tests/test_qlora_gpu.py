@@ -105,3 +105,63 @@ def test_fused_lora_node_matches_module_by_module(monkeypatch, p):
         return
     for a, b in zip(res["1"], res["0"]):
         torch.testing.assert_close(a, b, rtol=4e-2, atol=4e-2 * b.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(1024, 4096, 8), (37, 11008, 8), (130, 256, 16), (5, 1032, 16)])
+def test_lora_rank_kernels_match_fp32(shape, dtype):
+    """lora_down / lora_up (one-pass rank-r products) against fp32 matmuls, both storage orders of the small operand,
+    with and without the dropout mask and the accumulate flag; strided activations"""
+    from bigdl_amd.ops import hip
+    m, k, r = shape
+    torch.manual_seed(30)
+    x = torch.randn(m, k + 8, device="cuda").to(dtype)[:, :k]                   # row stride k + 8
+    a = (torch.randn(r, k, device="cuda") * 0.05).to(dtype)                    # [r, K]   (an adapter's A)
+    b = (torch.randn(k, r, device="cuda") * 0.05).to(dtype)                    # [K, r]   (an adapter's B, K = its out size)
+    tol = dict(rtol=2e-2, atol=2e-2) if dtype == torch.bfloat16 else dict(rtol=4e-3, atol=4e-3)
+    t1 = hip.lora_down(x, a, r)
+    torch.testing.assert_close(t1.float(), x.float() @ a.float().t(), **tol)
+    t2 = hip.lora_down(x, b, r, alpha=0.5)
+    torch.testing.assert_close(t2.float(), 0.5 * (x.float() @ b.float()), **tol)
+    t = (torch.randn(m, r, device="cuda") * 0.5).to(dtype)
+    out0 = torch.randn(m, k + 8, device="cuda").to(dtype)[:, :k]
+    out = out0.clone()
+    hip.lora_up(t, a, out, alpha=2.0)                                           # out += 2 * t @ A
+    torch.testing.assert_close(out.float(), out0.float() + 2.0 * (t.float() @ a.float()), **tol)
+    out = out0.clone()
+    hip.lora_up(t, b, out, alpha=1.0, accumulate=False)                         # out = t @ B^T
+    torch.testing.assert_close(out.float(), t.float() @ b.float().t(), **tol)
+    mask = torch.rand(m, k, device="cuda") > 0.3
+    out = out0.clone()
+    hip.lora_up(t, a, out, alpha=1.0 / 0.7, mask=mask)
+    torch.testing.assert_close(out.float(), out0.float() + (t.float() @ a.float()) * mask.float() / 0.7, **tol)
+    with pytest.raises(ValueError):
+        hip.lora_down(x, a[:4], 4)
+
+
+@pytest.mark.parametrize("p", [0.0, 0.25])
+def test_fused_lora_node_native_kernels_match_library_products(monkeypatch, p):
+    """FusedLoraLowBit with the rank-r kernels against the same node on library GEMMs: same dropout kernel and seed, so
+    the same mask; output, activation gradient and adapter gradients"""
+    import bigdl_amd.transformers.qlora as Q_
+    from bigdl_amd.transformers.qlora import LoraConfig, get_peft_model
+    pm = get_peft_model(_qmodel("nf4"), LoraConfig(r=8, lora_alpha=16, target_modules=["q_proj"], lora_dropout=p,
+                                                   training_mode="qlora"))
+    lin = pm.base_model.model.layers[0].self_attn.q_proj
+    torch.nn.init.normal_(lin.lora_B["default"].weight, std=0.05)
+    lin.train()
+    x0 = torch.randn(3, 40, 256, device="cuda", dtype=torch.bfloat16)
+    g = torch.randn(3, 40, lin.out_features, device="cuda", dtype=torch.bfloat16)
+    res = {}
+    for native in (True, False):
+        monkeypatch.setattr(Q_, "_LORA_KERNELS", native)
+        x = x0.clone().requires_grad_(True)
+        for prm in (lin.lora_A["default"].weight, lin.lora_B["default"].weight):
+            prm.grad = None
+        torch.manual_seed(123)
+        y = lin(x)
+        y.backward(g)
+        res[native] = (y.detach().float(), x.grad.float(), lin.lora_A["default"].weight.grad.float().clone(),
+                       lin.lora_B["default"].weight.grad.float().clone())
+    for a, b in zip(res[True], res[False]):
+        torch.testing.assert_close(a, b, rtol=4e-2, atol=4e-2 * b.abs().max().item())
