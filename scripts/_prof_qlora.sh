@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 export PYTHONPATH=.
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/qlora_prof -o q -- python benchmark/qlora_bench.py --steps 4 --warmup 2 --full-targets > gpurun_out/qlora_prof.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/qlora_prof -o q -- python benchmark/qlora_bench.py --steps 4 --warmup 2 --full-targets --graph > gpurun_out/qlora_prof.log 2>&1
 tail -2 gpurun_out/qlora_prof.log
 f=$(find gpurun_out/qlora_prof -name "*kernel_stats.csv" | head -1)
 python3 - "$f" <<'PY'
