@@ -59,6 +59,11 @@ def random_lowbit_llama(cfg, qtype, device, skip=("lm_head",), seed=0):
     return model
 
 
+def _dense_cache_on():
+    from bigdl_amd.transformers.low_bit_linear import train_dense_cache_enabled
+    return train_dense_cache_enabled()
+
+
 def main(process_group_ready: bool = False):
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=10)
@@ -143,7 +148,8 @@ def main(process_group_ready: bool = False):
                           "dtype": "bf16 compute, %s base weights" % args.low_bit, "data": "synthetic",
                           "config": {"model": args.model + " (random-init)", "global_batch": world * args.batch,
                                      "seq_len": args.seq_len, "parallelism": f"dp{world}" if world > 1 else "single",
-                                     "lora_targets": targets, "lora_r": 8, "hip_graph": bool(args.graph)},
+                                     "lora_targets": targets, "lora_r": 8, "hip_graph": bool(args.graph),
+                                     "dense_weight_cache": _dense_cache_on()},
                           "bench": "qlora_train_step", "model": args.model, "low_bit": args.low_bit, "n_gpus": world,
                           "per_device_batch": args.batch, "seq_len": args.seq_len, "s_per_it": round(dt, 4),
                           "samples_per_s": round(world * args.batch / dt, 2),

@@ -466,6 +466,8 @@ def prepare_model_for_kbit_training(model, use_gradient_checkpointing=True):
         else:
             model.get_input_embeddings().register_forward_hook(lambda m, i, o: o.requires_grad_(True))
         model.gradient_checkpointing_enable()
+    from .low_bit_linear import auto_train_dense_cache
+    auto_train_dense_cache(model)
     return model
 
 
