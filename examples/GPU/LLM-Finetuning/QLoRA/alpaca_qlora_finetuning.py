@@ -32,8 +32,8 @@ def build_examples(path, tok, cutoff_len):
     return out
 
 
-def collate(batch, pad):
-    n = max(len(i) for i, _ in batch)
+def collate(batch, pad, length=None):
+    n = length or max(len(i) for i, _ in batch)
     ids = torch.full((len(batch), n), pad)
     labels = torch.full((len(batch), n), -100)
     mask = torch.zeros(len(batch), n, dtype=torch.long)
@@ -61,13 +61,16 @@ if __name__ == "__main__":
     ap.add_argument("--lora_target_modules", nargs="+",
                     default=["q_proj", "k_proj", "v_proj", "o_proj", "up_proj", "down_proj", "gate_proj"])
     ap.add_argument("--relora_steps", type=int, default=300)
+    ap.add_argument("--hip_graph", action="store_true",
+                    help="pad every batch to cutoff_len and replay forward + backward as one hipGraph "
+                         "(bigdl_amd/transformers/graph_train.py); no activation checkpointing in this mode")
     a = ap.parse_args()
     rank, world, device = init_distributed()
     low_bit = {"qlora": "nf4", "qalora": "sym_int4", "lora": "bf16", "relora": "nf4"}[a.training_mode]
     model = AutoModelForCausalLM.from_pretrained(a.base_model, load_in_low_bit=low_bit, optimize_model=False,
                                                  torch_dtype=torch.bfloat16, modules_to_not_convert=["lm_head"])
     model = model.to(device)
-    model = prepare_model_for_kbit_training(model, use_gradient_checkpointing=True)
+    model = prepare_model_for_kbit_training(model, use_gradient_checkpointing=not a.hip_graph)
     cfg = LoraConfig(r=a.lora_r, lora_alpha=a.lora_alpha, target_modules=a.lora_target_modules,
                      lora_dropout=a.lora_dropout, bias="none", task_type="CAUSAL_LM", training_mode=a.training_mode)
     model = get_peft_model(model, cfg)
@@ -81,6 +84,20 @@ if __name__ == "__main__":
     dp = DataParallelAdapter(model, opt, grad_accum=accum, max_grad_norm=1.0)
     model.train()
     step = 0
+    if a.hip_graph:
+        from bigdl_amd.transformers.graph_train import GraphedTrainStep
+        first = tuple(t.to(device) for t in collate(data[:a.micro_batch_size], tok.pad_token_id, a.cutoff_len))
+        graphed = GraphedTrainStep(model, opt, first[0], example_labels=first[1], example_mask=first[2], grad_accum=accum,
+                                   max_grad_norm=1.0)
+        for epoch in range(a.num_epochs):
+            for i in range(0, len(data) - a.micro_batch_size + 1, a.micro_batch_size):
+                ids, labels, mask = (t.to(device) for t in collate(data[i:i + a.micro_batch_size], tok.pad_token_id, a.cutoff_len))
+                loss = graphed(ids, labels, mask)
+                if graphed.stepped:
+                    step += 1
+                    if rank == 0 and step % 10 == 0:
+                        print(f"epoch {epoch} step {step} loss {loss.item():.4f}", flush=True)
+        a.num_epochs = 0
     for epoch in range(a.num_epochs):
         for i in range(0, len(data) - a.micro_batch_size + 1, a.micro_batch_size):
             ids, labels, mask = (t.to(device) for t in collate(data[i:i + a.micro_batch_size], tok.pad_token_id))
