@@ -199,13 +199,105 @@ __global__ __launch_bounds__(256) void moe_route_kernel(const void* logits, int*
     route_pick(v, mx, t, E, top_k, normalize, lo, hi, sigmoid_scores, ids, weights);
 }
 
+// sum over the wavefront with the four in-row steps as DPP moves (a few cycles each) and only the two cross-row steps as
+// LDS-routed permutes: the chain of six dependent permutes of wave_sum is most of a microsecond
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += dpp_mov<0xB1>(v);     // quad_perm [1, 0, 3, 2]
+  v += dpp_mov<0x4E>(v);     // quad_perm [2, 3, 0, 1]
+  v += dpp_mov<0x141>(v);    // row_half_mirror
+  v += dpp_mov<0x140>(v);    // row_mirror
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+
+// Selection by rank counting, one thread per expert (E <= NR_WAVES * 64), every cross-thread step through LDS broadcasts
+// instead of dependent cross-lane permutes: p = softmax / sigmoid of the logits, choice = p + bias, optional group limit
+// (groups ranked by their best or their two best choices, choices outside the topk_group best groups become 0), rank of
+// each choice (ties: lower expert first), the top_k ranks write their id and p (renormalized on request).
+// lg[E]: logits; ch[E + 64]: scratch.  All threads of the workgroup must call it.
+__device__ __forceinline__ void route_pick_ranked(const float* lg, float* ch, int t, int E, int top_k, int normalize, int lo,
+                                                  int hi, int sigmoid_scores, const float* bias, int n_group, int topk_group,
+                                                  int group_top2, int* ids, float* weights) {
+  const int e = threadIdx.x;
+  const bool mine = e < E;
+  float* gsc = ch + E;                    // [n_group] group scores, later the picked p by rank [top_k]
+  float p = 0.0f;
+  if (mine) {
+    if (sigmoid_scores) {
+      p = 1.0f / (1.0f + __expf(-lg[e]));
+    } else {
+      float mx = -3.0e38f, sum = 0.0f;
+      for (int j = 0; j < E; ++j) mx = fmaxf(mx, lg[j]);
+      for (int j = 0; j < E; ++j) sum += __expf(lg[j] - mx);
+      p = __expf(lg[e] - mx) / sum;
+    }
+  }
+  float c = mine ? p + (bias != nullptr ? bias[e] : 0.0f) : -3.0e38f;
+  if (n_group > 1) {
+    const int gs = E / n_group;
+    if (mine) ch[e] = c;
+    __syncthreads();
+    if (e < n_group) {
+      float b1 = -3.0e38f, b2 = -3.0e38f;
+      for (int j = 0; j < gs; ++j) {
+        const float x = ch[e * gs + j];
+        if (x > b1) { b2 = b1; b1 = x; } else if (x > b2) { b2 = x; }
+      }
+      gsc[e] = group_top2 ? b1 + (gs > 1 ? b2 : 0.0f) : b1;
+    }
+    __syncthreads();
+    if (mine) {
+      const int g = e / gs;
+      const float mine_s = gsc[g];
+      int rank = 0;
+      for (int j = 0; j < n_group; ++j) {
+        const float o = gsc[j];
+        rank += (o > mine_s || (o == mine_s && j < g)) ? 1 : 0;
+      }
+      if (rank >= topk_group) c = 0.0f;
+    }
+    __syncthreads();
+  }
+  if (mine) ch[e] = c;
+  __syncthreads();
+  int rank = 0x7fffffff;
+  if (mine) {
+    rank = 0;
+    for (int j = 0; j < E; ++j) {
+      const float o = ch[j];
+      rank += (o > c || (o == c && j < e)) ? 1 : 0;
+    }
+    if (rank < top_k) gsc[rank] = p;
+  }
+  __syncthreads();
+  if (rank < top_k) {
+    float w = p;
+    if (normalize) {
+      float picked = 0.0f;
+      for (int j = 0; j < top_k; ++j) picked += gsc[j];
+      w /= picked + ((bias != nullptr || n_group > 1) ? 1e-20f : 0.0f);
+    }
+    int id = e;
+    if (hi > lo) id = (id >= lo && id < hi) ? id - lo : -1;
+    ids[t * top_k + rank] = id;
+    weights[t * top_k + rank] = w;
+  }
+}
+
 // h [T, ldh] fp16 -> x = rmsnorm(h) * (gamma + offset) [T, H] fp16, router logits of x (rounded to fp16 like the dense
-// product they replace) -> ids / weights.  One workgroup of 16 wavefronts per token; H % 8 == 0, H <= 8192 (one 16-byte
-// chunk per thread); E <= 64 * ROUTE_MAX_PER_LANE.  LPE = 16-byte requests per lane and router row (H <= 512 * LPE): a
-// wavefront takes 16 / LPE experts at a time with all their requests in flight together, so a 64-expert, 2048-wide
-// router (DeepSeek-V2-Lite, Qwen-MoE) and an 8-expert, 4096-wide one (Mixtral) are both one memory round trip.
+// product they replace) -> ids / weights.  One workgroup of 8 wavefronts per token (256 VGPRs per lane: 1024 threads
+// spilled 800 registers); H % 8 == 0, H <= 8192 (two 16-byte chunks per thread); E <= 512 (one thread per expert in
+// the selection).  LPE = 16-byte requests per lane and router row (H <= 512 * LPE): a wavefront takes 32 / LPE experts
+// at a time with all their requests in flight together, so a 64-expert, 2048-wide router (DeepSeek-V2-Lite, Qwen-MoE)
+// and an 8-expert, 4096-wide one (Mixtral) are both one memory round trip.
+constexpr int NR_WAVES = 8;
 template <int LPE>
-__global__ __launch_bounds__(1024) void moe_norm_route_kernel(const _Float16* h, const _Float16* gamma, const _Float16* router,
+__global__ __launch_bounds__(NR_WAVES * 64) void moe_norm_route_kernel(const _Float16* h, const _Float16* gamma, const _Float16* router,
                                                               _Float16* x_out, int* ids, float* weights, int H, int64_t ldh,
                                                               float eps, float offset, int E, int top_k, int normalize, int lo,
                                                               int hi, int sigmoid_scores, const float* bias, int n_group,
@@ -214,8 +306,8 @@ __global__ __launch_bounds__(1024) void moe_norm_route_kernel(const _Float16* h,
   _Float16* xs = (_Float16*)smem;                       // [H]
   float* lg = (float*)(xs + H);                         // [E]
   float* sh = lg + ((E + 3) & ~3);                      // [16]
-  float* ch = sh + 16;                                  // [E + n_group] (grouped selection only)
-  constexpr int EB = 16 / LPE;
+  float* ch = sh + 16;                                  // [E + 64]
+  constexpr int EB = 32 / LPE;
   const int t = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = H >> 3;
@@ -231,64 +323,62 @@ __global__ __launch_bounds__(1024) void moe_norm_route_kernel(const _Float16* h,
       }
   };
   request(wave * EB);
-  float v[8];
-  half8 gm;
+  float v[2][8];
+  half8 gm[2];
   float ss = 0.0f;
-  const int c = threadIdx.x * 8;
-  if (c < H) {
-    const half8 hv = *(const half8*)(h + (int64_t)t * ldh + c);
-    gm = *(const half8*)(gamma + c);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { v[j] = (float)hv[j]; ss += v[j] * v[j]; }
+  for (int i = 0; i < 2; ++i) {
+    const int c = (threadIdx.x + i * NR_WAVES * 64) * 8;
+    if (c < H) {
+      const half8 hv = *(const half8*)(h + (int64_t)t * ldh + c);
+      gm[i] = *(const half8*)(gamma + c);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { v[i][j] = (float)hv[j]; ss += v[i][j] * v[i][j]; }
+    }
   }
-  ss = wave_sum(ss);
+  ss = wave_sum_dpp(ss);
   if (lane == 0) sh[wave] = ss;
   __syncthreads();
   float tot = 0.0f;
 #pragma unroll
-  for (int q = 0; q < 16; ++q) tot += sh[q];
+  for (int q = 0; q < NR_WAVES; ++q) tot += sh[q];
   const float rs = rsqrtf(tot / (float)H + eps);
-  if (c < H) {
-    half8 o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (_Float16)(v[j] * rs * ((float)gm[j] + offset));
-    *(half8*)(xs + c) = o;
-    *(half8*)(x_out + (int64_t)t * H + c) = o;
+  for (int i = 0; i < 2; ++i) {
+    const int c = (threadIdx.x + i * NR_WAVES * 64) * 8;
+    if (c < H) {
+      half8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (_Float16)(v[i][j] * rs * ((float)gm[i][j] + offset));
+      *(half8*)(xs + c) = o;
+      *(half8*)(x_out + (int64_t)t * H + c) = o;
+    }
   }
   __syncthreads();
-  for (int e0 = wave * EB; e0 < E; e0 += 16 * EB) {
+  for (int e0 = wave * EB; e0 < E; e0 += NR_WAVES * EB) {
     if (e0 != wave * EB) request(e0);
+    float acc[EB];
 #pragma unroll
     for (int b = 0; b < EB; ++b) {
-      float acc = 0.0f;
+      acc[b] = 0.0f;
 #pragma unroll
       for (int u = 0; u < LPE; ++u) {
         const int chk = u * 64 + lane;
         if (chk < nch) {
           const half8 xv = *(const half8*)(xs + chk * 8);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) acc += (float)w[b][u][j] * (float)xv[j];
+          for (int j = 0; j < 8; ++j) acc[b] += (float)w[b][u][j] * (float)xv[j];
         }
       }
-      acc = wave_sum(acc);
-      if (lane == 0 && e0 + b < E) lg[e0 + b] = (float)(_Float16)acc;
     }
+#pragma unroll
+    for (int b = 0; b < EB; ++b) acc[b] = wave_sum_dpp(acc[b]);      // EB independent chains, interleaved by the scheduler
+#pragma unroll
+    for (int b = 0; b < EB; ++b)
+      if (lane == 0 && e0 + b < E) lg[e0 + b] = (float)(_Float16)acc[b];
   }
   __syncthreads();
-  if (wave != 0) return;
-  float lv[ROUTE_MAX_PER_LANE];
-  float mx = -3.0e38f;
-#pragma unroll
-  for (int i = 0; i < ROUTE_MAX_PER_LANE; ++i) {
-    const int e = i * 64 + lane;
-    lv[i] = e < E ? lg[e] : -3.0e38f;
-    mx = fmaxf(mx, lv[i]);
-  }
-  if (bias != nullptr || n_group > 1)
-    route_pick_grouped(lv, mx, t, E, top_k, normalize, lo, hi, sigmoid_scores, bias, n_group, topk_group, group_top2, ch, ids,
-                       weights);
-  else
-    route_pick(lv, mx, t, E, top_k, normalize, lo, hi, sigmoid_scores, ids, weights);
+  route_pick_ranked(lg, ch, t, E, top_k, normalize, lo, hi, sigmoid_scores, bias, n_group, topk_group, group_top2, ids, weights);
 }
 
 __global__ __launch_bounds__(256) void moe_combine_kernel(const _Float16* y, const _Float16* shared, const _Float16* shared_gate,
@@ -371,9 +461,10 @@ extern "C" int bigdl_moe_norm_route(const void* h, const void* gamma, const void
       top_k <= 0 || top_k > 64 || top_k > E)
     return -1;
   if (n_group < 1 || n_group > 64 || E % n_group || topk_group < 1 || topk_group > n_group) return -1;
-  const size_t lds = (size_t)H * 2 + (size_t)((E + 3) & ~3) * 4 + 64 + (size_t)(E + n_group) * 4;
+  const size_t lds = (size_t)H * 2 + (size_t)((E + 3) & ~3) * 4 + 64 + (size_t)(E + 64) * 4;
+  if (E > NR_WAVES * 64) return -1;
 #define BIGDL_NR_LAUNCH(LPE)                                                                                                 \
-  hipLaunchKernelGGL((moe_norm_route_kernel<LPE>), dim3(T), dim3(1024), lds, st, (const _Float16*)h, (const _Float16*)gamma, \
+  hipLaunchKernelGGL((moe_norm_route_kernel<LPE>), dim3(T), dim3(NR_WAVES * 64), lds, st, (const _Float16*)h, (const _Float16*)gamma, \
                      (const _Float16*)router, (_Float16*)x, ids, weights, H, ldh, eps, offset, E, top_k, normalize, lo, hi,  \
                      sigmoid_scores, bias, n_group, topk_group, group_top2)
   if (H <= 512) BIGDL_NR_LAUNCH(1);

@@ -631,7 +631,7 @@ def moe_norm_route_ok(h, gamma, router, n_experts) -> bool:
             and h.shape[1] % 8 == 0 and h.shape[1] <= 8192 and h.shape[0] <= 65535
             and gamma.dtype == torch.float16 and gamma.is_contiguous()
             and router.dtype == torch.float16 and router.is_contiguous() and tuple(router.shape) == (n_experts, h.shape[1])
-            and n_experts <= 1024 and n_experts * h.shape[1] <= 256 * 1024)     # one workgroup reads the whole router
+            and n_experts <= 512 and n_experts * h.shape[1] <= 256 * 1024)     # one workgroup reads the whole router
 
 
 def moe_norm_route(h, gamma, eps, router, top_k, normalize=True, expert_range=None, offset=0.0, sigmoid_scores=False,
