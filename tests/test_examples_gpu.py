@@ -234,3 +234,56 @@ def test_all_in_one_tensor_parallel_mode(ckpt, tmp_path):
                         str(tmp_path)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, f"{r.stdout[-2000:]}\n{r.stderr[-3000:]}"
     assert any(f.startswith("deepspeed_optimize_model_gpu-results") for f in os.listdir(tmp_path))
+
+
+def test_eagle_example_with_stand_in_package(ckpt, tmp_path):
+    """Speculative-Decoding/EAGLE against a stand-in ``eagle`` package (the real one is not installable here: parity
+    with it is unpinned): ``EaModel`` with a base model, a one-layer draft head and ``eagenerate``; the script swaps in
+    the low-bit base model, converts the draft head and writes the answer file that speed.py summarizes."""
+    pkg = tmp_path / "site" / "eagle" / "model"
+    pkg.mkdir(parents=True)
+    (tmp_path / "site" / "eagle" / "__init__.py").write_text("")
+    (pkg / "__init__.py").write_text("")
+    (pkg / "ea_model.py").write_text('''
+import torch
+from torch import nn
+from transformers import AutoModelForCausalLM
+
+
+class EaLayer(nn.Module):
+    def __init__(self, hidden):
+        super().__init__()
+        self.fc = nn.Linear(2 * hidden, hidden, bias=False)
+        self.tree_mask_init = torch.eye(4)
+        self.position_ids = torch.zeros(4, dtype=torch.long)
+
+
+class EaModel(nn.Module):
+    def __init__(self, base):
+        super().__init__()
+        self.base_model = base
+        self.ea_layer = EaLayer(base.config.hidden_size)
+
+    @classmethod
+    def from_pretrained(cls, base_model_path=None, ea_model_path=None, total_token=60, depth=5, top_k=10, **kw):
+        kw.pop("low_cpu_mem_usage", None)
+        return cls(AutoModelForCausalLM.from_pretrained(base_model_path, **kw))
+
+    def eagenerate(self, input_ids, temperature=0.0, max_new_tokens=32, log=False):
+        assert type(self.ea_layer.fc).__name__ == "LowBitLinear" and self.ea_layer.tree_mask_init.is_cuda
+        out = self.base_model.generate(input_ids, max_new_tokens=max_new_tokens, do_sample=False)
+        return (out, out.shape[1] - input_ids.shape[1], 1) if log else out
+''')
+    q = tmp_path / "q.jsonl"
+    q.write_text("\n".join(json.dumps({"question_id": i, "turns": [f"w{i} w{i + 1} w{i + 2}", f"w{i + 5} w{i + 6}"]})
+                           for i in range(3)))
+    ans = tmp_path / "answers.jsonl"
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, str(tmp_path / "site"), os.environ.get("PYTHONPATH", "")]))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "GPU", "Speculative-Decoding", "EAGLE", "eagle_generate.py"),
+                        "--base-model-path", str(ckpt), "--ea-model-path", str(ckpt), "--question-file", str(q),
+                        "--answer-file", str(ans), "--max-new-token", "8"], env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    rows = [json.loads(line) for line in ans.read_text().splitlines()]
+    assert len(rows) == 2 and all(sum(x["choices"][0]["new_tokens"]) == 16 for x in rows)      # the first question warms up
+    out = _run("Speculative-Decoding/EAGLE/speed.py", "--jsonl-file", ans)
+    assert json.loads(out)["total_tokens"] == 32
