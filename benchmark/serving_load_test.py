@@ -95,6 +95,30 @@ def http_stream(url: str, prompt: str, max_new_tokens: int, timeout: float = 600
     return run
 
 
+def openai_stream(url: str, prompt: str, max_new_tokens: int, model: str = "default", chat: bool = False,
+                  timeout: float = 600.0) -> Callable[[RequestTrace], None]:
+    """One streamed ``/v1/completions`` (or ``/v1/chat/completions``) request of an OpenAI-compatible server (the
+    built-in one, the vLLM-style entry points, FastChat's): one time stamp per streamed chunk that carries text.
+    Reference client: docker/llm/serving/xpu/docker/vllm_online_benchmark.py:90-190."""
+    def run(trace: RequestTrace):
+        import requests
+        if chat:
+            body = {"model": model, "messages": [{"role": "user", "content": prompt}], "max_tokens": max_new_tokens,
+                    "temperature": 0.0, "stream": True}
+            route = "/v1/chat/completions"
+        else:
+            body = {"model": model, "prompt": prompt, "max_tokens": max_new_tokens, "temperature": 0.0, "stream": True}
+            route = "/v1/completions"
+        with requests.post(url.rstrip("/") + route, json=body, stream=True, timeout=timeout) as r:
+            r.raise_for_status()
+            for ev in sse_events(r.iter_lines()):
+                for choice in ev.get("choices") or []:
+                    text = (choice.get("delta") or {}).get("content") if chat else choice.get("text")
+                    if text:
+                        trace.token(time.perf_counter())
+    return run
+
+
 def run_level(send: Callable[[RequestTrace], None], concurrency: int, requests_per_client: int) -> Dict[str, float]:
     traces: List[RequestTrace] = []
     lock = threading.Lock()
@@ -133,9 +157,15 @@ def main(argv: Optional[List[str]] = None):
     ap.add_argument("--prompt-file", default=None, help="use this text as the prompt instead of a synthetic one")
     ap.add_argument("--max-new-tokens", type=int, default=128)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--api", default="tgi", choices=["tgi", "openai", "openai-chat"],
+                    help="tgi: /generate_stream; openai: /v1/completions; openai-chat: /v1/chat/completions (streamed)")
+    ap.add_argument("--model", default="default", help="model name sent with the OpenAI routes")
     args = ap.parse_args(argv)
     prompt = open(args.prompt_file).read() if args.prompt_file else synthetic_prompt(args.prompt_tokens)
-    send = http_stream(args.url, prompt, args.max_new_tokens)
+    if args.api == "tgi":
+        send = http_stream(args.url, prompt, args.max_new_tokens)
+    else:
+        send = openai_stream(args.url, prompt, args.max_new_tokens, model=args.model, chat=args.api == "openai-chat")
     rows = []
     for c in [int(x) for x in args.concurrency.split(",")]:
         row = run_level(send, c, args.requests_per_client)

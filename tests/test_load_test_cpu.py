@@ -42,3 +42,47 @@ def test_run_level_against_fake_stream():
     row = L.run_level(send, concurrency=4, requests_per_client=3)
     assert row["requests"] == 12 and row["failed"] == 0 and row["tokens"] == 60
     assert row["first_token_ms_avg"] >= 2.0 and row["tokens_per_s"] > 0
+
+
+def test_openai_routes_count_streamed_chunks(monkeypatch):
+    """``--api openai`` / ``openai-chat``: one time stamp per streamed chunk with text, on the right route and body"""
+    import json
+    import requests
+    seen = []
+
+    class Resp:
+        def __init__(self, lines):
+            self.lines = lines
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+        def raise_for_status(self):
+            pass
+
+        def iter_lines(self):
+            return iter(self.lines)
+
+    def fake_post(url, json=None, stream=None, timeout=None):
+        seen.append((url, json))
+        if url.endswith("/v1/chat/completions"):
+            chunks = [{"choices": [{"delta": {"role": "assistant"}}]}, {"choices": [{"delta": {"content": "a"}}]},
+                      {"choices": [{"delta": {"content": "b"}}]}, {"choices": [{"delta": {}, "finish_reason": "length"}]}]
+        else:
+            chunks = [{"choices": [{"text": "a"}]}, {"choices": [{"text": "b"}]}, {"choices": [{"text": "c"}]},
+                      {"choices": [{"text": "", "finish_reason": "length"}]}]
+        return Resp([("data: " + json_dumps(c)).encode() for c in chunks] + [b"data: [DONE]"])
+
+    json_dumps = json.dumps
+    monkeypatch.setattr(requests, "post", fake_post)
+    t = L.RequestTrace(time.perf_counter())
+    L.openai_stream("http://h:1/", "hello", 7, model="m")(t)
+    assert len(t.stamps) == 3 and seen[-1][0] == "http://h:1/v1/completions"
+    assert seen[-1][1]["max_tokens"] == 7 and seen[-1][1]["stream"] is True and seen[-1][1]["prompt"] == "hello"
+    t = L.RequestTrace(time.perf_counter())
+    L.openai_stream("http://h:1", "hello", 7, model="m", chat=True)(t)
+    assert len(t.stamps) == 2 and seen[-1][0].endswith("/v1/chat/completions")
+    assert seen[-1][1]["messages"] == [{"role": "user", "content": "hello"}]
