@@ -64,31 +64,92 @@ __device__ __forceinline__ void load_small(const void* W, int64_t ldw, int c, fl
 }
 
 constexpr int LORA_RB = 4;   // rows per workgroup
+constexpr int LORA_DW = 8;   // wavefronts of a lora_down workgroup (they split K)
 
-// one workgroup = LORA_RB rows; its four wavefronts split K, every lane keeps LORA_RB x R partial sums
+template <int DT>
+__device__ __forceinline__ void unpack8(const uint4v u, float (&v)[8]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if constexpr (DT == OUT_BF16) {
+      v[2 * q] = __uint_as_float(u[q] << 16);
+      v[2 * q + 1] = __uint_as_float(u[q] & 0xffff0000u);
+    } else {
+      union { uint32_t w; _Float16 h[2]; } c;
+      c.w = u[q];
+      v[2 * q] = (float)c.h[0];
+      v[2 * q + 1] = (float)c.h[1];
+    }
+  }
+}
+
+// one workgroup = LORA_RB rows; its eight wavefronts split K (one 512-column chunk per wavefront and pass: K = 4096 is a
+// single memory round trip), the requests of the next pass are issued before the products of the current one; every
+// lane keeps LORA_RB x R partial sums
 template <int R, bool WT, int DT>
-__global__ __launch_bounds__(256) void lora_down_kernel(const void* X, const void* W, void* T, int M, int K, int64_t ldx,
-                                                        int64_t ldw, float alpha) {
-  __shared__ float red[4][LORA_RB][R];
+__global__ __launch_bounds__(64 * LORA_DW) void lora_down_kernel(const void* X, const void* W, void* T, int M, int K, int64_t ldx,
+                                                               int64_t ldw, float alpha) {
+  __shared__ float red[LORA_DW][LORA_RB][R];
+  constexpr int NWV = WT ? 8 * (R / 8) : R;        // 16-byte requests of the small operand per chunk
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row0 = blockIdx.x * LORA_RB;
+  const uint16_t* Xp = (const uint16_t*)X;
+  const uint16_t* Wp = (const uint16_t*)W;
   float acc[LORA_RB][R];
 #pragma unroll
   for (int rb = 0; rb < LORA_RB; ++rb)
 #pragma unroll
     for (int j = 0; j < R; ++j) acc[rb][j] = 0.0f;
-  for (int c = (wave * 64 + lane) * 8; c < K; c += 4 * 64 * 8) {
-    float x[LORA_RB][8];
+  uint4v xr[2][LORA_RB], wr[2][NWV];
+  auto request = [&](int buf, int c) {
+    const int cc = min(c, K - 8);                  // past the end: a valid address, the products are skipped
 #pragma unroll
-    for (int rb = 0; rb < LORA_RB; ++rb) ld8<DT>(X, (int64_t)min(row0 + rb, M - 1) * ldx + c, x[rb]);
+    for (int rb = 0; rb < LORA_RB; ++rb) xr[buf][rb] = *(const uint4v*)(Xp + (int64_t)min(row0 + rb, M - 1) * ldx + cc);
+    if constexpr (!WT) {
+#pragma unroll
+      for (int j = 0; j < R; ++j) wr[buf][j] = *(const uint4v*)(Wp + j * ldw + cc);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j0 = 0; j0 < R / 8; ++j0) wr[buf][i * (R / 8) + j0] = *(const uint4v*)(Wp + (int64_t)(cc + i) * ldw + 8 * j0);
+    }
+  };
+  auto consume = [&](int buf) {
     float w[R][8];
-    load_small<R, WT, DT>(W, ldw, c, w);
+    if constexpr (!WT) {
 #pragma unroll
-    for (int rb = 0; rb < LORA_RB; ++rb)
+      for (int j = 0; j < R; ++j) unpack8<DT>(wr[buf][j], w[j]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j0 = 0; j0 < R / 8; ++j0) {
+          float t[8];
+          unpack8<DT>(wr[buf][i * (R / 8) + j0], t);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) w[8 * j0 + j][i] = t[j];
+        }
+    }
+#pragma unroll
+    for (int rb = 0; rb < LORA_RB; ++rb) {
+      float x[8];
+      unpack8<DT>(xr[buf][rb], x);
 #pragma unroll
       for (int j = 0; j < R; ++j)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[rb][j] += x[rb][i] * w[j][i];
+        for (int i = 0; i < 8; ++i) acc[rb][j] += x[i] * w[j][i];
+    }
+  };
+  constexpr int STEP = LORA_DW * 64 * 8;
+  int c = (wave * 64 + lane) * 8;
+  request(0, c);
+  for (; c < K; c += 2 * STEP) {
+    request(1, c + STEP);
+    consume(0);
+    if (c + STEP < K) {
+      request(0, c + 2 * STEP);
+      consume(1);
+    }
   }
 #pragma unroll
   for (int rb = 0; rb < LORA_RB; ++rb)
@@ -101,7 +162,9 @@ __global__ __launch_bounds__(256) void lora_down_kernel(const void* X, const voi
   if (threadIdx.x < LORA_RB * R) {
     const int rb = threadIdx.x / R, j = threadIdx.x % R;
     if (row0 + rb < M) {
-      const float s = red[0][rb][j] + red[1][rb][j] + red[2][rb][j] + red[3][rb][j];
+      float s = 0.0f;
+#pragma unroll
+      for (int w = 0; w < LORA_DW; ++w) s += red[w][rb][j];
       ((uint16_t*)T)[(int64_t)(row0 + rb) * R + j] = to16<DT>(alpha * s);
     }
   }
@@ -171,7 +234,7 @@ extern "C" int bigdl_lora_down(const void* X, const void* W, void* T, int M, int
   if (M <= 0 || K <= 0 || (K & 7) || (ldx & 7) || (R != 8 && R != 16) || (dt != OUT_F16 && dt != OUT_BF16) ||
       ((uintptr_t)X & 15) || ((uintptr_t)W & 15) || (wt ? ldw < R || (ldw & 7) : ldw < K || (ldw & 7)))
     return -1;
-  const dim3 grid((M + LORA_RB - 1) / LORA_RB), block(256);
+  const dim3 grid((M + LORA_RB - 1) / LORA_RB), block(64 * LORA_DW);
 #define BIGDL_LD(R_, WT_, DT_) hipLaunchKernelGGL((lora_down_kernel<R_, WT_, DT_>), grid, block, 0, st, X, W, T, M, K, ldx, ldw, alpha)
   if (R == 8) {
     if (wt) { if (dt == OUT_BF16) BIGDL_LD(8, true, OUT_BF16); else BIGDL_LD(8, true, OUT_F16); }
