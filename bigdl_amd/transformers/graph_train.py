@@ -48,6 +48,10 @@ class GraphedTrainStep:
                  bucket_mb: int = 64, grad_accum: int = 1):
         if not example_ids.is_cuda:
             raise ValueError("graph capture needs the batch on the GPU")
+        if any(getattr(m, "gradient_checkpointing", False) for m in model.modules()):
+            # recomputation saves and restores the random-number state on the host, which a capture cannot contain
+            raise ValueError("activation checkpointing cannot be captured: prepare the model with "
+                             "use_gradient_checkpointing=False (a 7B QLoRA step at 4 x 256 tokens holds 3 GB of activations)")
         import torch.distributed as dist
         self.model, self.optimizer, self.group = model, optimizer, group
         self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1

@@ -119,3 +119,17 @@ def test_graphed_step_needs_capturable_optimizer():
     opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-3)
     with pytest.raises(ValueError):
         GraphedTrainStep(model, opt, torch.randint(3, 512, (2, 32)).cuda())
+
+
+def test_graphed_step_refuses_activation_checkpointing():
+    from bigdl_amd.transformers.graph_train import GraphedTrainStep
+    model = _model()
+    inner = model
+    for _ in range(4):                       # the wrapper(s) around the HuggingFace model
+        if hasattr(inner, "gradient_checkpointing_enable"):
+            break
+        inner = getattr(inner, "base_model", getattr(inner, "model", inner))
+    inner.gradient_checkpointing_enable()
+    with pytest.raises(ValueError, match="checkpointing"):
+        GraphedTrainStep(model, torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=0.1),
+                         torch.randint(3, 512, (2, 32)).cuda())
