@@ -972,6 +972,14 @@ static inline int gemv_cu_count() {
 #ifndef GEMV_CU_ENABLE
 #define GEMV_CU_ENABLE 0
 #endif
+// ... and at run time: the CU-resident form for row counts in [gemv_cu_rows_lo, gemv_cu_rows_hi] (0, 0 = never).  With
+// several rows every tile-per-workgroup kernel stages all rows of x (2 bytes of x per byte of 4-bit weights at 8 rows);
+// the CU-resident form stages them once per CU.  Llama-2-7B decode step at 1024-token context, one MI355X, tile form ->
+// CU form: 2 rows 1.94 -> 2.23 ms, 4: 2.56 -> 2.75, 6: 3.33 -> 3.25, 7: 3.45 -> 3.52, 8: 3.25 -> 3.01, 9: 3.84 -> 3.45,
+// 10: 3.88 -> 3.59, 12: 4.03 -> 3.75, 14: 4.15 -> 4.10 (16 rows of K = 4096 no longer fit next to the partial sums).
+// Hence 8 .. 13 rows by default (bigdl_gemv_cu_rows / BIGDL_GEMV_CU_ROWS=lo,hi change it).
+inline int& gemv_cu_rows_lo() { static int v = 8; return v; }
+inline int& gemv_cu_rows_hi() { static int v = 13; return v; }
 
 template <int QT, int MT, bool GATE_UP>
 static int launch_x(const GemvArgs& a_in, hipStream_t st) {
@@ -1008,7 +1016,9 @@ static int launch_x(const GemvArgs& a_in, hipStream_t st) {
   if constexpr (MT == 1) {
     // CU-resident form: one workgroup per CU streams all its output tiles (see the kernel's comment).  Needs x and
     // at least one tile's partial sums in LDS.
-    if (GEMV_CU_ENABLE && a.slot_expert == nullptr && (GEMV_CU_ENABLE == 1 || (a.N + 15) / 16 <= gemv_cu_count())) {
+    const bool cu_rows = a.M >= gemv_cu_rows_lo() && a.M <= gemv_cu_rows_hi();
+    if ((GEMV_CU_ENABLE || cu_rows) && a.slot_expert == nullptr &&
+        (GEMV_CU_ENABLE == 1 || cu_rows || (a.N + 15) / 16 <= gemv_cu_count())) {
       const int n_tiles = (a.N + 15) / 16;
       const int G = n_tiles < gemv_cu_count() ? n_tiles : gemv_cu_count();
       const int cnt_max = (n_tiles + G - 1) / G;

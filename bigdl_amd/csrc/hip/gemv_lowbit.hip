@@ -150,3 +150,9 @@ extern "C" int bigdl_gemv_lowbit_moe_sum(const void* x, const void* w, void* out
   a.n_slots = tokens; a.slot_cat = top_k;
   return dispatch(a, qtype, stream);
 }
+
+// Row counts [lo, hi] for which the skinny products take the CU-resident form (0, 0: never)
+extern "C" void bigdl_gemv_cu_rows(int lo, int hi) {
+  gemv_cu_rows_lo() = lo;
+  gemv_cu_rows_hi() = hi;
+}

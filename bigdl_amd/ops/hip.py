@@ -40,6 +40,12 @@ def lib():
         vp, i64, ci, cf = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
         L.bigdl_gemv_lowbit.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, cf, cf, ci, ci, ci, ci, ci, ci, ci, ci, vp, ci, ci, ci, ci, ci, ci, vp]
         L.bigdl_gemv_f16.argtypes = [vp] * 8 + [cf, cf] + [ci] * 7 + [vp]
+        L.bigdl_gemv_cu_rows.argtypes = [ci, ci]
+        L.bigdl_gemv_cu_rows.restype = None
+        cu_rows = os.environ.get("BIGDL_GEMV_CU_ROWS")
+        if cu_rows:
+            lo_, hi_ = (int(v) for v in cu_rows.split(","))
+            L.bigdl_gemv_cu_rows(lo_, hi_)
         L.bigdl_gemv_f16_tune.argtypes = [ci]
         L.bigdl_gemv_f16_tune.restype = None
         L.bigdl_gemv_lowbit_ln.argtypes = [vp] * 8 + [cf] + [ci] * 8 + [vp] * 5
