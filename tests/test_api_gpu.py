@@ -202,6 +202,11 @@ def test_lookup_and_speculative_on_native_engine(tiny):
     assert (out2 == ref).float().mean() > 0.9
     out3 = q.generate(ids, max_new_tokens=12, do_sample=True, top_k=10)
     assert out3.shape[1] == ids.shape[1] + 12
+    # a draft that runs one of its two layers (layer skipping on the shared cache): still the target's own tokens
+    full_pair = q._spec_engine
+    out4 = q.generate(ids, max_new_tokens=24, max_step_draft=4, th_stop_draft=0.0, min_step_draft=1, draft_layers=1)
+    assert q._spec_engine is not full_pair and len(q._spec_engine.draft.layers) == 1 and q._spec_engine.draft.cache_layer == [0]
+    assert out4.shape == ref.shape and (out4 == ref).float().mean() > 0.9 and q.n_drafted > 0
 
 
 def test_fp8_kv_cache_module_path(tiny, monkeypatch):

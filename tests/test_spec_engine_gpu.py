@@ -109,3 +109,48 @@ def test_oracle_acceptance_sets_the_accepted_length():
     assert spec.n_matched == spec.n_drafted and max(spec.draft_num) == 5        # every round accepts all, k grows to the cap
     spec.generate(ids, max_new_tokens=36, oracle_accept=0.0)
     assert spec.n_matched == 0
+
+
+def test_default_kept_layers():
+    from bigdl_amd.models.spec_engine import default_kept_layers
+    for n, k in ((32, 12), (32, 8), (32, 16), (32, 4), (32, 1), (6, 5), (80, 24), (4, 9)):
+        kept = default_kept_layers(n, k)
+        assert len(kept) == min(k, n) and kept == sorted(set(kept)) and kept[0] == 0 and kept[-1] <= n - 1
+        if 4 <= k < n:
+            assert kept[:2] == [0, 1] and kept[-2:] == [n - 2, n - 1]
+
+
+@pytest.mark.parametrize("kept", [[0, 1, 3], [0, 5], [0, 1, 2, 3, 4, 5]])
+@pytest.mark.parametrize("kv_fp8", [False, True])
+def test_layer_skipping_draft_shares_the_cache_and_keeps_the_output(kept, kv_fp8):
+    """a draft that runs a subset of the (8-bit copy of the) target's layers on the target's own cache rows: the output
+    is still the target's greedy continuation; with all layers kept it is the full-depth draft"""
+    from bigdl_amd import qtypes as Q
+    from bigdl_amd.models.decoder import DecoderConfig, build_random_decoder
+    from bigdl_amd.models.spec_engine import SelfSpeculativeEngine, layer_skip_draft_of, quantized_draft_of
+    cfg = DecoderConfig(vocab_size=2048, hidden_size=1024, intermediate_size=2816, num_layers=6, num_heads=8, num_kv_heads=4,
+                        head_dim=128, max_position=2048)
+    target = build_random_decoder(cfg, Q.FP16, device="cuda", seed=7)
+    full = quantized_draft_of(target, Q.SYM_INT8)
+    draft = layer_skip_draft_of(full, kept)
+    assert draft.cache_layer == kept and len(draft.layers) == len(kept) and draft.layers[-1] is full.layers[kept[-1]]
+    spec = SelfSpeculativeEngine(target, draft, max_step_draft=4)
+    ids = torch.randint(3, 2048, (1, 29), generator=torch.Generator().manual_seed(2)).cuda()
+    got = spec.generate(ids, max_new_tokens=32, kv_fp8=kv_fp8)
+    assert got.shape == (1, 29 + 32) and torch.equal(got[:, :29], ids)
+    # every generated token is the target's choice at its position: teacher-forced dense fp32 logits over the produced
+    # sequence; a token may differ from the dense argmax only by a rounding-sized logit gap (one-row and multi-row fp16
+    # kernels sum in different orders, the e5m2 cache rounds keys and values)
+    from bigdl_amd.models.decoder import dense_reference_logits
+    ref = dense_reference_logits(target, got[:, :-1])[0, -32:]
+    new = got[0, -32:]
+    gap = ref.max(-1).values - ref.gather(1, new[:, None]).squeeze(1)
+    assert bool((gap <= 0.25 * ref.std(-1)).all()) and float((ref.argmax(-1) == new).float().mean()) >= 0.75
+    assert draft.cache is target.cache and spec.n_drafted > 0
+    if len(kept) == 6:
+        ref = SelfSpeculativeEngine(target, full, max_step_draft=4)
+        ref.generate(ids, max_new_tokens=32, kv_fp8=kv_fp8)
+        assert (spec.n_matched, spec.n_drafted) == (ref.n_matched, ref.n_drafted)
+        assert spec.n_matched / spec.n_drafted > 0.5
+    with pytest.raises(AssertionError):
+        layer_skip_draft_of(full, [3, 1])
