@@ -17,6 +17,9 @@ if __name__ == "__main__":
     ap.add_argument("--prompt", default="Explain how a transformer decoder generates text, step by step.")
     ap.add_argument("--n-predict", type=int, default=128)
     ap.add_argument("--max-draft", type=int, default=6)
+    ap.add_argument("--draft-layers", default=None,
+                    help="the int4 draft runs only this many of its layers (or the comma-separated layer indices given) on the "
+                         "target's cache: a cheaper draft; how many layers a model lets a draft skip is found by trying")
     a = ap.parse_args()
     # speculative=True: fp16 target + sym_int4 draft of the same checkpoint, generate() routes to the speculative loop
     model = AutoModelForCausalLM.from_pretrained(a.repo_id_or_model_path, load_in_low_bit="fp16", optimize_model=True,
@@ -26,7 +29,8 @@ if __name__ == "__main__":
     ids = tok(a.prompt, return_tensors="pt").input_ids.to("cuda")
     with torch.inference_mode():
         for _ in range(2):
-            out = model.generate(ids, max_new_tokens=a.n_predict, max_step_draft=a.max_draft, do_sample=False)
+            out = model.generate(ids, max_new_tokens=a.n_predict, max_step_draft=a.max_draft, do_sample=False,
+                                 **({"draft_layers": a.draft_layers} if a.draft_layers else {}))
     print(tok.decode(out[0, ids.shape[1]:], skip_special_tokens=True))
     n = model.n_token_generated
     print(f"-- first token {model.first_token_time * 1e3:.1f} ms; {n - 1} more tokens in {model.e2e_time_without_first:.3f} s "

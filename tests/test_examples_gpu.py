@@ -236,6 +236,12 @@ def test_all_in_one_tensor_parallel_mode(ckpt, tmp_path):
     assert any(f.startswith("deepspeed_optimize_model_gpu-results") for f in os.listdir(tmp_path))
 
 
+def test_engine_speculative_example_with_layer_skipping_draft(ckpt):
+    out = _run("Speculative-Decoding/engine_speculative.py", "--repo-id-or-model-path", ckpt, "--prompt", "w1 w2 w3 w4",
+               "--n-predict", 16, "--max-draft", 3, "--draft-layers", 1)
+    assert "drafted" in out and "tokens per round" in out
+
+
 def test_eagle_example_with_stand_in_package(ckpt, tmp_path):
     """Speculative-Decoding/EAGLE against a stand-in ``eagle`` package (the real one is not installable here: parity
     with it is unpinned): ``EaModel`` with a base model, a one-layer draft head and ``eagenerate``; the script swaps in
