@@ -324,3 +324,44 @@ def layer_skip_draft_of(engine, kept_layers):
                           embed_norm=engine.embed_norm)
     draft.cache_layer = [base[i] for i in kept]
     return draft
+
+
+def search_kept_layers(target, full_draft, prompts, keep: int, max_new_tokens: int = 48, max_step_draft: int = 4,
+                       candidates_per_round: Optional[int] = None, kv_fp8=False, log=None):
+    """Which ``keep`` layers a layer-skipping draft of ``full_draft`` should run for ``target``: greedy backward
+    elimination on calibration prompts (token id tensors [1, S]).  Starting from all layers, the layer whose removal
+    costs the least acceptance is dropped, until ``keep`` remain; the acceptance of a candidate set is the share of
+    its draft tokens that the target accepts while generating ``max_new_tokens`` per prompt with that draft (the
+    selection criterion of Zhang et al., "Draft & Verify", with a greedy search in place of their Bayesian one).
+    ``candidates_per_round`` limits how many removals are tried per round (evenly spread over the kept layers; the first
+    and the last layer are never candidates).  Returns ``(kept_layers, acceptance)``.  One evaluation is one short
+    generation per prompt: for a 32-layer model and 16 kept layers about 400 of them with every candidate tried."""
+    n = len(full_draft.layers)
+    kept = list(range(n))
+
+    def acceptance(layers):
+        draft = layer_skip_draft_of(full_draft, layers) if len(layers) < n else full_draft
+        spec = SelfSpeculativeEngine(target, draft, max_step_draft=max_step_draft, adapt=False)
+        drafted = matched = 0
+        for ids in prompts:
+            spec.generate(ids, max_new_tokens=max_new_tokens, kv_fp8=kv_fp8)
+            drafted += spec.n_drafted
+            matched += spec.n_matched
+        return matched / max(1, drafted)
+
+    score = acceptance(kept)
+    while len(kept) > max(1, keep):
+        pool = [i for i in kept if i not in (kept[0], kept[-1])] or kept[1:]
+        if candidates_per_round and len(pool) > candidates_per_round:
+            step = len(pool) / candidates_per_round
+            pool = [pool[int(j * step)] for j in range(candidates_per_round)]
+        best = None
+        for cand in pool:
+            trial = [i for i in kept if i != cand]
+            sc = acceptance(trial)
+            if best is None or sc > best[0]:
+                best = (sc, cand, trial)
+        score, dropped, kept = best
+        if log is not None:
+            log(f"dropped layer {dropped}: {len(kept)} layers, acceptance {score:.3f}")
+    return kept, score

@@ -154,3 +154,31 @@ def test_layer_skipping_draft_shares_the_cache_and_keeps_the_output(kept, kv_fp8
         assert spec.n_matched / spec.n_drafted > 0.5
     with pytest.raises(AssertionError):
         layer_skip_draft_of(full, [3, 1])
+
+
+def test_search_kept_layers_keeps_the_layers_that_matter():
+    """greedy elimination on a 6-layer pair whose layer 3 was made (almost) an identity in the target and the draft: it
+    is the first layer the search drops, and the reported acceptance is reproducible"""
+    from bigdl_amd import qtypes as Q
+    from bigdl_amd.models.decoder import DecoderConfig, build_random_decoder
+    from bigdl_amd.models.spec_engine import (SelfSpeculativeEngine, layer_skip_draft_of, quantized_draft_of,
+                                              search_kept_layers)
+    cfg = DecoderConfig(vocab_size=2048, hidden_size=1024, intermediate_size=2816, num_layers=6, num_heads=8, num_kv_heads=4,
+                        head_dim=128, max_position=2048)
+    target = build_random_decoder(cfg, Q.FP16, device="cuda", seed=9)
+    for name in ("o", "down"):                      # layer 3 adds (nearly) nothing to the residual stream
+        lin = getattr(target.layers[3], name)
+        lin.w.mul_(1e-3)
+    full = quantized_draft_of(target, Q.SYM_INT8)
+    prompts = [torch.randint(3, 2048, (1, 24), generator=torch.Generator().manual_seed(s_)).cuda() for s_ in (1, 2)]
+    seen = []
+    kept, score = search_kept_layers(target, full, prompts, keep=5, max_new_tokens=24, log=seen.append)
+    assert kept == [0, 1, 2, 4, 5] and len(seen) == 1 and "dropped layer 3" in seen[0]
+    spec = SelfSpeculativeEngine(target, layer_skip_draft_of(full, kept), max_step_draft=4, adapt=False)
+    drafted = matched = 0
+    for ids in prompts:
+        spec.generate(ids, max_new_tokens=24)
+        drafted, matched = drafted + spec.n_drafted, matched + spec.n_matched
+    assert abs(matched / drafted - score) < 1e-9 and score > 0.4
+    kept2, _ = search_kept_layers(target, full, prompts[:1], keep=3, max_new_tokens=12, candidates_per_round=2)
+    assert len(kept2) == 3 and kept2[0] == 0 and kept2[-1] == 5
