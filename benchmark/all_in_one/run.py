@@ -71,9 +71,48 @@ def run_native_engine_gpu(repo_id, local_model_hub, in_out_pairs, warm_up, num_t
     return rows
 
 
+def _synthetic_hf(name, device):
+    """random-init HuggingFace Llama of a named shape in fp16 (no checkpoints on the test boxes): what a checkpoint of
+    that architecture gives ``from_pretrained``, drawn on the device and kept on the host"""
+    from transformers import LlamaConfig, LlamaForCausalLM
+    d = _synthetic_cfg(name)
+    cfg = LlamaConfig(vocab_size=d.vocab_size, hidden_size=d.hidden_size, intermediate_size=d.intermediate_size,
+                      num_hidden_layers=d.num_layers, num_attention_heads=d.num_heads, num_key_value_heads=d.num_kv_heads,
+                      max_position_embeddings=d.max_position, rms_norm_eps=d.rms_eps, rope_theta=d.rope_theta,
+                      tie_word_embeddings=False)
+    with torch.device("meta"):
+        model = LlamaForCausalLM(cfg)
+    model = model.to_empty(device="cpu").half()
+    gen_dev = device if device != "cpu" else "cpu"
+    g = torch.Generator(device=gen_dev).manual_seed(0)
+    with torch.no_grad():
+        for _, p in model.named_parameters():
+            if p.dim() == 1:
+                p.fill_(1.0)
+            else:
+                p.copy_((torch.randn(p.shape, device=gen_dev, generator=g, dtype=torch.float32) * 0.02).half())
+        for m in model.modules():          # buffers made on the meta device (rotary inv_freq) are uninitialised
+            if hasattr(m, "inv_freq"):
+                fresh = type(m)(cfg)
+                m.inv_freq = fresh.inv_freq.float()
+                if hasattr(m, "original_inv_freq"):
+                    m.original_inv_freq = fresh.inv_freq.float()
+    model.generation_config.eos_token_id = None
+    model.generation_config.pad_token_id = 0
+    return model.eval()
+
+
 def _load_hf(repo_id, hub, low_bit, conf, device, plain=False, tensor_parallel=False, **extra):
     from transformers import AutoTokenizer
     from bigdl_amd.transformers import AutoModelForCausalLM
+    if repo_id.startswith("synthetic:") and not tensor_parallel:
+        model = _synthetic_hf(repo_id.split(":", 1)[1], device)
+        if not plain:
+            from bigdl_amd.optimize import optimize_model
+            model = optimize_model(model, low_bit=low_bit, cpu_embedding=conf.get("cpu_embedding", False), **extra)
+        if device != "cpu":
+            model = model.half().to(device)
+        return model.eval(), None
     path = os.path.join(hub, os.path.basename(repo_id)) if hub else repo_id
     dt = torch.float16 if conf.get("use_fp16_torch_dtype", True) and device != "cpu" else "auto"
     if plain:
