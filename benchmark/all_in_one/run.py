@@ -31,7 +31,9 @@ SYNTHETIC = {}
 
 def _synthetic_cfg(name):
     from bigdl_amd.models import decoder as D
-    table = {"llama2-7b": D.LLAMA2_7B, "tinyllama": D.TINY_LLAMA, "mixtral-8x7b": D.MIXTRAL_8X7B}
+    table = {"llama2-7b": D.LLAMA2_7B, "tinyllama": D.TINY_LLAMA, "mixtral-8x7b": D.MIXTRAL_8X7B,
+             "tiny": dict(vocab_size=320, hidden_size=256, intermediate_size=512, num_layers=2, num_heads=4, num_kv_heads=2,
+                          head_dim=64, rms_eps=1e-5, max_position=2048, model_type="llama")}      # test-size llama
     return D.DecoderConfig(**table[name])
 
 

@@ -48,6 +48,28 @@ def test_benchmark_config_schema():
     assert "1024-128" in conf["in_out_pairs"]
 
 
+def test_all_in_one_harness_on_a_synthetic_model(tmp_path):
+    """benchmark/all_in_one/run.py with a ``synthetic:`` repo id through a HuggingFace front-door mode on the host: the
+    reference's CSV columns, one row per in / out pair (no checkpoint needed)"""
+    import csv
+    import subprocess
+    import sys
+    cfg = tmp_path / "config.yaml"
+    cfg.write_text(yaml.safe_dump({"repo_id": ["synthetic:tiny"], "local_model_hub": "", "warm_up": 1, "num_trials": 1,
+                                   "num_beams": 1, "low_bit": "sym_int4", "batch_size": 1, "in_out_pairs": ["8-4", "16-4"],
+                                   "test_api": ["transformer_int4"], "cpu_embedding": False, "streaming": False,
+                                   "use_fp16_torch_dtype": True, "task": "continuation"}))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "benchmark", "all_in_one", "run.py"), "-c", str(cfg), "-o",
+                        str(tmp_path)], capture_output=True, text=True, timeout=600, env=dict(os.environ, PYTHONPATH=ROOT))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    files = [f for f in os.listdir(tmp_path) if f.endswith(".csv")]
+    assert len(files) == 1 and files[0].startswith("transformer_int4-results-")
+    rows = list(csv.DictReader(open(tmp_path / files[0])))
+    assert [x["input/output tokens"] for x in rows] == ["8-4", "16-4"]
+    assert all(float(x["2+ avg latency (ms/token)"]) > 0 and x["actual input/output tokens"] == x["input/output tokens"]
+               for x in rows)
+
+
 def test_llm_patch_rebinds_names_for_unmodified_scripts():
     """After llm_patch(train=True) a stock script's ``from transformers import AutoModelForCausalLM`` and
     ``from peft import LoraConfig, get_peft_model`` resolve to this library (PEFT itself is optional)."""
