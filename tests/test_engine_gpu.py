@@ -407,3 +407,29 @@ def test_attention_sink_eviction_re_rotates_the_kept_keys(start):
     logits, _ = eng.decode(tok)
     assert torch.isfinite(logits).all() and eng.cache.host_len == start + recent + 1
     assert eng.evict_middle(start_size=start, recent_size=recent + 8) == 0                 # fits: nothing to drop
+
+
+@pytest.mark.parametrize("kv_fp8", [False, True])
+def test_short_prompts_replay_a_captured_prompt_pass(monkeypatch, kv_fp8):
+    """prompts of up to 128 tokens are padded to a length bucket and run as one captured pass: same tokens as the eager
+    pass, for lengths at, inside and across bucket borders, with buckets reused between calls"""
+    import bigdl_amd.models.decoder as D
+    from bigdl_amd import qtypes as Q
+    cfg = D.DecoderConfig(vocab_size=512, hidden_size=256, intermediate_size=512, num_layers=2, num_heads=4, num_kv_heads=2,
+                          head_dim=64, max_position=1024)
+    model = D.build_random_decoder(cfg, Q.SYM_INT4, device="cuda", seed=3)
+    gen = torch.Generator().manual_seed(5)
+    for s in (128, 5, 16, 17, 40, 33, 100):          # (the longest first: a cache that has to grow drops its captured passes)
+        ids = torch.randint(3, 512, (1, s), generator=gen).cuda()
+        monkeypatch.setenv("BIGDL_PREFILL_GRAPH", "0")
+        want = model.generate(ids, max_new_tokens=12, kv_fp8=kv_fp8)
+        monkeypatch.setenv("BIGDL_PREFILL_GRAPH", "1")
+        got = model.generate(ids, max_new_tokens=12, kv_fp8=kv_fp8)
+        assert torch.equal(got, want), (s, got[0, s:].tolist(), want[0, s:].tolist())
+    assert sorted(model._prefill_graphs) == [16, 32, 48, 128]
+    # a longer prompt takes the eager pass; a batch of two as well
+    ids = torch.randint(3, 512, (1, 130), generator=gen).cuda()
+    model.generate(ids, max_new_tokens=4, kv_fp8=kv_fp8)
+    assert sorted(model._prefill_graphs) == [16, 32, 48, 128]
+    model.generate(torch.randint(3, 512, (2, 20), generator=gen).cuda(), max_new_tokens=4, kv_fp8=kv_fp8)
+    assert not model._prefill_graphs          # (a cache of another shape: captured passes of the old one are dropped)
