@@ -102,6 +102,22 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
+// wave_sum with the four in-row steps as DPP moves (a few cycles each) and only the two cross-row steps as LDS-routed
+// permutes: the chain of six dependent permutes of wave_sum is most of a microsecond where a kernel waits on it.  (Another
+// summation order than wave_sum: the two are not interchangeable where results are compared bit for bit.)
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += dpp_mov<0xB1>(v);     // quad_perm [1, 0, 3, 2]
+  v += dpp_mov<0x4E>(v);     // quad_perm [2, 3, 0, 1]
+  v += dpp_mov<0x141>(v);    // row_half_mirror
+  v += dpp_mov<0x140>(v);    // row_mirror
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));

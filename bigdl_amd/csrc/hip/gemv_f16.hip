@@ -118,7 +118,7 @@ __global__ __launch_bounds__(F16_NW * 64) void gemv_f16_kernel(GemvF16Args a) {
         *(uint4v*)(xs + m * XS + i * 8) = xv.q;
       }
       if constexpr (NORM) {
-        s = wave_sum(s);
+        s = wave_sum_dpp(s);
         if (lane == 0) ssq_sh[wave][m] = s;
       }
     }
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(FR_NW * 64) void gemv_f16_rows_kernel(GemvF16Args a
     }
     for (int z = per_row + tid; z * 8 < XS; z += FR_NW * 64) *(uint4v*)(xs + m * XS + z * 8) = uint4v{0, 0, 0, 0};
     if constexpr (NORM) {
-      s = wave_sum(s);
+      s = wave_sum_dpp(s);
       if (lane == 0) ssq_sh[wave][m] = s;
     }
   }
@@ -331,8 +331,8 @@ __global__ __launch_bounds__(FR_NW * 64) void gemv_f16_rows_kernel(GemvF16Args a
       for (int ww = 0; ww < FR_NW; ++ww) s += ssq_sh[ww][m];
       rs = rsqrtf(s / (float)a.K + a.eps);
     }
-    float v = wave_sum(acc[0][m]) * rs + b1;
-    if constexpr (GATE_UP) v = act_apply(a.act, v) * (wave_sum(acc[1][m]) * rs + b2);
+    float v = wave_sum_dpp(acc[0][m]) * rs + b1;
+    if constexpr (GATE_UP) v = act_apply(a.act, v) * (wave_sum_dpp(acc[1][m]) * rs + b2);
     else v = act_apply(a.act, v);
     if (lane == m && nraw < a.N) {
       const int64_t o = (int64_t)m * a.ldo + n;

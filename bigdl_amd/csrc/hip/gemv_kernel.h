@@ -556,10 +556,10 @@ __global__ __launch_bounds__(NW * 64, LEAN ? 6 : (NW + 3) / 4) void gemv_t16_ker
       const bool inside = col < a.K;
       if (!inside) v = zero8;
       if (norm) {
-        const float ssq = wave_sum(frag_sumsq(v));
+        const float ssq = wave_sum_dpp(frag_sumsq(v));       // (on the path to the staging barrier)
         if (lane == 0) ssq_sh[wave * (MT * 16) + m] += ssq;
         if (lnorm) {
-          const float sm = wave_sum(frag_sum(v));
+          const float sm = wave_sum_dpp(frag_sum(v));
           if (lane == 0) sum_sh[wave * (MT * 16) + m] += sm;
         }
         if (a.gamma_offset != 0.0f) g8 = g8 + (_Float16)a.gamma_offset;

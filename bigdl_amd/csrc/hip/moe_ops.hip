@@ -199,22 +199,6 @@ __global__ __launch_bounds__(256) void moe_route_kernel(const void* logits, int*
     route_pick(v, mx, t, E, top_k, normalize, lo, hi, sigmoid_scores, ids, weights);
 }
 
-// sum over the wavefront with the four in-row steps as DPP moves (a few cycles each) and only the two cross-row steps as
-// LDS-routed permutes: the chain of six dependent permutes of wave_sum is most of a microsecond
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float wave_sum_dpp(float v) {
-  v += dpp_mov<0xB1>(v);     // quad_perm [1, 0, 3, 2]
-  v += dpp_mov<0x4E>(v);     // quad_perm [2, 3, 0, 1]
-  v += dpp_mov<0x141>(v);    // row_half_mirror
-  v += dpp_mov<0x140>(v);    // row_mirror
-  v += __shfl_xor(v, 16);
-  v += __shfl_xor(v, 32);
-  return v;
-}
-
 // Selection by rank counting, one thread per expert (E <= NR_WAVES * 64), every cross-thread step through LDS broadcasts
 // instead of dependent cross-lane permutes: p = softmax / sigmoid of the logits, choice = p + bias, optional group limit
 // (groups ranked by their best or their two best choices, choices outside the topk_group best groups become 0), rank of
