@@ -1049,7 +1049,7 @@ static int launch_x(const GemvArgs& a_in, hipStream_t st) {
   }
   // 16 wavefronts when the grid is small (about one workgroup per CU) and every wavefront still gets
   // at least two k-tiles: halves the per-wavefront instruction stream of the latency-bound small GEMVs
-  const bool wide = MT == 1 && !GATE_UP && xbytes <= GEMV_XLDS_LIMIT && grid.x <= 256 && grid.y == 1 && Kp / 128 >= 64;
+  const bool wide = MT == 1 && !GATE_UP && xbytes <= GEMV_XLDS_LIMIT && grid.x <= 256 && grid.y == 1 && Kp / 128 >= 32;
   if (a.att_ws != nullptr) {
     // split-KV attention partials combined in the staging prologue (host entry: x fits GEMV_XLDS_LIMIT, at most 16 rows)
     if constexpr (MT == 1 && !GATE_UP) {
