@@ -1419,7 +1419,7 @@ class NativeDecoder:
         return (self.use_graph and b == 1 and s <= self.PREFILL_BUCKETS[-1] and inputs_embeds is None
                 and mrope_positions is None and self.stage_first and self.stage_last and self.tp_group is None
                 and not self.compress_kv and not getattr(self, "prefill_fp8", False)
-                and self.cache.host_len == 0 and self.cache.slot_len is None
+                and self.cache.host_len == 0 and self.cache.slot_len is None and not self.cache.int4
                 and self.PREFILL_BUCKETS[-1] <= self.cache.capacity     # (pad rows are written up to the bucket's length)
                 and os.environ.get("BIGDL_PREFILL_GRAPH", "1") != "0"
                 and not any(lw.moe is not None or lw.mla is not None for lw in self.layers))
