@@ -1016,7 +1016,12 @@ static int launch_x(const GemvArgs& a_in, hipStream_t st) {
   if constexpr (MT == 1) {
     // CU-resident form: one workgroup per CU streams all its output tiles (see the kernel's comment).  Needs x and
     // at least one tile's partial sums in LDS.
-    const bool cu_rows = a.M >= gemv_cu_rows_lo() && a.M <= gemv_cu_rows_hi();
+    // (products with fewer tiles than CUs stay in the tile form: nothing to share, and half-empty workgroups of 16
+    // wavefronts: TinyLlama's 2048-wide products lose 10 - 20 % of a decode step in the CU form)
+    // ... and so do short reductions: with K = 2048 each of the 16 wavefronts gets one k-tile per output tile and nothing to
+    // overlap (same model: gate / up alone in the CU form still cost 14 %)
+    const bool cu_rows = a.M >= gemv_cu_rows_lo() && a.M <= gemv_cu_rows_hi() && (a.N + 15) / 16 >= gemv_cu_count() &&
+                         (a.K >> 7) >= 24;
     if ((GEMV_CU_ENABLE || cu_rows) && a.slot_expert == nullptr &&
         (GEMV_CU_ENABLE == 1 || cu_rows || (a.N + 15) / 16 <= gemv_cu_count())) {
       const int n_tiles = (a.N + 15) / 16;
