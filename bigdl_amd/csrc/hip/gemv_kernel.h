@@ -940,8 +940,10 @@ __global__ __launch_bounds__(NW * 64, LEAN ? 6 : (NW + 3) / 4) void gemv_t16_ker
 constexpr size_t GEMV_XLDS_LIMIT = 48 * 1024;   // stage x in LDS when it fits this budget
 // ... or, for at most 8 rows, this one (K = 11008 down projections at 3-4 rows: 21.5 -> about 12 us per launch; K = 4096
 // at 6-8 rows; decode step 2.22 -> 1.92 ms at batch 4 and 2.98 -> 2.69 ms at batch 8).  With more rows the single
-// workgroup per CU that such a footprint allows loses more than the LDS staging wins (measured at 16 rows).
-constexpr size_t GEMV_XLDS_LIMIT_FEW_ROWS = 100 * 1024;
+// workgroup per CU that such a footprint allows loses more than the LDS staging wins (measured at 16 rows).  148 KiB
+// (all but the partial-sum slots of the 160 KiB LDS) rather than 100: the K = 11008 products keep their LDS staging at
+// 5 and 6 rows (decode step 3.18 -> 2.97 ms at batch 5, 3.24 -> 3.06 at batch 6, same box).
+constexpr size_t GEMV_XLDS_LIMIT_FEW_ROWS = 148 * 1024;
 
 // more than 64 KiB of dynamic LDS has to be requested once per kernel
 static inline bool gemv_allow_lds(const void* kernel, size_t bytes) {
