@@ -68,3 +68,21 @@ def test_dense_cache_policy_leaves_host_models_alone(monkeypatch):
     monkeypatch.setenv("BIGDL_TRAIN_DENSE_CACHE", "0")
     assert L.auto_train_dense_cache(model) is False
     monkeypatch.setattr(L, "_TRAIN_DENSE_CACHE", before)
+
+
+def test_attn_decode_splits_rule(monkeypatch):
+    from bigdl_amd.models.decoder import attn_decode_splits
+    monkeypatch.delenv("BIGDL_ATTN_SPLITS", raising=False)
+    # a lone sequence is cut to fill the chip, ranges of at least 256 keys
+    assert attn_decode_splits(1, 32, 1280) == 5
+    assert attn_decode_splits(1, 32, 8192) == 8
+    assert attn_decode_splits(1, 8, 8192) == 16
+    # from 64 (sequence, head) pairs on a range holds at least 1024 keys
+    assert attn_decode_splits(2, 32, 1280) == 1
+    assert attn_decode_splits(2, 32, 4352) == 4
+    assert attn_decode_splits(5, 32, 4352) == 1
+    assert attn_decode_splits(8, 8, 4352) == 4
+    assert attn_decode_splits(64, 32, 65536) == 1
+    monkeypatch.setenv("BIGDL_ATTN_SPLITS", "3")
+    assert attn_decode_splits(8, 32, 4352) == 3
+    assert attn_decode_splits(8, 32, 300) == 1
