@@ -731,19 +731,24 @@ static int launch_rt(const AttnArgs& a, hipStream_t st) {
     return -4;
   }
   if (rt == 1) {
-    // 64 keys per wavefront (16-byte fragments) once every workgroup has several iterations of work anyway: one KV
-    // split (enough (batch, head) pairs to fill the GPU) or a long cache.  Latency-bound launches with few keys per
-    // workgroup keep 32 keys per wavefront and more workgroups.
+    // 64 keys per wavefront (16-byte fragments).  With one KV split and fewer than 512 (sequence, head) pairs the
+    // workgroup has ATT_NW wavefronts; with several splits or 512 pairs and more it has four (below).
     if constexpr (FP8 && D % 128 == 0) {
       static const char* force = getenv("BIGDL_ATTN_KEYS");      // "32" / "64": override for measurements
-      const bool wide = force ? atoi(force) == 64 : (a.splits == 1 || a.Lmax / a.splits >= 2048);
+      const bool wide = force ? atoi(force) == 64 : true;
       // batched decode (512 or more (sequence, head) workgroups, one KV split): four-wavefront workgroups, so
       // that two of them share a CU and one streams keys while the other is in its softmax / merge phase.  Measured
       // on Llama-2-7B at 1024-token context: batch 64 9.36 -> 8.65 ms per step, batch 16 4.34 -> 4.20.  Tried on top
       // and dropped: two-wavefront workgroups (8.94), keys / values kept as bytes in registers (no fewer live
       // registers: 186 either way), a second register set that prefetches the next block (256 registers, 8.83).
       static const char* nw4 = getenv("BIGDL_ATTN_NW4");           // "0" / "1": override for measurements
-      const bool small = nw4 ? atoi(nw4) == 1 : (a.splits == 1 && (int64_t)a.B * a.Hkv * a.nchunk >= 512);
+      // Several KV splits (few pairs, each split a short key range): the same four-wavefront form, one 256-key pass
+      // per wavefront round instead of ATT_NW x 32 keys, and a four-way merge in LDS instead of an ATT_NW-way one.
+      // Measured per decode step on one MI355X, same box, 32-key ATT_NW-wavefront form -> this one: Llama-2-7B batch 1
+      // 1.551 -> 1.511 ms at 1024 keys, 1.875 -> 1.781 at 4096; Llama-3-8B 1.642 -> 1.612 / 1.834 -> 1.756;
+      // Qwen2-7B 1.557 -> 1.532 / 1.714 -> 1.637.  With ONE split and fewer than 512 pairs it loses (Llama-2-7B
+      // batch 2 at 1024 keys 1.857 -> 1.899), so that case keeps ATT_NW wavefronts.
+      const bool small = nw4 ? atoi(nw4) == 1 : (a.splits > 1 || (int64_t)a.B * a.Hkv * a.nchunk >= 512);
       if constexpr (D == 128) {
         static const char* occ = getenv("BIGDL_ATTN_OCC");         // wavefronts per SIMD the register budget allows
         if (wide && small && occ && atoi(occ) == 3) return launch_one<D, FP8, 1, 64, false, 4, 3>(a, smem, st);
